@@ -1,0 +1,84 @@
+"""Deterministic synthetic weights / inputs (no checkpoints or datasets exist
+offline: SURVEY.md §8c "Pretrained weights / real data: Absent").
+
+Values come from numpy's PCG64 stream keyed by (seed, parameter name) so the
+same tensors can be rebuilt bit-for-bit on the GPU box, in the golden-vector
+generator (tests/golden/make_golden.py, which loads them into the *reference*
+modules) and in bench.py.  Scales follow the reference initialisers in spirit
+(xavier-normal for Linear/Conv weights, model/utils.py:29-38; randn null
+embeddings, model/diffusion.py:137-138) with non-trivial biases / LayerNorm
+affine terms so every term of every formula is exercised.
+"""
+from __future__ import annotations
+
+import zlib
+from typing import Dict
+
+import numpy as np
+import torch
+
+from .spec import DenoiserSpec, param_shapes
+
+
+def _rng(seed: int, name: str) -> np.random.Generator:
+    return np.random.Generator(np.random.PCG64([seed, zlib.crc32(name.encode())]))
+
+
+def synthetic_tensor(seed: int, name: str, shape, scale: float = 1.0, shift: float = 0.0) -> torch.Tensor:
+    a = _rng(seed, name).standard_normal(size=tuple(shape), dtype=np.float64)
+    return torch.from_numpy((a * scale + shift).astype(np.float32))
+
+
+def synthetic_state_dict(spec: DenoiserSpec, seed: int = 10) -> Dict[str, torch.Tensor]:
+    sd: Dict[str, torch.Tensor] = {}
+    for name, shape in param_shapes(spec).items():
+        leaf = name.split(".")[-1]
+        is_norm = (".norm" in name or name.startswith("norm_cond") or name.startswith("frame_norm_cond")
+                   or name.startswith("non_attn_cond_projection.0"))
+        if name.startswith("null_"):
+            t = synthetic_tensor(seed, name, shape, 1.0)
+        elif is_norm and leaf == "weight":
+            t = synthetic_tensor(seed, name, shape, 0.1, 1.0)
+        elif is_norm and leaf == "bias":
+            t = synthetic_tensor(seed, name, shape, 0.1)
+        elif leaf in ("bias", "in_proj_bias"):
+            t = synthetic_tensor(seed, name, shape, 0.02)
+        else:  # Linear / Conv / in_proj weights: xavier-normal std
+            if len(shape) == 3:
+                fan_out, fan_in = shape[0] * shape[2], shape[1] * shape[2]
+            else:
+                fan_out, fan_in = shape[0], shape[1]
+            t = synthetic_tensor(seed, name, shape, float(np.sqrt(2.0 / (fan_in + fan_out))))
+        sd[name] = t
+    # rotary frequency buffer (model/modules/rotary_embedding_torch.py:99-101)
+    d = spec.latent_dim
+    sd["rotary.freqs"] = 1.0 / (10000 ** (torch.arange(0, d, 2)[: d // 2].float() / d))
+    return sd
+
+
+def synthetic_inputs(spec: DenoiserSpec, batch: int, frames: int, seed: int = 10,
+                     steps_of_noise: int = 0) -> Dict[str, torch.Tensor]:
+    """x_T, conditioning features (fed past the hoisted audio front end,
+    SURVEY.md §8d "Synthetic inputs"), keyframes, mask, optional per-step noise."""
+    n_tok = cond_tokens_for_frames(frames)
+    out = {
+        "x_T": synthetic_tensor(seed, "x_T", (batch, spec.nfeats, 1, frames)),
+        "cond_embed": synthetic_tensor(seed, "cond_embed", (batch, n_tok, spec.cond_feature_dim)),
+    }
+    if spec.is_pose:
+        nk = len(range(frames)[:: spec.keyframe_step])
+        out["keyframes"] = synthetic_tensor(seed, "keyframes", (batch, nk, spec.keyframe_dim))
+        out["mask"] = torch.ones(batch, 1, 1, frames, dtype=torch.bool)
+    if steps_of_noise:
+        out["step_noise"] = synthetic_tensor(seed, "step_noise", (steps_of_noise, batch, spec.nfeats, 1, frames))
+    return out
+
+
+def cond_tokens_for_frames(frames: int) -> int:
+    """vq-wav2vec token count for `frames` motion frames (1600 samples @48 kHz per
+    frame, 3:1 resample, conv strides 5,4,2,2,2 / kernels 10,8,4,4,4):
+    600 frames -> 1998, 240 -> 798 (model/diffusion.py:136, train/train_guide.py:316)."""
+    n = (frames * 1600) // 3
+    for k, s in ((10, 5), (8, 4), (4, 2), (4, 2), (4, 2)):
+        n = (n - k) // s + 1
+    return n
