@@ -1,0 +1,106 @@
+"""ctypes binding of liba2p_hip.so (include/a2p_hip.h).
+
+There is deliberately NO fallback: if the HIP library is missing or a call
+fails the product raises -- a CPU/eager path would silently void parity
+claims (the oracle lives in oracle/ and is test-only).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "liba2p_hip.so")
+
+FACE, POSE = 0, 1
+PREC_F32, PREC_BF16 = 0, 1
+PASS_COND, PASS_UNCOND, PASS_CFG = 0, 1, 2
+SAMPLER_DDIM, SAMPLER_DDPM = 0, 1
+KERNEL_GEMM, KERNEL_ATTN_SELF, KERNEL_ATTN_CROSS, KERNEL_LNROPE = 0, 1, 2, 3
+# a2p_table_id
+TABLE_NAMES = (
+    "posterior_mean_coef1", "posterior_mean_coef2", "posterior_variance", "posterior_log_variance_clipped",
+    "sqrt_recip_alphas_cumprod", "sqrt_recipm1_alphas_cumprod", "alphas_cumprod", "alphas_cumprod_prev",
+    "sqrt_alphas_cumprod", "sqrt_one_minus_alphas_cumprod",
+)
+
+EXPORTS = (
+    "a2p_ctx_create", "a2p_ctx_destroy", "a2p_last_error", "a2p_version", "a2p_set_weight", "a2p_finalize_weights",
+    "a2p_prepare_cond", "a2p_denoise_forward", "a2p_sample_step", "a2p_p_mean_variance", "a2p_ddim_update",
+    "a2p_p_sample_update", "a2p_q_sample", "a2p_decoder_layer_forward", "a2p_gemm", "a2p_attention",
+    "a2p_kernel_timing", "a2p_kernel_time_ms",
+)
+
+
+class A2PConfig(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in (
+        "data_format", "nfeats", "latent_dim", "ff_size", "num_layers", "num_heads", "cond_feature_dim",
+        "max_frames", "emb_len", "keyframe_dim", "keyframe_step", "precision", "max_batch", "reserved")]
+
+
+class A2PError(RuntimeError):
+    pass
+
+
+_lib: Optional[C.CDLL] = None
+
+
+def load() -> C.CDLL:
+    """Load the shared library or raise (never falls back)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise A2PError(
+            f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(hipcc --offload-arch=gfx950).  There is no CPU fallback.")
+    lib = C.CDLL(LIB_PATH)
+    vp, i32, i64, f32 = C.c_void_p, C.c_int32, C.c_int64, C.c_float
+    lib.a2p_last_error.restype = C.c_char_p
+    lib.a2p_version.restype = C.c_char_p
+    sig = {
+        "a2p_ctx_create": [C.POINTER(A2PConfig), C.POINTER(vp)],
+        "a2p_ctx_destroy": [vp],
+        "a2p_set_weight": [vp, C.c_char_p, vp, i64, vp],
+        "a2p_finalize_weights": [vp, vp],
+        "a2p_prepare_cond": [vp, vp, i32, i32, vp, vp, i32, i32, vp],
+        "a2p_denoise_forward": [vp, vp, vp, vp, i32, vp, vp],
+        "a2p_sample_step": [vp, i32, vp, vp, vp, vp, i32, vp, vp, f32, i32, vp, vp, vp],
+        "a2p_p_mean_variance": [vp, vp, vp, vp, i32, i32, i32, i32, i32, vp, vp, vp],
+        "a2p_ddim_update": [vp, vp, vp, vp, i32, vp, f32, i32, i64, vp, vp],
+        "a2p_p_sample_update": [vp, vp, vp, i32, vp, i32, i64, vp, vp],
+        "a2p_q_sample": [vp, vp, vp, i32, vp, i32, i64, vp, vp],
+        "a2p_decoder_layer_forward": [vp, i32, vp, vp, vp, vp, i32, i32, i32, i32, vp],
+        "a2p_gemm": [vp, vp, vp, vp, vp, i32, i32, i32, vp],
+        "a2p_attention": [vp, vp, vp, vp, vp, i32, i32, i32, vp],
+        "a2p_kernel_timing": [vp, i32, i32],
+        "a2p_kernel_time_ms": [vp, C.POINTER(C.c_double), C.POINTER(i64)],
+    }
+    for name, args in sig.items():
+        fn = getattr(lib, name)
+        fn.argtypes = args
+        fn.restype = C.c_int
+    _lib = lib
+    return lib
+
+
+def check(rc: int, what: str) -> int:
+    if rc < 0:
+        raise A2PError(f"{what} failed ({rc}): {load().a2p_last_error().decode()}")
+    return rc
+
+
+def ptr(t) -> Optional[int]:
+    """Device pointer of a torch tensor (None passes NULL)."""
+    return None if t is None else t.data_ptr()
+
+
+def current_stream() -> int:
+    import torch
+    return torch.cuda.current_stream().cuda_stream
+
+
+def require_gpu_tensor(t, name: str):
+    if not t.is_cuda:
+        raise A2PError(f"{name} must live on the MI355X (got device {t.device}); the hot path has no CPU implementation")

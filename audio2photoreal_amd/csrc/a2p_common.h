@@ -1,0 +1,72 @@
+// Shared device helpers for the gfx950 (CDNA4) kernels: MFMA fragment traits for the two
+// compute precisions, wave64 reductions, activation functions.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef __bf16 bf16_t;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+
+// One MFMA "k-chunk": KCH k-values per instruction, each lane holding EPL contiguous
+// k-values of row/col (lane & 15), k-group (lane >> 4).  C/D layout for both:
+// col = lane & 15, row = (lane >> 4) * 4 + reg   (cdna_hip_programming.md §3).
+template <typename T>
+struct Prec;
+
+template <>
+struct Prec<float> {  // v_mfma_f32_16x16x4_f32: exact fp32, 1/16 of the bf16 rate
+  using Frag = float;
+  static constexpr int KCH = 4;
+  static constexpr int EPL = 1;
+  __device__ static __forceinline__ f32x4 mfma(Frag a, Frag b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+  }
+  __device__ static __forceinline__ Frag load(const float* p) { return *p; }
+};
+
+template <>
+struct Prec<bf16_t> {  // v_mfma_f32_16x16x32_bf16
+  using Frag = bf16x8;
+  static constexpr int KCH = 32;
+  static constexpr int EPL = 8;
+  __device__ static __forceinline__ f32x4 mfma(Frag a, Frag b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+  }
+  __device__ static __forceinline__ Frag load(const bf16_t* p) { return *reinterpret_cast<const bf16x8*>(p); }
+};
+
+__device__ __forceinline__ float to_f32(float v) { return v; }
+__device__ __forceinline__ float to_f32(bf16_t v) { return (float)v; }
+template <typename T>
+__device__ __forceinline__ T from_f32(float v);
+template <>
+__device__ __forceinline__ float from_f32<float>(float v) { return v; }
+template <>
+__device__ __forceinline__ bf16_t from_f32<bf16_t>(float v) { return (bf16_t)v; }
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+// activations (torch definitions)
+__device__ __forceinline__ float act_gelu(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+__device__ __forceinline__ float act_softplus(float x) { return x > 20.0f ? x : log1pf(expf(x)); }
+__device__ __forceinline__ float act_mish(float x) { return x * tanhf(act_softplus(x)); }
+__device__ __forceinline__ float act_silu(float x) { return x / (1.0f + expf(-x)); }
+__device__ __forceinline__ float act_lrelu02(float x) { return x > 0.0f ? x : 0.2f * x; }
+
+enum { ACT_NONE = 0, ACT_GELU = 1, ACT_MISH = 2, ACT_SILU = 3, ACT_LRELU = 4 };
+
+__device__ __forceinline__ float apply_act(float x, int act) {
+  switch (act) {
+    case ACT_GELU: return act_gelu(x);
+    case ACT_MISH: return act_mish(x);
+    case ACT_SILU: return act_silu(x);
+    case ACT_LRELU: return act_lrelu02(x);
+    default: return x;
+  }
+}

@@ -1,0 +1,543 @@
+// liba2p_hip.so -- host orchestration + C ABI (include/a2p_hip.h) of the MI355X-native
+// audio2photoreal sampling hot path.  One translation unit: device kernels live in the headers.
+//
+// Data layout in HBM (all owned by the context, sized once for max_batch):
+//   residual stream x        fp32 [N*T, d]           N = sequences (2B under classifier-free guidance)
+//   activations xn/xr/q/k/o  T    [N*T, d|2d]        T = fp32 (parity mode) or bf16 (throughput mode)
+//   V^T (self attention)     T    [N][d][T_ld]       transposed by the producing GEMM epilogue
+//   audio K cache            T    [B+1][S_ld][L*d]   slot 0 = batch-invariant unconditional branch
+//   audio V^T cache          T    [B+1][L*d][S_ld]
+//   keyframe K / V^T cache   T    [B+1][64][L*d] / [B+1][L*d][64]     (pose)
+//   FiLM scale|shift         fp32 [N][L][F][2d]      regenerated every step from the time path
+//   time-token K / V tail    fp32 [B*2][L*d]
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/a2p_hip.h"
+#include "kernels_attn.h"
+#include "kernels_gemm.h"
+#include "kernels_misc.h"
+
+static thread_local char g_err[1024] = "";
+static void set_err(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+#define HIPCHK(x)                                                                 \
+  do {                                                                            \
+    hipError_t e_ = (x);                                                          \
+    if (e_ != hipSuccess) {                                                       \
+      set_err("%s:%d %s -> %s", __FILE__, __LINE__, #x, hipGetErrorString(e_));   \
+      return A2P_ERR_HIP;                                                         \
+    }                                                                             \
+  } while (0)
+#define CHK(x)            \
+  do {                    \
+    int r_ = (x);         \
+    if (r_ < 0) return r_; \
+  } while (0)
+#define ARG(cond, ...)       \
+  do {                       \
+    if (!(cond)) {           \
+      set_err(__VA_ARGS__);  \
+      return A2P_ERR_ARG;    \
+    }                        \
+  } while (0)
+
+struct Buf {
+  void* p = nullptr;
+  size_t bytes = 0;
+  float* f() const { return reinterpret_cast<float*>(p); }
+};
+
+static int buf_alloc(Buf& b, size_t bytes) {
+  if (b.p) {
+    hipFree(b.p);
+    b.p = nullptr;
+  }
+  if (bytes == 0) bytes = 16;
+  HIPCHK(hipMalloc(&b.p, bytes));
+  HIPCHK(hipMemset(b.p, 0, bytes));
+  b.bytes = bytes;
+  return 0;
+}
+static void buf_free(Buf& b) {
+  if (b.p) hipFree(b.p);
+  b.p = nullptr;
+  b.bytes = 0;
+}
+static inline int rup(int v, int m) { return (v + m - 1) / m * m; }
+
+struct a2p_ctx {
+  a2p_config cfg;
+  int d, H, DH, L, C, Cpad, ff, F, Fc, FcPad, Kd, KdPad, Tmax, Tld, S0max, Sld, Bmax, Nmax, KFmax;
+  bool bf16, pose;
+  size_t esz;
+  int64_t rows_cap, conv_rows;
+  std::map<std::string, Buf> w;   // fp32 parameters by reference state_dict key
+  std::map<std::string, Buf> wt;  // compute-dtype copies [N, Kpad]
+  bool finalized = false, prepared = false;
+  Buf rope_cs, time_freq, film_w, film_b, tct_w, tct_b;
+  Buf cak_w32, cak_b, cav_w32, cav_b, cak_wt, cav_wt;
+  Buf ca2k_wt, ca2v_wt, ca2k_b, ca2v_b;
+  Buf conv_wt[7];
+  Buf hidden, kc, vtc, k2c, vt2c, slot_cond, slot_unc, slot_cfg;
+  std::vector<int> h_slots;
+  int pB = 0, pS0 = 0, pT = 0, pK = 0;
+  // workspaces
+  Buf x, xn, xr, qk, vt, ao, hff, inpack, mo, cb[4];
+  Buf emb, th, tct, tvec, mt, tokn, tokr, film, ktail, vtail;
+  Buf ce_pack, pooled, tmpa, tmpb, kf_pack, kf_tok;
+  // timing
+  int time_kind = -1;
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> evs;
+  std::vector<hipEvent_t> ev_pool;
+
+  void* offT(const Buf& b, int64_t elems) const { return reinterpret_cast<char*>(b.p) + elems * (int64_t)esz; }
+  void* offT(void* p, int64_t elems) const { return reinterpret_cast<char*>(p) + elems * (int64_t)esz; }
+};
+
+// ------------------------------------------------------------------------------------------------
+// launch helpers
+// ------------------------------------------------------------------------------------------------
+struct KernelTimer {
+  a2p_ctx* c;
+  hipStream_t s;
+  bool on;
+  hipEvent_t e0, e1;
+  KernelTimer(a2p_ctx* ctx, int kind, hipStream_t st) : c(ctx), s(st), on(ctx && ctx->time_kind == kind) {
+    if (on) {
+      hipEventCreate(&e0);
+      hipEventCreate(&e1);
+      hipEventRecord(e0, s);
+    }
+  }
+  ~KernelTimer() {
+    if (on) {
+      hipEventRecord(e1, s);
+      c->evs.push_back({e0, e1});
+    }
+  }
+};
+
+static GemmP gemm_base(const void* A, int64_t lda, const void* W, int64_t ldw, const float* bias, void* out, int64_t ldo,
+                       int M, int N, int K) {
+  GemmP p;
+  memset(&p, 0, sizeof(p));
+  p.A = A; p.lda = lda; p.W = W; p.ldw = ldw; p.bias = bias; p.out = out; p.ldo = ldo;
+  p.M = M; p.N = N; p.K = K; p.ntaps = 1; p.epi = EPI_STORE; p.act = ACT_NONE; p.rows_per_seq = 1;
+  return p;
+}
+
+static int launch_gemm(a2p_ctx* c, const GemmP& p, hipStream_t s) {
+  const int bk = c->bf16 ? 64 : 32;
+  ARG(p.K % bk == 0 && p.N % 4 == 0 && p.M > 0, "gemm: bad shape M=%d N=%d K=%d", p.M, p.N, p.K);
+  dim3 grid((p.N + 127) / 128, (p.M + 127) / 128);
+  KernelTimer kt(c, A2P_KERNEL_GEMM, s);
+  if (c->bf16)
+    gemm_kernel<bf16_t><<<grid, 256, 0, s>>>(p);
+  else
+    gemm_kernel<float><<<grid, 256, 0, s>>>(p);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+static int launch_skinny(const float* A, int64_t lda, const float* W, int64_t ldw, const float* bias, float* out, int64_t ldo,
+                         int M, int N, int K, int act, hipStream_t s) {
+  ARG(K % 64 == 0 && N % 16 == 0, "skinny gemm: bad shape N=%d K=%d", N, K);
+  for (int m0 = 0; m0 < M; m0 += 64) {
+    SkinnyP p;
+    p.A = A + (int64_t)m0 * lda; p.W = W; p.bias = bias; p.out = out + (int64_t)m0 * ldo;
+    p.lda = lda; p.ldw = ldw; p.ldo = ldo; p.M = (M - m0 < 64) ? M - m0 : 64; p.N = N; p.K = K; p.act = act;
+    skinny_gemm_kernel<<<N / 16, 256, 0, s>>>(p);
+  }
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+static int launch_ln_rope(a2p_ctx* c, bool as_f32, const float* x, int64_t ldx, const float* gamma, const float* beta,
+                          void* out_n, void* out_r, int64_t ldo, int rows, int rows_per_seq, int pos_off, hipStream_t s) {
+  LnRopeP p;
+  p.x = x; p.ldx = ldx; p.gamma = gamma; p.beta = beta; p.cs = reinterpret_cast<const float2*>(c->rope_cs.p);
+  p.out_n = out_n; p.out_r = out_r; p.ldo = ldo; p.rows = rows; p.rows_per_seq = rows_per_seq; p.pos_off = pos_off;
+  const int grid = (rows + 3) / 4;
+  KernelTimer kt(c, A2P_KERNEL_LNROPE, s);
+  const bool b16 = c->bf16 && !as_f32;
+  if (c->d == 512) {
+    if (b16) ln_rope_kernel<bf16_t, 8><<<grid, 256, 0, s>>>(p);
+    else ln_rope_kernel<float, 8><<<grid, 256, 0, s>>>(p);
+  } else {
+    if (b16) ln_rope_kernel<bf16_t, 4><<<grid, 256, 0, s>>>(p);
+    else ln_rope_kernel<float, 4><<<grid, 256, 0, s>>>(p);
+  }
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+static int launch_attn(a2p_ctx* c, const AttnP& p, int nseq, int kind, hipStream_t s) {
+  dim3 grid((p.Tq + 127) / 128, c->H, nseq);
+  KernelTimer kt(c, kind, s);
+  if (c->DH == 64) {
+    if (c->bf16) attn_kernel<bf16_t, 64><<<grid, 256, 0, s>>>(p);
+    else attn_kernel<float, 64><<<grid, 256, 0, s>>>(p);
+  } else {
+    if (c->bf16) attn_kernel<bf16_t, 32><<<grid, 256, 0, s>>>(p);
+    else attn_kernel<float, 32><<<grid, 256, 0, s>>>(p);
+  }
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+static int launch_cast(a2p_ctx* c, const float* src, int64_t lds, void* dst, int64_t ldd, int64_t rows, int cols, int cols_pad,
+                       const uint8_t* keep, hipStream_t s, int src_col_stride = 1) {
+  const int64_t n = rows * cols_pad;
+  const int grid = (int)((n + 255) / 256);
+  if (c->bf16) cast_pad_kernel<bf16_t><<<grid, 256, 0, s>>>(src, lds, src_col_stride, (bf16_t*)dst, ldd, rows, cols, cols_pad, keep);
+  else cast_pad_kernel<float><<<grid, 256, 0, s>>>(src, lds, src_col_stride, (float*)dst, ldd, rows, cols, cols_pad, keep);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// weights
+// ------------------------------------------------------------------------------------------------
+static const char* kFilmNames[4] = {"film1", "film2", "film3", "film2a"};
+
+static bool ignorable_weight(const std::string& n) {
+  auto starts = [&](const char* p) { return n.rfind(p, 0) == 0; };
+  if (starts("audio_model.") || starts("lip_model.") || starts("transformer.") || starts("tokenizer.")) return true;
+  const std::string suf = "rotary.freqs";
+  if (n.size() >= suf.size() && n.compare(n.size() - suf.size(), suf.size(), suf) == 0) return true;
+  return false;
+}
+
+static void expected_weights(const a2p_ctx* c, std::map<std::string, int64_t>& e) {
+  const int64_t d = c->d, C = c->C, ff = c->ff;
+  e["null_cond_embed"] = (int64_t)c->cfg.emb_len * d;
+  e["null_cond_hidden"] = d;
+  e["time_mlp.1.weight"] = 4 * d * d; e["time_mlp.1.bias"] = 4 * d;
+  e["to_time_cond.0.weight"] = d * 4 * d; e["to_time_cond.0.bias"] = d;
+  e["to_time_tokens.0.weight"] = 2 * d * 4 * d; e["to_time_tokens.0.bias"] = 2 * d;
+  e["norm_cond.weight"] = d; e["norm_cond.bias"] = d;
+  e["input_projection.weight"] = d * C; e["input_projection.bias"] = d;
+  e["cond_projection.weight"] = d * c->Fc; e["cond_projection.bias"] = d;
+  e["non_attn_cond_projection.0.weight"] = d; e["non_attn_cond_projection.0.bias"] = d;
+  e["non_attn_cond_projection.1.weight"] = d * d; e["non_attn_cond_projection.1.bias"] = d;
+  e["non_attn_cond_projection.3.weight"] = d * d; e["non_attn_cond_projection.3.bias"] = d;
+  e["final_layer.weight"] = C * d; e["final_layer.bias"] = C;
+  auto attn = [&](const std::string& p) {
+    e[p + ".in_proj_weight"] = 3 * d * d; e[p + ".in_proj_bias"] = 3 * d;
+    e[p + ".out_proj.weight"] = d * d; e[p + ".out_proj.bias"] = d;
+  };
+  auto norm = [&](const std::string& p) { e[p + ".weight"] = d; e[p + ".bias"] = d; };
+  if (c->pose) {
+    e["null_pose_embed"] = (int64_t)c->KFmax * d;
+    e["frame_cond_projection.weight"] = d * c->Kd; e["frame_cond_projection.bias"] = d;
+    norm("frame_norm_cond");
+    const int64_t hid = C > 256 ? C : 256;
+    const int64_t ci[6] = {C, hid, C, C, C, C}, co[6] = {hid, C, C, C, C, C};
+    for (int i = 0; i < 6; ++i) {
+      e["post_pose_layers." + std::to_string(i) + ".weight"] = co[i] * ci[i] * 3;
+      e["post_pose_layers." + std::to_string(i) + ".bias"] = co[i];
+    }
+    e["final_conv.weight"] = C * C; e["final_conv.bias"] = C;
+  } else {
+    for (int i = 0; i < 2; ++i) {
+      const std::string p = "cond_encoder." + std::to_string(i) + ".";
+      attn(p + "self_attn");
+      e[p + "linear1.weight"] = ff * d; e[p + "linear1.bias"] = ff;
+      e[p + "linear2.weight"] = d * ff; e[p + "linear2.bias"] = d;
+      norm(p + "norm1"); norm(p + "norm2");
+    }
+  }
+  for (int l = 0; l < c->L; ++l) {
+    const std::string p = "seqTransDecoder.stack." + std::to_string(l) + ".";
+    attn(p + "self_attn"); attn(p + "multihead_attn");
+    if (c->pose) attn(p + "multihead_attn2");
+    e[p + "linear1.weight"] = ff * d; e[p + "linear1.bias"] = ff;
+    e[p + "linear2.weight"] = d * ff; e[p + "linear2.bias"] = d;
+    norm(p + "norm1"); norm(p + "norm2"); norm(p + "norm3");
+    if (c->pose) norm(p + "norm2a");
+    for (int f = 0; f < c->F; ++f) {
+      e[p + kFilmNames[f] + ".block.1.weight"] = 2 * d * d;
+      e[p + kFilmNames[f] + ".block.1.bias"] = 2 * d;
+    }
+  }
+}
+
+static float* W32(a2p_ctx* c, const std::string& n) { return c->w.at(n).f(); }
+
+// compute-dtype copy of a [rows, cols] fp32 matrix, K padded to a multiple of 64
+static int make_wt(a2p_ctx* c, const std::string& name, const float* src, int rows, int cols, hipStream_t s, Buf* into = nullptr) {
+  const int kp = rup(cols, 64);
+  Buf& b = into ? *into : c->wt[name];
+  CHK(buf_alloc(b, (size_t)rows * kp * c->esz));
+  return launch_cast(c, src, cols, b.p, kp, rows, cols, kp, nullptr, s);
+}
+
+// ------------------------------------------------------------------------------------------------
+// context
+// ------------------------------------------------------------------------------------------------
+extern "C" const char* a2p_last_error(void) { return g_err; }
+extern "C" const char* a2p_version(void) { return "a2p_hip 0.1 (gfx950)"; }
+
+extern "C" int a2p_ctx_create(const a2p_config* cfg, a2p_ctx** out) {
+  ARG(cfg && out, "null argument");
+  ARG(cfg->latent_dim == 256 || cfg->latent_dim == 512, "latent_dim must be 256 or 512 (got %d)", cfg->latent_dim);
+  ARG(cfg->num_heads > 0 && cfg->latent_dim % cfg->num_heads == 0, "bad num_heads");
+  const int dh = cfg->latent_dim / cfg->num_heads;
+  ARG(dh == 32 || dh == 64, "head_dim must be 32 or 64 (got %d)", dh);
+  ARG(cfg->ff_size % 64 == 0 && cfg->nfeats % 4 == 0 && cfg->nfeats <= 256, "bad ff_size/nfeats");
+  ARG(cfg->max_batch >= 1 && cfg->max_frames >= 16 && cfg->emb_len >= 16 && cfg->num_layers >= 1, "bad capacity");
+  ARG(cfg->precision == A2P_PREC_F32 || cfg->precision == A2P_PREC_BF16, "bad precision");
+  a2p_ctx* c = new a2p_ctx();
+  c->cfg = *cfg;
+  c->d = cfg->latent_dim; c->H = cfg->num_heads; c->DH = dh; c->L = cfg->num_layers; c->C = cfg->nfeats;
+  c->Cpad = rup(cfg->nfeats, 64); c->ff = cfg->ff_size; c->pose = cfg->data_format == A2P_POSE; c->F = c->pose ? 4 : 3;
+  c->Fc = cfg->cond_feature_dim; c->FcPad = rup(c->Fc, 64); c->Kd = cfg->keyframe_dim; c->KdPad = rup(c->Kd, 64);
+  c->Tmax = cfg->max_frames; c->S0max = cfg->emb_len; c->Sld = rup(cfg->emb_len + 2, 64);
+  c->Tld = rup(c->Tmax, 64) > c->Sld ? rup(c->Tmax, 64) : c->Sld;
+  c->Bmax = cfg->max_batch; c->Nmax = 2 * c->Bmax;
+  c->KFmax = (c->Tmax + cfg->keyframe_step - 1) / cfg->keyframe_step;
+  c->bf16 = cfg->precision == A2P_PREC_BF16; c->esz = c->bf16 ? 2 : 4;
+  ARG(c->KFmax <= 64, "too many keyframes");
+  const int64_t r1 = (int64_t)c->Nmax * c->Tmax, r2 = (int64_t)c->Bmax * c->S0max;
+  c->rows_cap = (r1 > r2 ? r1 : r2) + 128;
+  c->conv_rows = (int64_t)c->Nmax * (c->Tmax + 24) + 64;
+  const int64_t R = c->rows_cap, d = c->d;
+  int rc = 0;
+  auto A = [&](Buf& b, size_t bytes) { if (rc == 0) rc = buf_alloc(b, bytes); };
+  A(c->x, R * d * 4); A(c->xn, R * d * c->esz); A(c->xr, R * d * c->esz); A(c->qk, R * 2 * d * c->esz);
+  A(c->ao, R * d * c->esz); A(c->hff, R * c->ff * c->esz);
+  A(c->vt, (size_t)c->Nmax * d * c->Tld * c->esz);
+  A(c->inpack, (size_t)c->Bmax * c->Tmax * c->Cpad * c->esz);
+  A(c->mo, (size_t)c->conv_rows * c->C * 4);
+  if (c->pose) {
+    A(c->cb[0], (size_t)c->conv_rows * 128 * c->esz); A(c->cb[1], (size_t)c->conv_rows * 256 * c->esz);
+    A(c->cb[2], (size_t)c->conv_rows * 128 * c->esz); A(c->cb[3], (size_t)c->conv_rows * 128 * c->esz);
+  }
+  const int64_t B = c->Bmax, N = c->Nmax, LF = (int64_t)c->L * c->F;
+  A(c->emb, B * d * 4); A(c->th, B * 4 * d * 4); A(c->tct, B * 3 * d * 4); A(c->tvec, N * d * 4); A(c->mt, N * d * 4);
+  A(c->tokn, B * 2 * d * 4); A(c->tokr, B * 2 * d * 4); A(c->film, N * LF * 2 * d * 4);
+  A(c->ktail, B * 2 * c->L * d * 4); A(c->vtail, B * 2 * c->L * d * 4);
+  A(c->ce_pack, (size_t)B * c->S0max * c->FcPad * c->esz);
+  A(c->pooled, B * d * 4); A(c->tmpa, B * d * 4); A(c->tmpb, B * d * 4);
+  A(c->hidden, (B + 1) * d * 4);
+  A(c->kc, (size_t)(B + 1) * c->Sld * c->L * d * c->esz); A(c->vtc, (size_t)(B + 1) * c->L * d * c->Sld * c->esz);
+  if (c->pose) {
+    A(c->k2c, (size_t)(B + 1) * 64 * c->L * d * c->esz); A(c->vt2c, (size_t)(B + 1) * c->L * d * 64 * c->esz);
+    A(c->kf_pack, (size_t)B * c->KFmax * c->KdPad * c->esz); A(c->kf_tok, (size_t)B * c->KFmax * d * 4);
+  }
+  A(c->slot_cond, B * 4); A(c->slot_unc, B * 4); A(c->slot_cfg, N * 4);
+  if (rc != 0) {
+    a2p_ctx_destroy(c);
+    return rc;
+  }
+  *out = c;
+  return 0;
+}
+
+extern "C" int a2p_ctx_destroy(a2p_ctx* c) {
+  if (!c) return 0;
+  hipDeviceSynchronize();
+  for (auto& kv : c->w) buf_free(kv.second);
+  for (auto& kv : c->wt) buf_free(kv.second);
+  Buf* all[] = {&c->rope_cs, &c->time_freq, &c->film_w, &c->film_b, &c->tct_w, &c->tct_b, &c->cak_w32, &c->cak_b, &c->cav_w32,
+                &c->cav_b, &c->cak_wt, &c->cav_wt, &c->ca2k_wt, &c->ca2v_wt, &c->ca2k_b, &c->ca2v_b, &c->hidden, &c->kc, &c->vtc,
+                &c->k2c, &c->vt2c, &c->slot_cond, &c->slot_unc, &c->slot_cfg, &c->x, &c->xn, &c->xr, &c->qk, &c->vt, &c->ao,
+                &c->hff, &c->inpack, &c->mo, &c->cb[0], &c->cb[1], &c->cb[2], &c->cb[3], &c->emb, &c->th, &c->tct, &c->tvec,
+                &c->mt, &c->tokn, &c->tokr, &c->film, &c->ktail, &c->vtail, &c->ce_pack, &c->pooled, &c->tmpa, &c->tmpb,
+                &c->kf_pack, &c->kf_tok};
+  for (Buf* b : all) buf_free(*b);
+  for (int i = 0; i < 7; ++i) buf_free(c->conv_wt[i]);
+  for (auto& e : c->evs) {
+    hipEventDestroy(e.first);
+    hipEventDestroy(e.second);
+  }
+  delete c;
+  return 0;
+}
+
+extern "C" int a2p_set_weight(a2p_ctx* c, const char* name, const float* data, int64_t numel, void* stream) {
+  ARG(c && name && data, "null argument");
+  const std::string n(name);
+  if (ignorable_weight(n)) return 1;
+  std::map<std::string, int64_t> e;
+  expected_weights(c, e);
+  auto it = e.find(n);
+  if (it == e.end()) {
+    set_err("unexpected parameter '%s' (reference: load_model asserts no unexpected keys)", name);
+    return A2P_ERR_NOWEIGHT;
+  }
+  if (it->second != numel) {
+    set_err("parameter '%s': expected %lld elements, got %lld", name, (long long)it->second, (long long)numel);
+    return A2P_ERR_NOWEIGHT;
+  }
+  Buf& b = c->w[n];
+  CHK(buf_alloc(b, (size_t)numel * 4));
+  HIPCHK(hipMemcpyAsync(b.p, data, (size_t)numel * 4, hipMemcpyDefault, (hipStream_t)stream));
+  c->finalized = false;
+  c->prepared = false;
+  return 0;
+}
+
+// K / V^T of `rows` memory tokens (already normalised+rotated in xr / normalised in xn) for all layers
+static int project_kv_all(a2p_ctx* c, const void* xr, const void* xn, int rows, int rows_per_seq, const Buf& kw, const float* kb,
+                          const Buf& vw, const float* vb, void* kdst, int kslot_rows, void* vtdst, int first_slot, hipStream_t s) {
+  const int d = c->d, LD = c->L * d;
+  GemmP pk = gemm_base(xr, d, kw.p, d, kb, kdst, LD, rows, LD, d);
+  pk.rows_per_seq = rows_per_seq;
+  // row remap: (seq, s) -> (first_slot + seq) * kslot_rows + s     (handled through out pointer + seq pad)
+  pk.out = c->offT(kdst, (int64_t)first_slot * kslot_rows * LD);
+  pk.epi = EPI_STORE;
+  pk.out_seq_pad = kslot_rows - rows_per_seq;
+  CHK(launch_gemm(c, pk, s));
+  GemmP pv = gemm_base(xn, d, vw.p, d, vb, vtdst, kslot_rows, rows, LD, d);
+  pv.epi = EPI_STORE_T;
+  pv.rows_per_seq = rows_per_seq;
+  pv.t_seq_stride = (int64_t)LD * kslot_rows;
+  pv.out = c->offT(vtdst, (int64_t)first_slot * LD * kslot_rows);
+  CHK(launch_gemm(c, pv, s));
+  return 0;
+}
+
+extern "C" int a2p_finalize_weights(a2p_ctx* c, void* stream) {
+  ARG(c, "null ctx");
+  hipStream_t s = (hipStream_t)stream;
+  std::map<std::string, int64_t> e;
+  expected_weights(c, e);
+  for (auto& kv : e)
+    if (!c->w.count(kv.first)) {
+      set_err("missing parameter '%s'", kv.first.c_str());
+      return A2P_ERR_NOWEIGHT;
+    }
+  const int d = c->d, L = c->L, F = c->F;
+  // rotary table: freqs_i = 1 / 10000^(2i/d) in fp32 exactly like the reference buffer
+  {
+    std::vector<float> fr(d / 2);
+    for (int i = 0; i < d / 2; ++i) fr[i] = 1.0f / powf(10000.0f, (float)(2 * i) / (float)d);
+    Buf tmp;
+    CHK(buf_alloc(tmp, fr.size() * 4));
+    HIPCHK(hipMemcpy(tmp.p, fr.data(), fr.size() * 4, hipMemcpyHostToDevice));
+    const int npos = c->Sld > c->Tld ? c->Sld : c->Tld;
+    CHK(buf_alloc(c->rope_cs, (size_t)npos * (d / 2) * 8));
+    rope_table_kernel<<<(npos * (d / 2) + 255) / 256, 256, 0, s>>>(tmp.f(), (float2*)c->rope_cs.p, npos, d / 2);
+    HIPCHK(hipStreamSynchronize(s));
+    buf_free(tmp);
+    // SinusoidalPosEmb frequencies (model/utils.py:73-75): exp(arange(half) * -(ln 1e4 / (half-1))), fp32
+    const int half = d / 2;
+    std::vector<float> tf(half);
+    const float em = (float)(-(log(10000.0) / (half - 1)));
+    for (int k = 0; k < half; ++k) tf[k] = expf((float)k * em);
+    CHK(buf_alloc(c->time_freq, half * 4));
+    HIPCHK(hipMemcpy(c->time_freq.p, tf.data(), half * 4, hipMemcpyHostToDevice));
+  }
+  // compute-dtype copies of every GEMM weight
+  CHK(make_wt(c, "input_projection.weight", W32(c, "input_projection.weight"), d, c->C, s));
+  CHK(make_wt(c, "cond_projection.weight", W32(c, "cond_projection.weight"), d, c->Fc, s));
+  CHK(make_wt(c, "final_layer.weight", W32(c, "final_layer.weight"), c->C, d, s));
+  if (c->pose) CHK(make_wt(c, "frame_cond_projection.weight", W32(c, "frame_cond_projection.weight"), d, c->Kd, s));
+  auto attn_wt = [&](const std::string& p) -> int {
+    CHK(make_wt(c, p + ".in_proj_weight", W32(c, p + ".in_proj_weight"), 3 * d, d, s));
+    CHK(make_wt(c, p + ".out_proj.weight", W32(c, p + ".out_proj.weight"), d, d, s));
+    return 0;
+  };
+  if (!c->pose)
+    for (int i = 0; i < 2; ++i) {
+      const std::string p = "cond_encoder." + std::to_string(i) + ".";
+      CHK(attn_wt(p + "self_attn"));
+      CHK(make_wt(c, p + "linear1.weight", W32(c, p + "linear1.weight"), c->ff, d, s));
+      CHK(make_wt(c, p + "linear2.weight", W32(c, p + "linear2.weight"), d, c->ff, s));
+    }
+  // stacked per-layer tensors
+  CHK(buf_alloc(c->film_w, (size_t)L * F * 2 * d * d * 4)); CHK(buf_alloc(c->film_b, (size_t)L * F * 2 * d * 4));
+  CHK(buf_alloc(c->cak_w32, (size_t)L * d * d * 4)); CHK(buf_alloc(c->cav_w32, (size_t)L * d * d * 4));
+  CHK(buf_alloc(c->cak_b, (size_t)L * d * 4)); CHK(buf_alloc(c->cav_b, (size_t)L * d * 4));
+  Buf ca2k32, ca2v32;
+  if (c->pose) {
+    CHK(buf_alloc(ca2k32, (size_t)L * d * d * 4)); CHK(buf_alloc(ca2v32, (size_t)L * d * d * 4));
+    CHK(buf_alloc(c->ca2k_b, (size_t)L * d * 4)); CHK(buf_alloc(c->ca2v_b, (size_t)L * d * 4));
+  }
+  auto d2d = [&](void* dst, const void* src, size_t bytes) { return hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, s); };
+  for (int l = 0; l < L; ++l) {
+    const std::string p = "seqTransDecoder.stack." + std::to_string(l) + ".";
+    CHK(attn_wt(p + "self_attn"));
+    CHK(attn_wt(p + "multihead_attn"));
+    if (c->pose) CHK(attn_wt(p + "multihead_attn2"));
+    CHK(make_wt(c, p + "linear1.weight", W32(c, p + "linear1.weight"), c->ff, d, s));
+    CHK(make_wt(c, p + "linear2.weight", W32(c, p + "linear2.weight"), d, c->ff, s));
+    for (int f = 0; f < F; ++f) {
+      HIPCHK(d2d(c->film_w.f() + ((size_t)(l * F + f) * 2 * d) * d, W32(c, p + kFilmNames[f] + ".block.1.weight"), (size_t)2 * d * d * 4));
+      HIPCHK(d2d(c->film_b.f() + (size_t)(l * F + f) * 2 * d, W32(c, p + kFilmNames[f] + ".block.1.bias"), (size_t)2 * d * 4));
+    }
+    const float* iw = W32(c, p + "multihead_attn.in_proj_weight");
+    const float* ib = W32(c, p + "multihead_attn.in_proj_bias");
+    HIPCHK(d2d(c->cak_w32.f() + (size_t)l * d * d, iw + (size_t)d * d, (size_t)d * d * 4));
+    HIPCHK(d2d(c->cav_w32.f() + (size_t)l * d * d, iw + (size_t)2 * d * d, (size_t)d * d * 4));
+    HIPCHK(d2d(c->cak_b.f() + (size_t)l * d, ib + d, (size_t)d * 4));
+    HIPCHK(d2d(c->cav_b.f() + (size_t)l * d, ib + 2 * d, (size_t)d * 4));
+    if (c->pose) {
+      const float* iw2 = W32(c, p + "multihead_attn2.in_proj_weight");
+      const float* ib2 = W32(c, p + "multihead_attn2.in_proj_bias");
+      HIPCHK(d2d(ca2k32.f() + (size_t)l * d * d, iw2 + (size_t)d * d, (size_t)d * d * 4));
+      HIPCHK(d2d(ca2v32.f() + (size_t)l * d * d, iw2 + (size_t)2 * d * d, (size_t)d * d * 4));
+      HIPCHK(d2d(c->ca2k_b.f() + (size_t)l * d, ib2 + d, (size_t)d * 4));
+      HIPCHK(d2d(c->ca2v_b.f() + (size_t)l * d, ib2 + 2 * d, (size_t)d * 4));
+    }
+  }
+  CHK(make_wt(c, "", c->cak_w32.f(), L * d, d, s, &c->cak_wt));
+  CHK(make_wt(c, "", c->cav_w32.f(), L * d, d, s, &c->cav_wt));
+  if (c->pose) {
+    CHK(make_wt(c, "", ca2k32.f(), L * d, d, s, &c->ca2k_wt));
+    CHK(make_wt(c, "", ca2v32.f(), L * d, d, s, &c->ca2v_wt));
+  }
+  // time path: [to_time_cond ; to_time_tokens] stacked -> [3d, 4d]
+  CHK(buf_alloc(c->tct_w, (size_t)3 * d * 4 * d * 4)); CHK(buf_alloc(c->tct_b, (size_t)3 * d * 4));
+  HIPCHK(d2d(c->tct_w.f(), W32(c, "to_time_cond.0.weight"), (size_t)d * 4 * d * 4));
+  HIPCHK(d2d(c->tct_w.f() + (size_t)d * 4 * d, W32(c, "to_time_tokens.0.weight"), (size_t)2 * d * 4 * d * 4));
+  HIPCHK(d2d(c->tct_b.f(), W32(c, "to_time_cond.0.bias"), (size_t)d * 4));
+  HIPCHK(d2d(c->tct_b.f() + d, W32(c, "to_time_tokens.0.bias"), (size_t)2 * d * 4));
+  // slot 0 of the caches: the unconditional branch is batch- and input-invariant
+  HIPCHK(d2d(c->hidden.p, W32(c, "null_cond_hidden"), (size_t)d * 4));
+  {
+    const int rows = c->S0max;
+    CHK(launch_ln_rope(c, false, W32(c, "null_cond_embed"), d, W32(c, "norm_cond.weight"), W32(c, "norm_cond.bias"), c->xn.p,
+                       c->xr.p, d, rows, rows, 0, s));
+    CHK(project_kv_all(c, c->xr.p, c->xn.p, rows, rows, c->cak_wt, c->cak_b.f(), c->cav_wt, c->cav_b.f(), c->kc.p, c->Sld,
+                       c->vtc.p, 0, s));
+  }
+  if (c->pose) {
+    const int rows = c->KFmax;
+    // null_pose_embed replaces the *normalised* keyframe tokens (model/diffusion.py:331-335): no LayerNorm here
+    CHK(launch_ln_rope(c, false, W32(c, "null_pose_embed"), d, nullptr, nullptr, c->xn.p, c->xr.p, d, rows, rows, 0, s));
+    CHK(project_kv_all(c, c->xr.p, c->xn.p, rows, rows, c->ca2k_wt, c->ca2k_b.f(), c->ca2v_wt, c->ca2v_b.f(), c->k2c.p, 64,
+                       c->vt2c.p, 0, s));
+    // conv tail weights [Co, Ci, 3] -> [tap][Co][CiPad]
+    const int C = c->C, hid = C > 256 ? C : 256;
+    const int ci[7] = {C, hid, C, C, C, C, C}, co[7] = {hid, C, C, C, C, C, C};
+    for (int i = 0; i < 7; ++i) {
+      const int taps = i < 6 ? 3 : 1, cip = rup(ci[i], 64);
+      const std::string nm = i < 6 ? "post_pose_layers." + std::to_string(i) + ".weight" : "final_conv.weight";
+      CHK(buf_alloc(c->conv_wt[i], (size_t)taps * co[i] * cip * c->esz));
+      for (int t = 0; t < taps; ++t)  // src element (co, ci, tap) at (co*Ci + ci)*taps + tap
+        CHK(launch_cast(c, W32(c, nm) + t, (int64_t)ci[i] * taps, c->offT(c->conv_wt[i], (int64_t)t * co[i] * cip), cip, co[i], ci[i],
+                        cip, nullptr, s, taps));
+    }
+  }
+  HIPCHK(hipStreamSynchronize(s));
+  buf_free(ca2k32);
+  buf_free(ca2v32);
+  c->finalized = true;
+  return 0;
+}
+
+#include "a2p_lib_run.h"

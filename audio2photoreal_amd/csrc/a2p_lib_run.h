@@ -1,0 +1,543 @@
+// Second half of a2p_lib.hip (same translation unit): hoisted conditioning, the per-step time path,
+// the decoder stack, the fused sampler step and the unit / measurement entry points.
+#pragma once
+
+// ------------------------------------------------------------------------------------------------
+// one norm-first transformer block pieces
+// ------------------------------------------------------------------------------------------------
+struct CrossKV {
+  const void* K = nullptr;
+  const void* VT = nullptr;
+  int64_t k_slot_stride = 0, ldk = 0, vt_slot_stride = 0, ldvt = 0;
+  const int* slots = nullptr;
+  int S_main = 0;
+  const float* ktail = nullptr;
+  const float* vtail = nullptr;
+  int64_t tail_sample_stride = 0, tail_row_stride = 0;
+  int S_tail = 0, tail_mod = 1;
+};
+
+struct FilmRef {
+  const float* base = nullptr;  // scale of (layer, film 0) for sequence 0; NULL = plain residual
+  int64_t seq_stride = 0;
+};
+
+static int film_gemm(a2p_ctx* c, const void* A, int64_t lda, const std::string& wname, const float* bias, int K, const FilmRef& fr,
+                     int film_idx, int M, int rows_per_seq, hipStream_t s) {
+  const int d = c->d;
+  GemmP p = gemm_base(A, lda, c->wt.at(wname).p, rup(K, 64), bias, nullptr, 0, M, d, K);
+  p.epi = EPI_FILM_RES;
+  p.resid = c->x.f();
+  p.ldx = d;
+  p.rows_per_seq = rows_per_seq;
+  if (fr.base) {
+    p.film = fr.base + (int64_t)film_idx * 2 * d;
+    p.film_seq_stride = fr.seq_stride;
+    p.film_shift_off = d;
+  }
+  return launch_gemm(c, p, s);
+}
+
+// self attention block on the residual stream c->x: x += FiLM(out_proj(MHA(rot(LN x), rot(LN x), LN x)))
+static int self_attn_block(a2p_ctx* c, const std::string& p, const std::string& norm, int N, int T, const FilmRef& fr, int film_idx,
+                           hipStream_t s) {
+  const int d = c->d, M = N * T;
+  const int Tld = rup(T, 64);
+  CHK(launch_ln_rope(c, false, c->x.f(), d, W32(c, norm + ".weight"), W32(c, norm + ".bias"), c->xn.p, c->xr.p, d, M, T, 0, s));
+  const Buf& inw = c->wt.at(p + ".in_proj_weight");
+  const float* inb = W32(c, p + ".in_proj_bias");
+  GemmP pq = gemm_base(c->xr.p, d, inw.p, d, inb, c->qk.p, 2 * d, M, 2 * d, d);
+  CHK(launch_gemm(c, pq, s));
+  GemmP pv = gemm_base(c->xn.p, d, c->offT(inw, (int64_t)2 * d * d), d, inb + 2 * d, c->vt.p, Tld, M, d, d);
+  pv.epi = EPI_STORE_T;
+  pv.rows_per_seq = T;
+  pv.t_seq_stride = (int64_t)d * Tld;
+  CHK(launch_gemm(c, pv, s));
+  AttnP a;
+  memset(&a, 0, sizeof(a));
+  a.Q = c->qk.p; a.q_seq_stride = (int64_t)T * 2 * d; a.ldq = 2 * d;
+  a.K = c->offT(c->qk, d); a.k_slot_stride = (int64_t)T * 2 * d; a.ldk = 2 * d;
+  a.VT = c->vt.p; a.vt_slot_stride = (int64_t)d * Tld; a.ldvt = Tld;
+  a.O = c->ao.p; a.o_seq_stride = (int64_t)T * d; a.ldo = d;
+  a.tail_mod = 1; a.Tq = T; a.S_main = T; a.S_tail = 0;
+  a.scale_log2e = 1.4426950408889634f / sqrtf((float)c->DH);
+  CHK(launch_attn(c, a, N, A2P_KERNEL_ATTN_SELF, s));
+  return film_gemm(c, c->ao.p, d, p + ".out_proj.weight", W32(c, p + ".out_proj.bias"), d, fr, film_idx, M, T, s);
+}
+
+static int cross_attn_block(a2p_ctx* c, const std::string& p, const std::string& norm, int N, int T, const CrossKV& kv,
+                            const FilmRef& fr, int film_idx, hipStream_t s) {
+  const int d = c->d, M = N * T;
+  CHK(launch_ln_rope(c, false, c->x.f(), d, W32(c, norm + ".weight"), W32(c, norm + ".bias"), nullptr, c->xr.p, d, M, T, 0, s));
+  GemmP pq = gemm_base(c->xr.p, d, c->wt.at(p + ".in_proj_weight").p, d, W32(c, p + ".in_proj_bias"), c->qk.p, d, M, d, d);
+  CHK(launch_gemm(c, pq, s));
+  AttnP a;
+  memset(&a, 0, sizeof(a));
+  a.Q = c->qk.p; a.q_seq_stride = (int64_t)T * d; a.ldq = d;
+  a.K = kv.K; a.k_slot_stride = kv.k_slot_stride; a.ldk = kv.ldk;
+  a.VT = kv.VT; a.vt_slot_stride = kv.vt_slot_stride; a.ldvt = kv.ldvt;
+  a.O = c->ao.p; a.o_seq_stride = (int64_t)T * d; a.ldo = d;
+  a.ktail = kv.ktail; a.vtail = kv.vtail; a.tail_sample_stride = kv.tail_sample_stride; a.tail_row_stride = kv.tail_row_stride;
+  a.kv_slot = kv.slots; a.tail_mod = kv.tail_mod; a.Tq = T; a.S_main = kv.S_main; a.S_tail = kv.S_tail;
+  a.scale_log2e = 1.4426950408889634f / sqrtf((float)c->DH);
+  CHK(launch_attn(c, a, N, A2P_KERNEL_ATTN_CROSS, s));
+  return film_gemm(c, c->ao.p, d, p + ".out_proj.weight", W32(c, p + ".out_proj.bias"), d, fr, film_idx, M, T, s);
+}
+
+static int ffn_block(a2p_ctx* c, const std::string& p, const std::string& norm, int M, int rows_per_seq, const FilmRef& fr,
+                     int film_idx, hipStream_t s) {
+  const int d = c->d;
+  CHK(launch_ln_rope(c, false, c->x.f(), d, W32(c, norm + ".weight"), W32(c, norm + ".bias"), c->xn.p, nullptr, d, M, rows_per_seq, 0, s));
+  GemmP p1 = gemm_base(c->xn.p, d, c->wt.at(p + "linear1.weight").p, d, W32(c, p + "linear1.bias"), c->hff.p, c->ff, M, c->ff, d);
+  p1.act = ACT_GELU;
+  CHK(launch_gemm(c, p1, s));
+  return film_gemm(c, c->hff.p, c->ff, p + "linear2.weight", W32(c, p + "linear2.bias"), c->ff, fr, film_idx, M, rows_per_seq, s);
+}
+
+// FiLMTransformerDecoderLayer.forward (transformer_modules.py:178-217) on c->x
+static int decoder_layer(a2p_ctx* c, int l, int N, int T, const CrossKV& kv, const CrossKV* kv2, const FilmRef& fr, hipStream_t s) {
+  const std::string p = "seqTransDecoder.stack." + std::to_string(l) + ".";
+  CHK(self_attn_block(c, p + "self_attn", p + "norm1", N, T, fr, 0, s));
+  CHK(cross_attn_block(c, p + "multihead_attn", p + "norm2", N, T, kv, fr, 1, s));
+  if (kv2) CHK(cross_attn_block(c, p + "multihead_attn2", p + "norm2a", N, T, *kv2, fr, 3, s));
+  return ffn_block(c, p, p + "norm3", N * T, T, fr, 2, s);
+}
+
+// ------------------------------------------------------------------------------------------------
+// hoisted conditioning
+// ------------------------------------------------------------------------------------------------
+extern "C" int a2p_prepare_cond(a2p_ctx* c, const float* cond_embed, int32_t B, int32_t S0, const float* keyframes,
+                                const uint8_t* key_mask, int32_t n_key, int32_t T, void* stream) {
+  ARG(c && cond_embed, "null argument");
+  if (!c->finalized) {
+    set_err("a2p_prepare_cond before a2p_finalize_weights");
+    return A2P_ERR_STATE;
+  }
+  ARG(B >= 1 && B <= c->Bmax, "batch %d exceeds max_batch %d", B, c->Bmax);
+  ARG(S0 >= 1 && S0 <= c->S0max, "n_tok %d exceeds emb_len %d", S0, c->S0max);
+  ARG(T >= 1 && T <= c->Tmax && T % 4 == 0, "frames %d must be a multiple of 4 and <= %d", T, c->Tmax);
+  if (c->pose) ARG(keyframes && n_key >= 1 && n_key <= c->KFmax, "pose model needs keyframes (1..%d)", c->KFmax);
+  hipStream_t s = (hipStream_t)stream;
+  const int d = c->d, M = B * S0;
+  c->prepared = false;
+  // cond_projection (model/diffusion.py:372)
+  CHK(launch_cast(c, cond_embed, c->Fc, c->ce_pack.p, c->FcPad, M, c->Fc, c->FcPad, nullptr, s));
+  GemmP pc = gemm_base(c->ce_pack.p, c->FcPad, c->wt.at("cond_projection.weight").p, c->FcPad, W32(c, "cond_projection.bias"),
+                       c->x.p, d, M, d, c->FcPad);
+  pc.out_f32 = 1;
+  CHK(launch_gemm(c, pc, s));
+  if (!c->pose) {  // cond_encoder: 2 x TransformerEncoderLayerRotary (transformer_modules.py:68-102)
+    FilmRef none;
+    for (int i = 0; i < 2; ++i) {
+      const std::string p = "cond_encoder." + std::to_string(i) + ".";
+      CHK(self_attn_block(c, p + "self_attn", p + "norm1", B, S0, none, 0, s));
+      CHK(ffn_block(c, p, p + "norm2", M, S0, none, 0, s));
+    }
+  }
+  // pooled hidden (model/diffusion.py:380-381) -> hidden slot 1+b
+  mean_tokens_kernel<<<dim3((d + 255) / 256, B), 256, 0, s>>>(c->x.f(), c->pooled.f(), S0, d);
+  CHK(launch_ln_rope(c, true, c->pooled.f(), d, W32(c, "non_attn_cond_projection.0.weight"), W32(c, "non_attn_cond_projection.0.bias"),
+                     c->tmpa.p, nullptr, d, B, B, 0, s));
+  CHK(launch_skinny(c->tmpa.f(), d, W32(c, "non_attn_cond_projection.1.weight"), d, W32(c, "non_attn_cond_projection.1.bias"),
+                    c->tmpb.f(), d, B, d, d, ACT_SILU, s));
+  CHK(launch_skinny(c->tmpb.f(), d, W32(c, "non_attn_cond_projection.3.weight"), d, W32(c, "non_attn_cond_projection.3.bias"),
+                    c->hidden.f() + d, d, B, d, d, ACT_NONE, s));
+  // norm_cond + rotary of the audio tokens, then K / V^T of every decoder layer into slots 1..B
+  CHK(launch_ln_rope(c, false, c->x.f(), d, W32(c, "norm_cond.weight"), W32(c, "norm_cond.bias"), c->xn.p, c->xr.p, d, M, S0, 0, s));
+  CHK(project_kv_all(c, c->xr.p, c->xn.p, M, S0, c->cak_wt, c->cak_b.f(), c->cav_wt, c->cav_b.f(), c->kc.p, c->Sld, c->vtc.p, 1, s));
+  if (c->pose) {  // encode_keyframes (model/diffusion.py:315-336), conditional branch
+    const int Mk = B * n_key;
+    HIPCHK(hipMemsetAsync(c->cb[0].p, 0, c->cb[0].bytes, s));  // left-pad rows of the conv tail must be zero for this T
+    CHK(launch_cast(c, keyframes, c->Kd, c->kf_pack.p, c->KdPad, Mk, c->Kd, c->KdPad, key_mask, s));
+    GemmP pk = gemm_base(c->kf_pack.p, c->KdPad, c->wt.at("frame_cond_projection.weight").p,
+                         c->KdPad, W32(c, "frame_cond_projection.bias"), c->kf_tok.p, d, Mk, d, c->KdPad);
+    pk.out_f32 = 1;
+    CHK(launch_gemm(c, pk, s));
+    CHK(launch_ln_rope(c, false, c->kf_tok.f(), d, W32(c, "frame_norm_cond.weight"), W32(c, "frame_norm_cond.bias"), c->xn.p, c->xr.p,
+                       d, Mk, n_key, 0, s));
+    CHK(project_kv_all(c, c->xr.p, c->xn.p, Mk, n_key, c->ca2k_wt, c->ca2k_b.f(), c->ca2v_wt, c->ca2v_b.f(), c->k2c.p, 64, c->vt2c.p,
+                       1, s));
+  }
+  // slot tables
+  c->h_slots.assign(4 * (size_t)B, 0);
+  for (int b = 0; b < B; ++b) {
+    c->h_slots[b] = 1 + b;            // cond
+    c->h_slots[B + b] = 0;            // uncond
+    c->h_slots[2 * B + b] = 1 + b;    // cfg: first half cond ...
+    c->h_slots[3 * B + b] = 0;        // ... second half uncond
+  }
+  HIPCHK(hipMemcpyAsync(c->slot_cond.p, c->h_slots.data(), (size_t)B * 4, hipMemcpyHostToDevice, s));
+  HIPCHK(hipMemcpyAsync(c->slot_unc.p, c->h_slots.data() + B, (size_t)B * 4, hipMemcpyHostToDevice, s));
+  HIPCHK(hipMemcpyAsync(c->slot_cfg.p, c->h_slots.data() + 2 * B, (size_t)2 * B * 4, hipMemcpyHostToDevice, s));
+  HIPCHK(hipStreamSynchronize(s));  // h_slots is pageable; also surfaces kernel faults here
+  c->pB = B; c->pS0 = S0; c->pT = T; c->pK = n_key;
+  c->prepared = true;
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// per-step time path (a15, a20, time-token K/V)
+// ------------------------------------------------------------------------------------------------
+static int time_path(a2p_ctx* c, const int64_t* t_orig, int N, const int* slots, hipStream_t s) {
+  const int d = c->d, B = c->pB, L = c->L, F = c->F;
+  time_embed_kernel<<<(B * (d / 2) + 255) / 256, 256, 0, s>>>(t_orig, c->time_freq.f(), c->emb.f(), B, d / 2);
+  CHK(launch_skinny(c->emb.f(), d, W32(c, "time_mlp.1.weight"), d, W32(c, "time_mlp.1.bias"), c->th.f(), 4 * d, B, 4 * d, d, ACT_MISH, s));
+  CHK(launch_skinny(c->th.f(), 4 * d, c->tct_w.f(), 4 * d, c->tct_b.f(), c->tct.f(), 3 * d, B, 3 * d, 4 * d, ACT_NONE, s));
+  TPathP tp;
+  tp.tct = c->tct.f(); tp.hidden = c->hidden.f(); tp.slot = slots; tp.tvec = c->tvec.f(); tp.mt = c->mt.f();
+  tp.gamma = W32(c, "norm_cond.weight"); tp.beta = W32(c, "norm_cond.bias"); tp.cs = (const float2*)c->rope_cs.p;
+  tp.tok_n = c->tokn.f(); tp.tok_r = c->tokr.f(); tp.B = B; tp.nseq = N; tp.d = d; tp.pos0 = c->pS0;
+  tpath_post_kernel<<<N + B, 256, 0, s>>>(tp);
+  CHK(launch_skinny(c->mt.f(), d, c->film_w.f(), d, c->film_b.f(), c->film.f(), (int64_t)L * F * 2 * d, N, L * F * 2 * d, d, ACT_NONE, s));
+  CHK(launch_skinny(c->tokr.f(), d, c->cak_w32.f(), d, c->cak_b.f(), c->ktail.f(), (int64_t)L * d, 2 * B, L * d, d, ACT_NONE, s));
+  CHK(launch_skinny(c->tokn.f(), d, c->cav_w32.f(), d, c->cav_b.f(), c->vtail.f(), (int64_t)L * d, 2 * B, L * d, d, ACT_NONE, s));
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+// dilated conv tail of the pose model (model/diffusion.py:214-224,398-402) as tap-accumulating GEMMs over
+// left-padded per-sequence rows: buffers are [N][T+24][128|256] with the 24 pad rows zero.
+static int pose_conv_tail(a2p_ctx* c, int N, int T, hipStream_t s) {
+  const int C = c->C, hid = C > 256 ? C : 256, R = T + 24;
+  const int M = N * R;
+  const int ci[6] = {C, hid, C, C, C, C}, co[6] = {hid, C, C, C, C, C}, dil[6] = {1, 2, 3, 1, 2, 3};
+  Buf* src = &c->cb[0];
+  int cur = 0;
+  for (int i = 0; i < 6; ++i) {
+    const int cip = rup(ci[i], 64), cop = rup(co[i], 64);
+    Buf* dst = (i == 0) ? &c->cb[1] : ((cur == 2) ? &c->cb[3] : &c->cb[2]);
+    GemmP p = gemm_base(src->p, cip, c->conv_wt[i].p, cip, W32(c, "post_pose_layers." + std::to_string(i) + ".bias"), dst->p, cop, M,
+                        co[i], cip);
+    p.ntaps = 3;
+    p.a_tap_stride = (int64_t)dil[i] * cip;
+    p.w_tap_stride = (int64_t)co[i] * cip;
+    p.epi = EPI_CONV;
+    p.act = ACT_LRELU;
+    if (ci[i] == co[i]) {  // out = (in[t + 2*dil] + y) / 2
+      p.skip = c->offT(*src, (int64_t)2 * dil[i] * cip);
+      p.ld_skip = cip;
+    }
+    CHK(launch_gemm(c, p, s));
+    src = dst;
+    cur = (dst == &c->cb[2]) ? 2 : (dst == &c->cb[3] ? 3 : 1);
+  }
+  GemmP pf = gemm_base(src->p, rup(C, 64), c->conv_wt[6].p, rup(C, 64), W32(c, "final_conv.bias"), c->mo.p, C, M, C, rup(C, 64));
+  pf.out_f32 = 1;
+  return launch_gemm(c, pf, s);
+}
+
+// FiLMTransformer.forward for N sequences; result rows in c->mo ([N][mo_rows][C] fp32)
+static int run_forward(a2p_ctx* c, const float* x_in, const int64_t* t_orig, int pass, int* mo_seq_rows, hipStream_t s) {
+  if (!c->prepared) {
+    set_err("denoise before a2p_prepare_cond");
+    return A2P_ERR_STATE;
+  }
+  ARG(x_in && t_orig, "null argument");
+  ARG(pass >= 0 && pass <= 2, "bad pass %d", pass);
+  const int d = c->d, B = c->pB, T = c->pT, L = c->L, F = c->F;
+  const int N = pass == A2P_PASS_CFG ? 2 * B : B;
+  const int* slots = (const int*)(pass == A2P_PASS_CFG ? c->slot_cfg.p : (pass == A2P_PASS_COND ? c->slot_cond.p : c->slot_unc.p));
+  // input permute + projection (model/diffusion.py:345-346,364)
+  {
+    dim3 grid((T + 31) / 32, (c->Cpad + 31) / 32, B);
+    if (c->bf16) pack_input_kernel<bf16_t><<<grid, 256, 0, s>>>(x_in, (bf16_t*)c->inpack.p, B, c->C, T, c->Cpad);
+    else pack_input_kernel<float><<<grid, 256, 0, s>>>(x_in, (float*)c->inpack.p, B, c->C, T, c->Cpad);
+    GemmP p = gemm_base(c->inpack.p, c->Cpad, c->wt.at("input_projection.weight").p, c->Cpad, W32(c, "input_projection.bias"), c->x.p, d,
+                        B * T, d, c->Cpad);
+    p.out_f32 = 1;
+    CHK(launch_gemm(c, p, s));
+    if (N == 2 * B)
+      HIPCHK(hipMemcpyAsync(c->x.f() + (size_t)B * T * d, c->x.p, (size_t)B * T * d * 4, hipMemcpyDeviceToDevice, s));
+  }
+  CHK(time_path(c, t_orig, N, slots, s));
+  CrossKV kv, kv2;
+  for (int l = 0; l < L; ++l) {
+    kv.K = c->offT(c->kc, (int64_t)l * d); kv.k_slot_stride = (int64_t)c->Sld * L * d; kv.ldk = (int64_t)L * d;
+    kv.VT = c->offT(c->vtc, (int64_t)l * d * c->Sld); kv.vt_slot_stride = (int64_t)L * d * c->Sld; kv.ldvt = c->Sld;
+    kv.slots = slots; kv.S_main = c->pS0;
+    kv.ktail = c->ktail.f() + (size_t)l * d; kv.vtail = c->vtail.f() + (size_t)l * d;
+    kv.tail_row_stride = (int64_t)L * d; kv.tail_sample_stride = (int64_t)2 * L * d; kv.S_tail = 2; kv.tail_mod = B;
+    if (c->pose) {
+      kv2.K = c->offT(c->k2c, (int64_t)l * d); kv2.k_slot_stride = (int64_t)64 * L * d; kv2.ldk = (int64_t)L * d;
+      kv2.VT = c->offT(c->vt2c, (int64_t)l * d * 64); kv2.vt_slot_stride = (int64_t)L * d * 64; kv2.ldvt = 64;
+      kv2.slots = slots; kv2.S_main = c->pK; kv2.S_tail = 0; kv2.tail_mod = 1;
+    }
+    FilmRef fr;
+    fr.base = c->film.f() + (size_t)l * F * 2 * d;
+    fr.seq_stride = (int64_t)L * F * 2 * d;
+    CHK(decoder_layer(c, l, N, T, kv, c->pose ? &kv2 : nullptr, fr, s));
+  }
+  // final_layer (model/diffusion.py:397): cast the stream, GEMM
+  CHK(launch_ln_rope(c, false, c->x.f(), d, nullptr, nullptr, c->xn.p, nullptr, d, N * T, T, 0, s));
+  if (!c->pose) {
+    GemmP p = gemm_base(c->xn.p, d, c->wt.at("final_layer.weight").p, d, W32(c, "final_layer.bias"), c->mo.p, c->C, N * T, c->C, d);
+    p.out_f32 = 1;
+    CHK(launch_gemm(c, p, s));
+    *mo_seq_rows = T;
+  } else {
+    GemmP p = gemm_base(c->xn.p, d, c->wt.at("final_layer.weight").p, d, W32(c, "final_layer.bias"), c->offT(c->cb[0], (int64_t)24 * 128),
+                        128, N * T, c->C, d);
+    p.rows_per_seq = T;
+    p.out_seq_pad = 24;
+    CHK(launch_gemm(c, p, s));
+    CHK(pose_conv_tail(c, N, T, s));
+    *mo_seq_rows = T + 24;
+  }
+  return 0;
+}
+
+static int launch_step_tail(a2p_ctx* c, StepP& sp, hipStream_t s) {
+  dim3 grid((sp.Tn + 31) / 32, (sp.C + 31) / 32, sp.B);
+  step_tail_kernel<<<grid, 256, 0, s>>>(sp);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+extern "C" int a2p_denoise_forward(a2p_ctx* c, const float* x, const int64_t* t_orig, const float* scale, int32_t pass, float* out,
+                                   void* stream) {
+  ARG(c && out, "null argument");
+  ARG(pass != A2P_PASS_CFG || scale, "A2P_PASS_CFG needs scale");
+  hipStream_t s = (hipStream_t)stream;
+  int rows = 0;
+  CHK(run_forward(c, x, t_orig, pass, &rows, s));
+  StepP sp;
+  memset(&sp, 0, sizeof(sp));
+  sp.mo = c->mo.f(); sp.mo_seq_rows = rows; sp.mo_ld = c->C; sp.B = c->pB; sp.C = c->C; sp.Tn = c->pT;
+  sp.pass = pass; sp.scale = scale; sp.out_btc = out; sp.sampler = -1;
+  return launch_step_tail(c, sp, s);
+}
+
+__global__ void map_timesteps_kernel(const int64_t* t_idx, const int64_t* tmap, int64_t* out, int B) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < B) out[i] = tmap[t_idx[i]];
+}
+
+extern "C" int a2p_sample_step(a2p_ctx* c, int32_t sampler, const float* x, const int64_t* t_idx, const int64_t* timestep_map,
+                               const float* tables, int32_t n_steps, const float* scale, const float* noise, float eta,
+                               int32_t clip_denoised, float* x_next, float* pred_xstart, void* stream) {
+  ARG(c && x && t_idx && timestep_map && tables && x_next, "null argument");
+  ARG(sampler == A2P_SAMPLER_DDIM || sampler == A2P_SAMPLER_DDPM, "bad sampler");
+  ARG(sampler == A2P_SAMPLER_DDIM || noise, "DDPM step needs noise");
+  ARG(scale, "classifier-free guidance scale required");
+  hipStream_t s = (hipStream_t)stream;
+  // _WrappedModel.__call__ (respace.py:140-145): new_ts = timestep_map[ts]; reuse tmpa as int64 scratch
+  int64_t* t_orig = reinterpret_cast<int64_t*>(c->tmpa.p);
+  map_timesteps_kernel<<<1, 256, 0, s>>>(t_idx, timestep_map, t_orig, c->pB);
+  int rows = 0;
+  CHK(run_forward(c, x, t_orig, A2P_PASS_CFG, &rows, s));
+  StepP sp;
+  memset(&sp, 0, sizeof(sp));
+  sp.mo = c->mo.f(); sp.mo_seq_rows = rows; sp.mo_ld = c->C; sp.B = c->pB; sp.C = c->C; sp.Tn = c->pT;
+  sp.pass = A2P_PASS_CFG; sp.scale = scale; sp.sampler = sampler; sp.x = x; sp.t_idx = t_idx; sp.tables = tables;
+  sp.n_steps = n_steps; sp.noise = noise; sp.eta = eta; sp.clip = clip_denoised; sp.x_next = x_next; sp.x0 = pred_xstart;
+  return launch_step_tail(c, sp, s);
+}
+
+// ------------------------------------------------------------------------------------------------
+// stand-alone sampler arithmetic
+// ------------------------------------------------------------------------------------------------
+extern "C" int a2p_p_mean_variance(const float* model_out, const float* x, const int64_t* t_idx, const float* tables, int32_t n_steps,
+                                   int32_t batch, int32_t nfeats, int32_t frames, int32_t clip_denoised, float* pred_xstart,
+                                   float* mean, void* stream) {
+  ARG(model_out && x && t_idx && tables && pred_xstart, "null argument");
+  StepP sp;
+  memset(&sp, 0, sizeof(sp));
+  sp.mo = model_out; sp.mo_seq_rows = frames; sp.mo_ld = nfeats; sp.B = batch; sp.C = nfeats; sp.Tn = frames;
+  sp.pass = A2P_PASS_COND; sp.sampler = -1; sp.x = x; sp.t_idx = t_idx; sp.tables = tables; sp.n_steps = n_steps;
+  sp.clip = clip_denoised; sp.x0 = pred_xstart; sp.mean = mean;
+  return launch_step_tail(nullptr, sp, (hipStream_t)stream);
+}
+
+extern "C" int a2p_ddim_update(const float* pred_xstart, const float* x, const int64_t* t_idx, const float* tables, int32_t n_steps,
+                               const float* noise, float eta, int32_t batch, int64_t per_sample, float* sample, void* stream) {
+  ARG(pred_xstart && x && t_idx && tables && sample, "null argument");
+  const int64_t total = batch * per_sample;
+  ddim_update_kernel<<<(int)((total + 255) / 256), 256, 0, (hipStream_t)stream>>>(pred_xstart, x, t_idx, tables, n_steps, noise, eta,
+                                                                                 per_sample, total, sample);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+extern "C" int a2p_p_sample_update(const float* mean, const int64_t* t_idx, const float* tables, int32_t n_steps, const float* noise,
+                                   int32_t batch, int64_t per_sample, float* sample, void* stream) {
+  ARG(mean && t_idx && tables && noise && sample, "null argument");
+  const int64_t total = batch * per_sample;
+  p_sample_update_kernel<<<(int)((total + 255) / 256), 256, 0, (hipStream_t)stream>>>(mean, t_idx, tables, n_steps, noise, per_sample,
+                                                                                     total, sample);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+extern "C" int a2p_q_sample(const float* x_start, const int64_t* t_idx, const float* tables, int32_t n_steps, const float* noise,
+                            int32_t batch, int64_t per_sample, float* out, void* stream) {
+  ARG(x_start && t_idx && tables && noise && out, "null argument");
+  const int64_t total = batch * per_sample;
+  q_sample_kernel<<<(int)((total + 255) / 256), 256, 0, (hipStream_t)stream>>>(x_start, t_idx, tables, n_steps, noise, per_sample, total,
+                                                                              out);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// unit entry points
+// ------------------------------------------------------------------------------------------------
+extern "C" int a2p_gemm(a2p_ctx* c, const float* A, const float* W, const float* bias, float* C, int32_t M, int32_t N, int32_t K,
+                        void* stream) {
+  ARG(c && A && W && C && M > 0 && N > 0 && K > 0 && N % 4 == 0, "bad gemm arguments");
+  hipStream_t s = (hipStream_t)stream;
+  const int kp = rup(K, 64);
+  Buf a, w;
+  CHK(buf_alloc(a, (size_t)M * kp * c->esz));
+  CHK(buf_alloc(w, (size_t)N * kp * c->esz));
+  CHK(launch_cast(c, A, K, a.p, kp, M, K, kp, nullptr, s));
+  CHK(launch_cast(c, W, K, w.p, kp, N, K, kp, nullptr, s));
+  GemmP p = gemm_base(a.p, kp, w.p, kp, bias, C, N, M, N, kp);
+  p.out_f32 = 1;
+  int rc = launch_gemm(c, p, s);
+  hipStreamSynchronize(s);
+  buf_free(a);
+  buf_free(w);
+  return rc;
+}
+
+__global__ void widen_kernel(const bf16_t* a, float* o, int64_t n) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) o[i] = (float)a[i];
+}
+
+template <typename T>
+__global__ void transpose_cast_kernel(const float* __restrict__ v, T* __restrict__ vt, int S, int d, int Sld) {
+  // v [n][S][d] -> vt [n][d][Sld]
+  const int n = blockIdx.z;
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (int64_t)S * d) return;
+  const int s = (int)(i / d), c = (int)(i - (int64_t)s * d);
+  vt[((int64_t)n * d + c) * Sld + s] = from_f32<T>(v[((int64_t)n * S + s) * d + c]);
+}
+
+extern "C" int a2p_attention(a2p_ctx* c, const float* q, const float* k, const float* v, float* out, int32_t N, int32_t Tq, int32_t S,
+                             void* stream) {
+  ARG(c && q && k && v && out && N > 0 && Tq > 0 && S > 0, "bad attention arguments");
+  hipStream_t s = (hipStream_t)stream;
+  const int d = c->d, Sld = rup(S, 64);
+  Buf qb, kb, vb, ob;
+  CHK(buf_alloc(qb, (size_t)N * Tq * d * c->esz));
+  CHK(buf_alloc(kb, ((size_t)N * Sld + 64) * d * c->esz));
+  CHK(buf_alloc(vb, (size_t)N * d * Sld * c->esz));
+  CHK(buf_alloc(ob, (size_t)N * Tq * d * c->esz));
+  CHK(launch_cast(c, q, d, qb.p, d, (int64_t)N * Tq, d, d, nullptr, s));
+  for (int n = 0; n < N; ++n)
+    CHK(launch_cast(c, k + (size_t)n * S * d, d, c->offT(kb, (int64_t)n * Sld * d), d, S, d, d, nullptr, s));
+  dim3 tg((unsigned)(((int64_t)S * d + 255) / 256), 1, N);
+  if (c->bf16) transpose_cast_kernel<bf16_t><<<tg, 256, 0, s>>>(v, (bf16_t*)vb.p, S, d, Sld);
+  else transpose_cast_kernel<float><<<tg, 256, 0, s>>>(v, (float*)vb.p, S, d, Sld);
+  AttnP a;
+  memset(&a, 0, sizeof(a));
+  a.Q = qb.p; a.q_seq_stride = (int64_t)Tq * d; a.ldq = d;
+  a.K = kb.p; a.k_slot_stride = (int64_t)Sld * d; a.ldk = d;
+  a.VT = vb.p; a.vt_slot_stride = (int64_t)d * Sld; a.ldvt = Sld;
+  a.O = ob.p; a.o_seq_stride = (int64_t)Tq * d; a.ldo = d;
+  a.tail_mod = 1; a.Tq = Tq; a.S_main = S; a.S_tail = 0;
+  a.scale_log2e = 1.4426950408889634f / sqrtf((float)c->DH);
+  int rc = launch_attn(c, a, N, A2P_KERNEL_ATTN_SELF, s);
+  // back to fp32
+  if (rc == 0) {
+    if (c->bf16) {
+      const int64_t n = (int64_t)N * Tq * d;
+      widen_kernel<<<(int)((n + 255) / 256), 256, 0, s>>>((const bf16_t*)ob.p, out, n);
+    } else {
+      hipMemcpyAsync(out, ob.p, (size_t)N * Tq * d * 4, hipMemcpyDeviceToDevice, s);
+    }
+  }
+  hipStreamSynchronize(s);
+  buf_free(qb); buf_free(kb); buf_free(vb); buf_free(ob);
+  return rc;
+}
+
+extern "C" int a2p_decoder_layer_forward(a2p_ctx* c, int32_t layer, float* x, const float* memory, const float* t,
+                                         const float* memory2, int32_t N, int32_t T, int32_t S, int32_t S2, void* stream) {
+  ARG(c && x && memory && t, "null argument");
+  if (!c->finalized) {
+    set_err("a2p_decoder_layer_forward before a2p_finalize_weights");
+    return A2P_ERR_STATE;
+  }
+  ARG(layer >= 0 && layer < c->L && N >= 1 && N <= c->Nmax && T >= 1 && T <= c->Tmax && T % 4 == 0, "bad layer/shape");
+  ARG(S >= 1 && S <= c->S0max + 2 && (int64_t)N * S <= c->rows_cap, "bad memory length");
+  ARG(!memory2 || (c->pose && S2 >= 1 && S2 <= 64), "bad memory2");
+  hipStream_t s = (hipStream_t)stream;
+  const int d = c->d, F = c->F, Sld = rup(S, 64);
+  const std::string p = "seqTransDecoder.stack." + std::to_string(layer) + ".";
+  Buf kb, vb, k2b, v2b, mtb, flm;
+  CHK(buf_alloc(kb, ((size_t)N * Sld + 64) * d * c->esz));
+  CHK(buf_alloc(vb, (size_t)N * d * Sld * c->esz));
+  CHK(buf_alloc(mtb, (size_t)N * d * 4));
+  CHK(buf_alloc(flm, (size_t)N * F * 2 * d * 4));
+  // K = rot(mem) Wk + bk ; V^T = (mem Wv + bv)^T   for this layer
+  auto kvproj = [&](const float* mem, int len, int ld_rows, const std::string& an, Buf& kdst, Buf& vdst) -> int {
+    CHK(launch_ln_rope(c, false, mem, d, nullptr, nullptr, c->xn.p, c->xr.p, d, N * len, len, 0, s));
+    const Buf& inw = c->wt.at(p + an + ".in_proj_weight");
+    const float* inb = W32(c, p + an + ".in_proj_bias");
+    GemmP pk = gemm_base(c->xr.p, d, c->offT(inw, (int64_t)d * d), d, inb + d, kdst.p, d, N * len, d, d);
+    pk.rows_per_seq = len;
+    pk.out_seq_pad = ld_rows - len;
+    CHK(launch_gemm(c, pk, s));
+    GemmP pv = gemm_base(c->xn.p, d, c->offT(inw, (int64_t)2 * d * d), d, inb + 2 * d, vdst.p, ld_rows, N * len, d, d);
+    pv.epi = EPI_STORE_T;
+    pv.rows_per_seq = len;
+    pv.t_seq_stride = (int64_t)d * ld_rows;
+    return launch_gemm(c, pv, s);
+  };
+  CHK(kvproj(memory, S, Sld, "multihead_attn", kb, vb));
+  CrossKV kv, kv2;
+  kv.K = kb.p; kv.k_slot_stride = (int64_t)Sld * d; kv.ldk = d; kv.VT = vb.p; kv.vt_slot_stride = (int64_t)d * Sld; kv.ldvt = Sld;
+  kv.S_main = S;
+  if (memory2) {
+    CHK(buf_alloc(k2b, ((size_t)N * 64 + 64) * d * c->esz));
+    CHK(buf_alloc(v2b, (size_t)N * d * 64 * c->esz));
+    CHK(kvproj(memory2, S2, 64, "multihead_attn2", k2b, v2b));
+    kv2.K = k2b.p; kv2.k_slot_stride = (int64_t)64 * d; kv2.ldk = d; kv2.VT = v2b.p; kv2.vt_slot_stride = (int64_t)d * 64; kv2.ldvt = 64;
+    kv2.S_main = S2;
+  }
+  // FiLM generators of this layer
+  mish_kernel<<<(N * d + 255) / 256, 256, 0, s>>>(t, mtb.f(), (int64_t)N * d);
+  CHK(launch_skinny(mtb.f(), d, c->film_w.f() + (size_t)layer * F * 2 * d * d, d, c->film_b.f() + (size_t)layer * F * 2 * d, flm.f(),
+                    (int64_t)F * 2 * d, N, F * 2 * d, d, ACT_NONE, s));
+  FilmRef fr;
+  fr.base = flm.f();
+  fr.seq_stride = (int64_t)F * 2 * d;
+  HIPCHK(hipMemcpyAsync(c->x.p, x, (size_t)N * T * d * 4, hipMemcpyDeviceToDevice, s));
+  int rc = decoder_layer(c, layer, N, T, kv, memory2 ? &kv2 : nullptr, fr, s);
+  if (rc == 0) hipMemcpyAsync(x, c->x.p, (size_t)N * T * d * 4, hipMemcpyDeviceToDevice, s);
+  hipStreamSynchronize(s);
+  buf_free(kb); buf_free(vb); buf_free(k2b); buf_free(v2b); buf_free(mtb); buf_free(flm);
+  return rc;
+}
+
+// ------------------------------------------------------------------------------------------------
+// measurement
+// ------------------------------------------------------------------------------------------------
+extern "C" int a2p_kernel_timing(a2p_ctx* c, int32_t kind, int32_t enable) {
+  ARG(c, "null ctx");
+  hipDeviceSynchronize();
+  for (auto& e : c->evs) {
+    hipEventDestroy(e.first);
+    hipEventDestroy(e.second);
+  }
+  c->evs.clear();
+  c->time_kind = enable ? kind : -1;
+  return 0;
+}
+
+extern "C" int a2p_kernel_time_ms(a2p_ctx* c, double* total_ms, int64_t* launches) {
+  ARG(c && total_ms && launches, "null argument");
+  HIPCHK(hipDeviceSynchronize());
+  double tot = 0;
+  for (auto& e : c->evs) {
+    float ms = 0;
+    HIPCHK(hipEventElapsedTime(&ms, e.first, e.second));
+    tot += ms;
+  }
+  *total_ms = tot;
+  *launches = (int64_t)c->evs.size();
+  return 0;
+}

@@ -1,0 +1,322 @@
+// HBM-bound kernels of the denoiser / sampler: LayerNorm + full-width rotary, casts / packing,
+// the per-step time path glue, classifier-free-guidance combine + DDIM/DDPM posterior update.
+#pragma once
+#include "a2p_common.h"
+
+// ---------------------------------------------------------------------------------------------
+// cos/sin table of the rotary embedding: cs[pos][i] = (cos(pos*f_i), sin(pos*f_i)), angle formed in
+// fp32 like the reference's cached table (rotary_embedding_torch.py:124-139).
+// ---------------------------------------------------------------------------------------------
+__global__ void rope_table_kernel(const float* __restrict__ freqs, float2* __restrict__ cs, int npos, int half) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= npos * half) return;
+  const int pos = i / half, k = i - pos * half;
+  const float ang = (float)pos * freqs[k];
+  cs[i] = make_float2(cosf(ang), sinf(ang));
+}
+
+// ---------------------------------------------------------------------------------------------
+// LayerNorm (eps 1e-5, biased variance) over d = 64*NPL, optionally followed by the full-width
+// interleaved-pair rotation (rotary_embedding_torch.py:46-66).  One wave per row, fp32 statistics.
+//   xn = LN(x)           -> out_n (dtype T), may be NULL
+//   xr = rotary(LN(x))   -> out_r (dtype T), may be NULL, position = row % rows_per_seq + pos_off
+// gamma == NULL skips the normalisation (rotation only, used for the keyframe tokens).
+// ---------------------------------------------------------------------------------------------
+struct LnRopeP {
+  const float* x;
+  int64_t ldx;
+  const float* gamma;
+  const float* beta;
+  const float2* cs;  // [pos][d/2]
+  void* out_n;
+  void* out_r;
+  int64_t ldo;
+  int rows, rows_per_seq, pos_off;
+};
+
+template <typename T, int NPL>
+__global__ __launch_bounds__(256) void ln_rope_kernel(LnRopeP p) {
+  constexpr int D = 64 * NPL;
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= p.rows) return;
+  const int e0 = lane * NPL;
+  float v[NPL];
+  const float* xr = p.x + (int64_t)row * p.ldx + e0;
+#pragma unroll
+  for (int i = 0; i < NPL; i += 4) {
+    const float4 t = *reinterpret_cast<const float4*>(xr + i);
+    v[i] = t.x; v[i + 1] = t.y; v[i + 2] = t.z; v[i + 3] = t.w;
+  }
+  if (p.gamma) {
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < NPL; ++i) s += v[i];
+    const float mean = wave_sum(s) * (1.0f / D);
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < NPL; ++i) {
+      v[i] -= mean;
+      q += v[i] * v[i];
+    }
+    const float rstd = 1.0f / sqrtf(wave_sum(q) * (1.0f / D) + 1e-5f);
+#pragma unroll
+    for (int i = 0; i < NPL; ++i) v[i] = v[i] * rstd * p.gamma[e0 + i] + p.beta[e0 + i];
+  }
+  if (p.out_n) {
+    T* o = reinterpret_cast<T*>(p.out_n) + (int64_t)row * p.ldo + e0;
+#pragma unroll
+    for (int i = 0; i < NPL; ++i) o[i] = from_f32<T>(v[i]);
+  }
+  if (p.out_r) {
+    const int pos = row % p.rows_per_seq + p.pos_off;
+    const float2* c = p.cs + (int64_t)pos * (D / 2) + e0 / 2;
+    T* o = reinterpret_cast<T*>(p.out_r) + (int64_t)row * p.ldo + e0;
+#pragma unroll
+    for (int i = 0; i < NPL; i += 2) {
+      const float2 t = c[i / 2];
+      o[i] = from_f32<T>(v[i] * t.x - v[i + 1] * t.y);
+      o[i + 1] = from_f32<T>(v[i + 1] * t.x + v[i] * t.y);
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// fp32 [rows, cols] -> T [rows, cols_pad] (zero pad); optional per-row keep mask (keyframes:
+// "pad the unknown", model/diffusion.py:319-320).
+// ---------------------------------------------------------------------------------------------
+template <typename T>
+__global__ void cast_pad_kernel(const float* __restrict__ src, int64_t lds, int src_col_stride, T* __restrict__ dst, int64_t ldd,
+                                int64_t rows, int cols, int cols_pad, const uint8_t* __restrict__ keep) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= rows * cols_pad) return;
+  const int64_t r = i / cols_pad;
+  const int c = (int)(i - r * cols_pad);
+  float v = 0.f;
+  if (c < cols && (!keep || keep[r])) v = src[r * lds + (int64_t)c * src_col_stride];
+  dst[r * ldd + c] = from_f32<T>(v);
+}
+
+// x [B, C, T] fp32 -> A [B*T, Cpad] T  (the permute of model/diffusion.py:345-346 fused with the cast)
+template <typename T>
+__global__ void pack_input_kernel(const float* __restrict__ x, T* __restrict__ dst, int B, int C, int Tn, int Cpad) {
+  __shared__ float tile[32][33];
+  const int b = blockIdx.z, t0 = blockIdx.x * 32, c0 = blockIdx.y * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 256 threads: ty 0..7
+  for (int i = ty; i < 32; i += 8) {
+    const int c = c0 + i, t = t0 + tx;
+    tile[i][tx] = (c < C && t < Tn) ? x[((int64_t)b * C + c) * Tn + t] : 0.f;
+  }
+  __syncthreads();
+  for (int i = ty; i < 32; i += 8) {
+    const int t = t0 + i, c = c0 + tx;
+    if (t < Tn && c < Cpad) dst[((int64_t)b * Tn + t) * Cpad + c] = from_f32<T>(tile[tx][i]);
+  }
+}
+
+// mean over the token axis: src fp32 [B, S, d] -> dst [B, d]   (model/diffusion.py:380)
+__global__ void mean_tokens_kernel(const float* __restrict__ src, float* __restrict__ dst, int S, int d) {
+  const int b = blockIdx.y, c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= d) return;
+  const float* p = src + (int64_t)b * S * d + c;
+  float s = 0.f;
+  for (int i = 0; i < S; ++i) s += p[(int64_t)i * d];
+  dst[(int64_t)b * d + c] = s / (float)S;
+}
+
+// SinusoidalPosEmb (model/utils.py:67-79): emb[b] = [sin(t f_k), cos(t f_k)], f_k host-built fp32.
+__global__ void time_embed_kernel(const int64_t* __restrict__ t, const float* __restrict__ freq, float* __restrict__ emb,
+                                  int B, int half) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= B * half) return;
+  const int b = i / half, k = i - b * half;
+  const float a = (float)t[b] * freq[k];
+  emb[(int64_t)b * 2 * half + k] = sinf(a);
+  emb[(int64_t)b * 2 * half + half + k] = cosf(a);
+}
+
+// Glue of the time path (model/diffusion.py:385-393): per sequence t = to_time_cond(h) + cond_hidden
+// (null_cond_hidden for unconditional sequences), mish(t) for the FiLM generators
+// (transformer_modules.py:111-113), and norm_cond + rotary of the two time tokens.
+struct TPathP {
+  const float* tct;     // [B, 3d]: time cond | token0 | token1
+  const float* hidden;  // [(B+1), d] slot table (0 = null_cond_hidden)
+  const int* slot;      // [nseq]
+  float* tvec;          // [nseq, d]
+  float* mt;            // [nseq, d]  mish(t)
+  const float* gamma;   // norm_cond
+  const float* beta;
+  const float2* cs;
+  float* tok_n;         // [B*2, d]
+  float* tok_r;         // [B*2, d]
+  int B, nseq, d, pos0; // pos0 = number of audio tokens (time tokens sit at pos0, pos0+1)
+};
+
+__global__ __launch_bounds__(256) void tpath_post_kernel(TPathP p) {
+  const int d = p.d;
+  const int wid = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int blk = blockIdx.x;
+  if (blk < p.nseq) {  // t vector of one sequence
+    const int n = blk, b = n % p.B, sl = p.slot[n];
+    for (int c = threadIdx.x; c < d; c += 256) {
+      const float v = p.tct[(int64_t)b * 3 * d + c] + p.hidden[(int64_t)sl * d + c];
+      p.tvec[(int64_t)n * d + c] = v;
+      p.mt[(int64_t)n * d + c] = act_mish(v);
+    }
+    return;
+  }
+  // time tokens of one sample: waves 0,1 -> token 0,1
+  const int b = blk - p.nseq;
+  if (wid >= 2) return;
+  const float* src = p.tct + (int64_t)b * 3 * d + d + wid * d;
+  const int npl = d / 64;
+  float v[8];
+  float s = 0.f;
+  for (int i = 0; i < npl; ++i) {
+    v[i] = src[lane * npl + i];
+    s += v[i];
+  }
+  const float mean = wave_sum(s) / d;
+  float q = 0.f;
+  for (int i = 0; i < npl; ++i) {
+    v[i] -= mean;
+    q += v[i] * v[i];
+  }
+  const float rstd = 1.0f / sqrtf(wave_sum(q) / d + 1e-5f);
+  const int row = b * 2 + wid, pos = p.pos0 + wid;
+  for (int i = 0; i < npl; ++i) {
+    const int c = lane * npl + i;
+    v[i] = v[i] * rstd * p.gamma[c] + p.beta[c];
+    p.tok_n[(int64_t)row * d + c] = v[i];
+  }
+  for (int i = 0; i < npl; i += 2) {
+    const int c = lane * npl + i;
+    const float2 t = p.cs[(int64_t)pos * (d / 2) + c / 2];
+    p.tok_r[(int64_t)row * d + c] = v[i] * t.x - v[i + 1] * t.y;
+    p.tok_r[(int64_t)row * d + c + 1] = v[i + 1] * t.x + v[i] * t.y;
+  }
+}
+
+__global__ void mish_kernel(const float* __restrict__ a, float* __restrict__ o, int64_t n) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) o[i] = act_mish(a[i]);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Sampler arithmetic.  Tables are fp32 rows of length n_steps (a2p_table_id order); all formulas in
+// fp32 in the reference's operation order (gaussian_diffusion.py:235-257, 305-316, 347-351,
+// 470-476, 699-717).
+// ---------------------------------------------------------------------------------------------
+enum { TAB_C1 = 0, TAB_C2, TAB_VAR, TAB_LOGVAR, TAB_SRA, TAB_SRM1, TAB_ACP, TAB_ACPP, TAB_SQRT_ACP, TAB_SQRT_1M };
+
+__device__ __forceinline__ float ddim_update(float x0, float x, float noise, const float* tab, int ns, int t, float eta) {
+  const float eps = (tab[TAB_SRA * ns + t] * x - x0) / tab[TAB_SRM1 * ns + t];
+  const float ab = tab[TAB_ACP * ns + t], abp = tab[TAB_ACPP * ns + t];
+  const float sigma = eta * sqrtf((1.f - abp) / (1.f - ab)) * sqrtf(1.f - ab / abp);
+  const float mean_pred = x0 * sqrtf(abp) + sqrtf(1.f - abp - sigma * sigma) * eps;
+  const float nz = t != 0 ? 1.f : 0.f;
+  return mean_pred + nz * sigma * noise;
+}
+
+__device__ __forceinline__ float ddpm_update(float x0, float x, float noise, const float* tab, int ns, int t) {
+  const float mean = tab[TAB_C1 * ns + t] * x0 + tab[TAB_C2 * ns + t] * x;
+  const float nz = t != 0 ? 1.f : 0.f;
+  return mean + nz * expf(0.5f * tab[TAB_LOGVAR * ns + t]) * noise;
+}
+
+// Fused tail of one sampling step: classifier-free-guidance combine (model/cfg_sampler.py:33),
+// [B,T,C] -> [B,C,1,T] (gaussian_diffusion.py:312-313), optional clamp, posterior update.
+struct StepP {
+  const float* mo;        // model output rows: mo[(seq*mo_seq_rows + t) * mo_ld + c]
+  int64_t mo_seq_rows, mo_ld;
+  int B, C, Tn;
+  int pass;               // A2P_PASS_*: CFG reads sequences b and B+b
+  const float* scale;     // [B]
+  float* out_btc;         // [B,T,C] or NULL
+  int sampler;            // -1 none, 0 ddim, 1 ddpm
+  const float* x;         // [B,C,T]
+  const int64_t* t_idx;   // [B]
+  const float* tables;
+  int n_steps;
+  const float* noise;     // [B,C,T] or NULL
+  float eta;
+  int clip;
+  float* x_next;          // [B,C,T]
+  float* x0;              // [B,C,T] pred_xstart
+  float* mean;            // optional posterior mean [B,C,T] (p_mean_variance API)
+};
+
+__global__ __launch_bounds__(256) void step_tail_kernel(StepP p) {
+  __shared__ float tile[32][33];  // [t][c]
+  const int b = blockIdx.z, t0 = blockIdx.x * 32, c0 = blockIdx.y * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  const float sc = (p.pass == 2) ? p.scale[b] : 0.f;
+  for (int i = ty; i < 32; i += 8) {
+    const int t = t0 + i, c = c0 + tx;
+    float g = 0.f;
+    if (t < p.Tn && c < p.C) {
+      const float a = p.mo[((int64_t)b * p.mo_seq_rows + t) * p.mo_ld + c];
+      if (p.pass == 2) {
+        const float u = p.mo[((int64_t)(p.B + b) * p.mo_seq_rows + t) * p.mo_ld + c];
+        g = u + sc * (a - u);
+      } else {
+        g = a;
+      }
+      if (p.out_btc) p.out_btc[((int64_t)b * p.Tn + t) * p.C + c] = g;
+    }
+    tile[i][tx] = g;
+  }
+  if (p.sampler < 0 && !p.x0 && !p.mean) return;
+  __syncthreads();
+  const int ts = (int)p.t_idx[b];
+  for (int i = ty; i < 32; i += 8) {
+    const int c = c0 + i, t = t0 + tx;
+    if (c >= p.C || t >= p.Tn) continue;
+    float x0 = tile[tx][i];
+    if (p.clip) x0 = fminf(fmaxf(x0, -1.f), 1.f);
+    const int64_t o = ((int64_t)b * p.C + c) * p.Tn + t;
+    if (p.x0) p.x0[o] = x0;
+    const float xv = p.x[o];
+    if (p.mean) p.mean[o] = p.tables[TAB_C1 * p.n_steps + ts] * x0 + p.tables[TAB_C2 * p.n_steps + ts] * xv;
+    if (p.sampler >= 0) {
+      const float nv = p.noise ? p.noise[o] : 0.f;
+      p.x_next[o] = p.sampler == 0 ? ddim_update(x0, xv, nv, p.tables, p.n_steps, ts, p.eta)
+                                   : ddpm_update(x0, xv, nv, p.tables, p.n_steps, ts);
+    }
+  }
+}
+
+// stand-alone elementwise forms (x, x0, noise all [B, per_sample])
+__global__ void ddim_update_kernel(const float* x0, const float* x, const int64_t* t_idx, const float* tab, int ns,
+                                   const float* noise, float eta, int64_t per, int64_t total, float* out) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const int t = (int)t_idx[i / per];
+  out[i] = ddim_update(x0[i], x[i], noise ? noise[i] : 0.f, tab, ns, t, eta);
+}
+
+__global__ void p_sample_update_kernel(const float* mean, const int64_t* t_idx, const float* tab, int ns, const float* noise,
+                                       int64_t per, int64_t total, float* out) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const int t = (int)t_idx[i / per];
+  const float nz = t != 0 ? 1.f : 0.f;
+  out[i] = mean[i] + nz * expf(0.5f * tab[TAB_LOGVAR * ns + t]) * noise[i];
+}
+
+__global__ void q_sample_kernel(const float* xs, const int64_t* t_idx, const float* tab, int ns, const float* noise,
+                                int64_t per, int64_t total, float* out) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const int t = (int)t_idx[i / per];
+  out[i] = tab[TAB_SQRT_ACP * ns + t] * xs[i] + tab[TAB_SQRT_1M * ns + t] * noise[i];
+}
+
+// gather rows: dst[r] = src[idx[r]]  (fp32 rows of `cols`)
+__global__ void gather_rows_kernel(const float* __restrict__ src, const int* __restrict__ idx, float* __restrict__ dst, int rows,
+                                   int cols) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (int64_t)rows * cols) return;
+  const int r = (int)(i / cols), c = (int)(i - (int64_t)r * cols);
+  dst[i] = src[(int64_t)idx[r] * cols + c];
+}

@@ -1,0 +1,326 @@
+"""FiLMTransformer: drop-in for the reference denoiser on the sampling path.
+
+Mirrors `model/diffusion.py:82-403` of the reference at its *interface*:
+constructor arguments, the attributes callers read (`nfeats, cond_mode,
+add_frame_cond, step, resume_trans, transformer, tokenizer`),
+`forward(x, times, y, cond_drop_prob)` and the `state_dict()` key layout, so
+reference checkpoints load unchanged and `ClassifierFreeSampleModel` /
+`SpacedDiffusion` drive it as they drive the reference.
+
+Nothing is computed in PyTorch: the torch sub-modules below are parameter
+*containers* (they give the reference key names and initialisers); `forward`
+hands device pointers to liba2p_hip.so, which runs the hand-written gfx950
+kernels (csrc/).  Everything that does not depend on (x_t, t) -- the
+conditioning-token path, the face cond-encoder, the audio / keyframe K,V of every
+decoder layer, the unconditional branch -- is hoisted into `a2p_prepare_cond`
+and cached per `y` (the reference recomputes it in every step and CFG pass,
+model/diffusion.py:355-381).
+
+The audio front end (vq-wav2vec conv stack + lip regressor,
+model/diffusion.py:285-313) is outside this path (weights
+unavailable offline): pass its output as `y["cond_embed"]`, or give the module an
+`audio_frontend` callable that maps `y["audio"]` to it.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Callable, Dict, Optional
+
+import torch
+import torch.nn as nn
+from torch.nn import functional as F
+
+from .. import _lib
+from ..spec import DenoiserSpec
+
+_PRECISIONS = {"fp32": _lib.PREC_F32, "f32": _lib.PREC_F32, "bf16": _lib.PREC_BF16}
+
+
+def init_weight(m: nn.Module) -> None:
+    """xavier-normal weights, zero bias (reference model/utils.py:29-38)."""
+    if isinstance(m, (nn.Conv1d, nn.Linear, nn.ConvTranspose1d)):
+        nn.init.xavier_normal_(m.weight)
+        if m.bias is not None:
+            nn.init.constant_(m.bias, 0)
+
+
+class RotaryEmbedding(nn.Module):
+    """Holds the `freqs` buffer (rotary_embedding_torch.py:99-114); the rotation itself
+    is fused into the LayerNorm kernel (csrc/kernels_misc.h: ln_rope_kernel)."""
+
+    def __init__(self, dim: int, theta: float = 10000.0):
+        super().__init__()
+        self.register_buffer("freqs", 1.0 / (theta ** (torch.arange(0, dim, 2)[: dim // 2].float() / dim)))
+
+
+class SinusoidalPosEmb(nn.Module):
+    """Parameter-free slot 0 of `time_mlp` (model/utils.py:67-79); computed in the HIP time path."""
+
+    def __init__(self, dim: int):
+        super().__init__()
+        self.dim = dim
+
+
+class DenseFiLM(nn.Module):
+    def __init__(self, d: int):
+        super().__init__()
+        self.block = nn.Sequential(nn.Mish(), nn.Linear(d, 2 * d))
+
+
+class _EncoderLayerParams(nn.Module):
+    """Parameter layout of TransformerEncoderLayerRotary (transformer_modules.py:36-66)."""
+
+    def __init__(self, d, nhead, ff, dropout, rotary):
+        super().__init__()
+        self.self_attn = nn.MultiheadAttention(d, nhead, dropout=dropout, batch_first=True)
+        self.linear1 = nn.Linear(d, ff)
+        self.linear2 = nn.Linear(ff, d)
+        self.norm1 = nn.LayerNorm(d)
+        self.norm2 = nn.LayerNorm(d)
+        self.rotary = rotary
+
+
+class _DecoderLayerParams(nn.Module):
+    """Parameter layout of FiLMTransformerDecoderLayer (transformer_modules.py:127-175)."""
+
+    def __init__(self, d, nhead, ff, dropout, rotary, use_cm):
+        super().__init__()
+        self.self_attn = nn.MultiheadAttention(d, nhead, dropout=dropout, batch_first=True)
+        self.multihead_attn = nn.MultiheadAttention(d, nhead, dropout=dropout, batch_first=True)
+        self.linear1 = nn.Linear(d, ff)
+        self.linear2 = nn.Linear(ff, d)
+        self.norm1, self.norm2, self.norm3 = nn.LayerNorm(d), nn.LayerNorm(d), nn.LayerNorm(d)
+        self.film1, self.film2, self.film3 = DenseFiLM(d), DenseFiLM(d), DenseFiLM(d)
+        if use_cm:
+            self.multihead_attn2 = nn.MultiheadAttention(d, nhead, dropout=dropout, batch_first=True)
+            self.norm2a = nn.LayerNorm(d)
+            self.film2a = DenseFiLM(d)
+        self.rotary = rotary
+
+
+class DecoderLayerStack(nn.Module):
+    def __init__(self, stack: nn.ModuleList):
+        super().__init__()
+        self.stack = stack
+
+
+class FiLMTransformer(nn.Module):
+    def __init__(self, args, nfeats: int, latent_dim: int = 512, ff_size: int = 1024, num_layers: int = 4,
+                 num_heads: int = 4, dropout: float = 0.1, cond_feature_dim: int = 4800,
+                 activation: Callable = F.gelu, use_rotary: bool = True, cond_mode: str = "audio",
+                 split_type: str = "train", device: str = "cuda", audio_frontend: Optional[Callable] = None,
+                 precision: str = "fp32", max_batch: int = 32, **kwargs) -> None:
+        super().__init__()
+        if not use_rotary:
+            raise NotImplementedError("--not_rotary (absolute PE) is not on the accelerated path")
+        if cond_mode != "audio":
+            raise NotImplementedError("only cond_mode='audio' is on the accelerated path")
+        if activation is not F.gelu:
+            raise NotImplementedError("the reference factory always passes F.gelu (utils/model_util.py:66)")
+        self.nfeats = nfeats
+        self.cond_mode = cond_mode
+        self.cond_feature_dim = cond_feature_dim
+        self.add_frame_cond = args.add_frame_cond
+        self.data_format = args.data_format
+        self.split_type = split_type
+        self.device = device
+        self.seq_len = args.max_seq_length
+        self.audio_frontend = audio_frontend
+        self.precision = precision
+        self.max_batch = max_batch
+        d = latent_dim
+        self.latent_dim, self.ff_size, self.num_layers, self.num_heads = d, ff_size, num_layers, num_heads
+
+        self.rotary = RotaryEmbedding(dim=d)
+        self.abs_pos_encoding = nn.Identity()
+        self.time_mlp = nn.Sequential(SinusoidalPosEmb(d), nn.Linear(d, d * 4), nn.Mish())
+        self.to_time_cond = nn.Sequential(nn.Linear(d * 4, d))
+        self.to_time_tokens = nn.Sequential(nn.Linear(d * 4, d * 2), nn.Identity())
+        emb_len = 1998  # same hard-coded length as model/diffusion.py:136
+        self.emb_len = emb_len
+        self.null_cond_embed = nn.Parameter(torch.randn(1, emb_len, d))
+        self.null_cond_hidden = nn.Parameter(torch.randn(1, d))
+        self.norm_cond = nn.LayerNorm(d)
+
+        self.input_projection = nn.Linear(nfeats, d)
+        if self.data_format == "pose":
+            cond_feature_dim = 1024
+            self.step = 30
+            self.use_cm = True
+            n_key = len(list(range(self.seq_len))[:: self.step])
+            self.null_pose_embed = nn.Parameter(torch.randn(1, n_key, d))
+            self.frame_cond_projection = nn.Linear(104, d)
+            self.frame_norm_cond = nn.LayerNorm(d)
+            self.resume_trans = getattr(args, "resume_trans", None) if split_type == "test" else None
+            hid = max(256, nfeats)
+            chans = [(nfeats, hid, 1), (hid, nfeats, 2), (nfeats, nfeats, 3), (nfeats, nfeats, 1),
+                     (nfeats, nfeats, 2), (nfeats, nfeats, 3)]
+            self.post_pose_layers = nn.ModuleList([nn.Conv1d(ci, co, kernel_size=3, dilation=dl) for ci, co, dl in chans])
+            self.post_pose_layers.apply(init_weight)
+            self.final_conv = nn.Conv1d(nfeats, nfeats, kernel_size=1)
+            self.receptive_field = 25
+        elif self.data_format == "face":
+            self.use_cm = False
+            cond_feature_dim = 1024 + 1014
+            self.cond_encoder = nn.Sequential(*[_EncoderLayerParams(d, num_heads, ff_size, dropout, self.rotary)
+                                                for _ in range(2)])
+            self.cond_encoder.apply(init_weight)
+        else:
+            raise ValueError(f"unknown data_format {self.data_format}")
+        self.cond_feature_dim = cond_feature_dim
+        self.cond_projection = nn.Linear(cond_feature_dim, d)
+        self.non_attn_cond_projection = nn.Sequential(nn.LayerNorm(d), nn.Linear(d, d), nn.SiLU(), nn.Linear(d, d))
+        self.seqTransDecoder = DecoderLayerStack(nn.ModuleList(
+            [_DecoderLayerParams(d, num_heads, ff_size, dropout, self.rotary, self.use_cm) for _ in range(num_layers)]))
+        self.seqTransDecoder.apply(init_weight)
+        self.final_layer = nn.Linear(d, nfeats)
+        self.final_layer.apply(init_weight)
+
+        self._ctx: Optional[C.c_void_p] = None
+        self._ctx_key = None
+        self._weights_key = None
+        self._cond_key = None
+
+    # ------------------------------------------------------------------ plumbing
+    def spec(self) -> DenoiserSpec:
+        return DenoiserSpec(self.data_format, self.nfeats, self.latent_dim, self.num_layers, self.num_heads,
+                            self.ff_size, self.cond_feature_dim, self.seq_len, self.emb_len)
+
+    def parameters_w_grad(self):
+        return [p for p in self.parameters() if p.requires_grad]
+
+    def _hot_state(self) -> Dict[str, torch.Tensor]:
+        return {k: v for k, v in self.state_dict().items() if not k.endswith("rotary.freqs")}
+
+    def _ensure_ctx(self, device: torch.device, batch: int):
+        lib = _lib.load()
+        prec = _PRECISIONS[self.precision]
+        cap = max(self.max_batch, batch)
+        key = (str(device), prec, cap)
+        if self._ctx is not None and self._ctx_key == key:
+            return lib
+        self.release()
+        cfg = _lib.A2PConfig(
+            data_format=_lib.POSE if self.data_format == "pose" else _lib.FACE, nfeats=self.nfeats,
+            latent_dim=self.latent_dim, ff_size=self.ff_size, num_layers=self.num_layers, num_heads=self.num_heads,
+            cond_feature_dim=self.cond_feature_dim, max_frames=self.seq_len, emb_len=self.emb_len,
+            keyframe_dim=104, keyframe_step=30, precision=prec, max_batch=cap, reserved=0)
+        ctx = C.c_void_p()
+        with torch.cuda.device(device):
+            _lib.check(lib.a2p_ctx_create(C.byref(cfg), C.byref(ctx)), "a2p_ctx_create")
+        self._ctx, self._ctx_key, self._weights_key, self._cond_key = ctx, key, None, None
+        return lib
+
+    def _ensure_weights(self, lib, device):
+        state = self._hot_state()
+        key = tuple((k, v.data_ptr(), v._version) for k, v in state.items())
+        if key == self._weights_key:
+            return
+        stream = _lib.current_stream()
+        keep = []
+        for name, t in state.items():
+            t = t.detach().to(device=device, dtype=torch.float32).contiguous()
+            keep.append(t)
+            _lib.check(lib.a2p_set_weight(self._ctx, name.encode(), _lib.ptr(t), t.numel(), stream), f"a2p_set_weight({name})")
+        _lib.check(lib.a2p_finalize_weights(self._ctx, stream), "a2p_finalize_weights")
+        self._weights_key, self._cond_key = key, None
+
+    def release(self):
+        if self._ctx is not None:
+            _lib.load().a2p_ctx_destroy(self._ctx)
+            self._ctx = None
+
+    def __del__(self):
+        try:
+            self.release()
+        except Exception:
+            pass
+
+    def set_precision(self, precision: str):
+        assert precision in _PRECISIONS
+        if precision != self.precision:
+            self.precision = precision
+            self.release()
+
+    # ------------------------------------------------------------------ conditioning (hoisted)
+    def _cond_embed(self, y) -> torch.Tensor:
+        if "cond_embed" in y:
+            return y["cond_embed"]
+        if self.audio_frontend is not None:
+            return self.audio_frontend(y["audio"])
+        raise _lib.A2PError(
+            "no audio front end: pass the wav2vec(+lip) features as y['cond_embed'] "
+            f"[B, n_tok, {self.cond_feature_dim}] or construct the model with audio_frontend=...")
+
+    def prepare(self, x: torch.Tensor, y) -> None:
+        """Hoist everything t-independent for this `y` (cached until y's tensors change)."""
+        _lib.require_gpu_tensor(x, "x")
+        B, T = x.shape[0], x.shape[-1] if x.dim() == 4 else x.shape[1]
+        lib = self._ensure_ctx(x.device, B)
+        self._ensure_weights(lib, x.device)
+        ce = self._cond_embed(y)
+        kf = mask = None
+        if self.data_format == "pose":
+            kf, mask = y["keyframes"], y["mask"]
+
+        def cache_key():
+            k = [ce.data_ptr(), ce._version, tuple(ce.shape), T]
+            if kf is not None:
+                k += [kf.data_ptr(), kf._version, mask.data_ptr(), mask._version]
+            return tuple(k)
+
+        if cache_key() == self._cond_key:
+            return
+        ce = ce.to(device=x.device, dtype=torch.float32).contiguous()
+        assert ce.shape[0] == B and ce.shape[2] == self.cond_feature_dim, f"cond_embed shape {tuple(ce.shape)}"
+        kf_d = mk_d = None
+        n_key = 0
+        if self.data_format == "pose":
+            new_mask = mask[..., :: self.step].reshape(B, -1)           # y["mask"][..., ::step].squeeze((1, 2))
+            kf[~new_mask.to(kf.device)] = 0.0                             # the reference pads y in place (:320)
+            kf_d = kf.to(device=x.device, dtype=torch.float32).contiguous()
+            mk_d = new_mask.to(device=x.device, dtype=torch.uint8).contiguous()
+            n_key = kf_d.shape[1]
+            assert mk_d.shape[1] == n_key, "mask[..., ::step] and keyframes disagree"
+        _lib.check(lib.a2p_prepare_cond(self._ctx, _lib.ptr(ce), B, ce.shape[1], _lib.ptr(kf_d), _lib.ptr(mk_d), n_key, T,
+                                        _lib.current_stream()), "a2p_prepare_cond")
+        ce = self._cond_embed(y)
+        self._cond_key = cache_key()
+
+    # ------------------------------------------------------------------ forward
+    def _run(self, x, times, y, pass_id, scale=None) -> torch.Tensor:
+        if x.dim() == 3:  # [B, T, C] accepted by the reference too (model/diffusion.py:345)
+            x = x.permute(0, 2, 1).unsqueeze(2)
+        x = x.to(torch.float32).contiguous()
+        self.prepare(x, y)
+        B, T = x.shape[0], x.shape[-1]
+        out = torch.empty(B, T, self.nfeats, device=x.device, dtype=torch.float32)
+        ts = times.to(device=x.device, dtype=torch.int64).contiguous()
+        sc = None if scale is None else scale.to(device=x.device, dtype=torch.float32).contiguous()
+        _lib.check(_lib.load().a2p_denoise_forward(self._ctx, _lib.ptr(x), _lib.ptr(ts), _lib.ptr(sc), pass_id, _lib.ptr(out),
+                                                   _lib.current_stream()), "a2p_denoise_forward")
+        return out
+
+    def forward(self, x: torch.Tensor, times: torch.Tensor, y=None, cond_drop_prob: float = 0.0) -> torch.Tensor:
+        if cond_drop_prob == 0.0:
+            return self._run(x, times, y, _lib.PASS_COND)
+        if cond_drop_prob == 1.0:
+            return self._run(x, times, y, _lib.PASS_UNCOND)
+        raise NotImplementedError("stochastic conditioning dropout is a training feature (out of scope)")
+
+    def forward_cfg(self, x, times, y) -> torch.Tensor:
+        """Both guidance passes batched as 2B sequences + the lerp (model/cfg_sampler.py:30-33)."""
+        return self._run(x, times, y, _lib.PASS_CFG, y["scale"])
+
+    def sample_step(self, sampler: int, x, t_idx, timestep_map, tables, y, noise, eta: float, clip_denoised: bool):
+        """Fused p_mean_variance + ddim_sample / p_sample for one step (include/a2p_hip.h a2p_sample_step)."""
+        x = x.to(torch.float32).contiguous()
+        self.prepare(x, y)
+        x_next, x0 = torch.empty_like(x), torch.empty_like(x)
+        sc = y["scale"].to(device=x.device, dtype=torch.float32).contiguous()
+        nz = None if noise is None else noise.to(device=x.device, dtype=torch.float32).contiguous()
+        _lib.check(_lib.load().a2p_sample_step(self._ctx, sampler, _lib.ptr(x), _lib.ptr(t_idx), _lib.ptr(timestep_map),
+                                               _lib.ptr(tables), tables.shape[1], _lib.ptr(sc), _lib.ptr(nz), float(eta),
+                                               int(bool(clip_denoised)), _lib.ptr(x_next), _lib.ptr(x0), _lib.current_stream()),
+                   "a2p_sample_step")
+        return x_next, x0

@@ -1,0 +1,176 @@
+/*
+ * a2p_hip.h -- C ABI of liba2p_hip.so, the MI355X (gfx950) implementation of
+ * audio2photoreal's audio-to-motion diffusion sampling hot path.
+ *
+ * The reference is pure Python/PyTorch and has NO FFI for this path (SURVEY.md
+ * §0, §8b "C-ABI to define (new; nothing to mirror)").  Each entry point below
+ * therefore cites the reference *Python* interface it replaces
+ * (paths relative to /root/reference); INTEGRATION.md shows the ctypes binding a
+ * reference maintainer would add.
+ *
+ * Conventions
+ *  - every pointer is a DEVICE pointer unless the name ends in `_host`;
+ *  - tensors are dense row-major fp32 unless stated; int64 for timesteps
+ *    (the reference passes torch.long, gaussian_diffusion.py:911);
+ *  - all work is enqueued on `stream` (a hipStream_t passed as void*); nothing
+ *    synchronises the device except a2p_ctx_destroy and a2p_kernel_time_ms;
+ *  - return value: 0 = ok, negative = A2P_ERR_* (no exceptions cross the ABI);
+ *    a2p_last_error() returns a static thread-local message;
+ *  - inputs are borrowed for the duration of the enqueued work, outputs are
+ *    caller-allocated (ownership rules of the reference: SURVEY.md §8b
+ *    "Ownership / errors / threading").
+ */
+#ifndef A2P_HIP_H
+#define A2P_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define A2P_OK 0
+#define A2P_ERR_ARG (-1)      /* bad argument / shape (reference: Python assert, gaussian_diffusion.py:286,318-322) */
+#define A2P_ERR_STATE (-2)    /* call order: weights not finalized / conditioning not prepared */
+#define A2P_ERR_HIP (-3)      /* HIP runtime error */
+#define A2P_ERR_NOWEIGHT (-4) /* unknown / missing / mis-sized parameter (reference: load_model asserts, utils/model_util.py:30-38) */
+
+#define A2P_FACE 0
+#define A2P_POSE 1
+
+#define A2P_PREC_F32 0  /* fp32 operands, v_mfma_f32_16x16x4_f32: the parity mode (<=1e-3 vs CPU reference) */
+#define A2P_PREC_BF16 1 /* bf16 operands, fp32 accumulate/statistics/residual: the throughput mode      */
+
+/* cond_drop_prob selector of FiLMTransformer.forward (model/diffusion.py:338-344);
+ * A2P_PASS_CFG = ClassifierFreeSampleModel.forward (model/cfg_sampler.py:30-33). */
+#define A2P_PASS_COND 0
+#define A2P_PASS_UNCOND 1
+#define A2P_PASS_CFG 2
+
+#define A2P_SAMPLER_DDIM 0 /* GaussianDiffusion.ddim_sample (gaussian_diffusion.py:667-718) */
+#define A2P_SAMPLER_DDPM 1 /* GaussianDiffusion.p_sample    (gaussian_diffusion.py:434-477, noise restored) */
+
+typedef struct a2p_ctx a2p_ctx;
+
+/* Constructor contract of FiLMTransformer (model/diffusion.py:83-99) as produced by
+ * utils/model_util.py:49-76, plus the capacity the workspace is sized for. */
+typedef struct a2p_config {
+  int32_t data_format;      /* A2P_FACE | A2P_POSE                      */
+  int32_t nfeats;           /* 256 | 104                                 */
+  int32_t latent_dim;       /* 512 | 256   (must be 256 or 512)          */
+  int32_t ff_size;          /* 1024                                      */
+  int32_t num_layers;       /* 8 | 6                                     */
+  int32_t num_heads;        /* 8   (latent_dim/num_heads must be 32|64)  */
+  int32_t cond_feature_dim; /* 2038 | 1024                               */
+  int32_t max_frames;       /* args.max_seq_length = 600                 */
+  int32_t emb_len;          /* 1998 (model/diffusion.py:136)             */
+  int32_t keyframe_dim;     /* 104                                       */
+  int32_t keyframe_step;    /* 30                                        */
+  int32_t precision;        /* A2P_PREC_*                                */
+  int32_t max_batch;        /* largest B (samples) of any later call     */
+  int32_t reserved;
+} a2p_config;
+
+/* ---- lifetime --------------------------------------------------------------- */
+int a2p_ctx_create(const a2p_config* cfg, a2p_ctx** out);
+int a2p_ctx_destroy(a2p_ctx* ctx);
+const char* a2p_last_error(void);
+const char* a2p_version(void);
+
+/* ---- weights: nn.Module.load_state_dict (utils/model_util.py:30-38) ----------
+ * `name` is the reference state_dict key (SURVEY.md §8b "Weights"), `data` a device
+ * fp32 pointer of `numel` elements (copied).  Unknown names that belong to the
+ * out-of-scope conditioning producers (audio_model.*, lip_model.*, *.rotary.freqs,
+ * transformer.*, tokenizer.*) are accepted and ignored (returns 1). */
+int a2p_set_weight(a2p_ctx* ctx, const char* name, const float* data, int64_t numel, void* stream);
+/* Checks every hot-path parameter was provided, builds the packed compute-dtype
+ * copies, rotary tables and the batch-invariant unconditional K/V caches. */
+int a2p_finalize_weights(a2p_ctx* ctx, void* stream);
+
+/* ---- hoisted conditioning (t-independent part of FiLMTransformer.forward,
+ *      model/diffusion.py:360-381 + the audio-token K/V of every decoder layer) ----
+ * cond_embed : [B, n_tok, cond_feature_dim]  = what encode_audio/encode_lip return
+ *              (model/diffusion.py:355-358); n_tok = 1998 for 600 frames, 798 for 240.
+ * keyframes  : pose only, [B, n_key, keyframe_dim]   (y["keyframes"])
+ * key_mask   : pose only, uint8 [B, n_key], 1 = known (y["mask"][..., ::step]); NULL = all known
+ * frames     : T of the motion sequence that will be denoised. */
+int a2p_prepare_cond(a2p_ctx* ctx, const float* cond_embed, int32_t batch, int32_t n_tok,
+                     const float* keyframes, const uint8_t* key_mask, int32_t n_key,
+                     int32_t frames, void* stream);
+
+/* ---- one denoiser evaluation -------------------------------------------------
+ * FiLMTransformer.forward / ClassifierFreeSampleModel.forward.
+ * x [B, nfeats, 1, T] ; t_orig int64 [B] (already mapped to 0..999, respace.py:140-145);
+ * scale fp32 [B] (y["scale"], A2P_PASS_CFG only) ; out [B, T, nfeats]. */
+int a2p_denoise_forward(a2p_ctx* ctx, const float* x, const int64_t* t_orig, const float* scale,
+                        int32_t pass, float* out, void* stream);
+
+/* ---- fused sampler step: p_mean_variance + ddim_sample / p_sample -------------
+ * tables: fp32 [A2P_NTAB, n_steps] rows in the order of a2p_table_id, built by the host
+ * from the float64 schedule exactly as _extract_into_tensor does (.float());
+ * t_idx int64 [B]: step index into the (respaced) chain; timestep_map int64 [n_steps].
+ * noise may be NULL for DDIM with eta == 0.  Outputs: x_next, pred_xstart, both
+ * [B, nfeats, 1, T] (x_next may alias x). */
+enum a2p_table_id {
+  A2P_TAB_POST_COEF1 = 0,
+  A2P_TAB_POST_COEF2,
+  A2P_TAB_POST_VAR,
+  A2P_TAB_POST_LOGVAR,
+  A2P_TAB_SQRT_RECIP_ACP,
+  A2P_TAB_SQRT_RECIPM1_ACP,
+  A2P_TAB_ACP,
+  A2P_TAB_ACP_PREV,
+  A2P_TAB_SQRT_ACP,
+  A2P_TAB_SQRT_1M_ACP,
+  A2P_NTAB
+};
+int a2p_sample_step(a2p_ctx* ctx, int32_t sampler, const float* x, const int64_t* t_idx,
+                    const int64_t* timestep_map, const float* tables, int32_t n_steps,
+                    const float* scale, const float* noise, float eta, int32_t clip_denoised,
+                    float* x_next, float* pred_xstart, void* stream);
+
+/* ---- stand-alone sampler arithmetic (any model callable on the host side) ------
+ * model_out [B, T, C] -> pred_xstart/mean [B, C, 1, T]: GaussianDiffusion.p_mean_variance
+ * (gaussian_diffusion.py:305-316) + q_posterior_mean_variance (:235-257). */
+int a2p_p_mean_variance(const float* model_out, const float* x, const int64_t* t_idx, const float* tables,
+                        int32_t n_steps, int32_t batch, int32_t nfeats, int32_t frames, int32_t clip_denoised,
+                        float* pred_xstart, float* mean, void* stream);
+/* ddim_sample update (gaussian_diffusion.py:699-717) from pred_xstart. */
+int a2p_ddim_update(const float* pred_xstart, const float* x, const int64_t* t_idx, const float* tables,
+                    int32_t n_steps, const float* noise, float eta, int32_t batch, int64_t per_sample,
+                    float* sample, void* stream);
+/* p_sample update (gaussian_diffusion.py:470-476): mean + [t!=0] exp(.5 logvar) noise. */
+int a2p_p_sample_update(const float* mean, const int64_t* t_idx, const float* tables, int32_t n_steps,
+                        const float* noise, int32_t batch, int64_t per_sample, float* sample, void* stream);
+/* q_sample (gaussian_diffusion.py:215-233). */
+int a2p_q_sample(const float* x_start, const int64_t* t_idx, const float* tables, int32_t n_steps,
+                 const float* noise, int32_t batch, int64_t per_sample, float* out, void* stream);
+
+/* ---- unit entry points (parity tests of single kernels / one decoder layer) -----
+ * FiLMTransformerDecoderLayer.forward (model/modules/transformer_modules.py:178-217):
+ * x [N, T, d] updated in place; memory [N, S, d]; t [N, d]; memory2 [N, S2, d] or NULL.
+ * Uses the weights of decoder layer `layer`. */
+int a2p_decoder_layer_forward(a2p_ctx* ctx, int32_t layer, float* x, const float* memory, const float* t,
+                              const float* memory2, int32_t nseq, int32_t frames, int32_t mem_len,
+                              int32_t mem2_len, void* stream);
+/* C[M,N] = A[M,K] W[N,K]^T + bias on the MFMA GEMM kernel of the context's precision. */
+int a2p_gemm(a2p_ctx* ctx, const float* A, const float* W, const float* bias, float* C, int32_t M, int32_t N,
+             int32_t K, void* stream);
+/* softmax(q k^T / sqrt(dh)) v per head; q [N, Tq, d], k/v [N, S, d], out [N, Tq, d]. */
+int a2p_attention(a2p_ctx* ctx, const float* q, const float* k, const float* v, float* out, int32_t nseq,
+                  int32_t tq, int32_t s, void* stream);
+
+/* ---- measurement (bench.py roofline leg) ----------------------------------------
+ * When enabled, every launch of the kernel class `kind` is bracketed by hipEvents on
+ * the launch stream; a2p_kernel_time_ms synchronises and returns total ms and count. */
+#define A2P_KERNEL_GEMM 0
+#define A2P_KERNEL_ATTN_SELF 1
+#define A2P_KERNEL_ATTN_CROSS 2
+#define A2P_KERNEL_LNROPE 3
+int a2p_kernel_timing(a2p_ctx* ctx, int32_t kind, int32_t enable);
+int a2p_kernel_time_ms(a2p_ctx* ctx, double* total_ms, int64_t* launches);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* A2P_HIP_H */

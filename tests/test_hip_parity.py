@@ -1,0 +1,229 @@
+"""Parity of the HIP path (through the C ABI) against the golden vectors produced by the
+reference and against the pinned oracle.  Needs a real MI355X: `pytest -m gpu`.
+
+Tolerances: fp32 mode <= 1e-3 relative (north_star; observed ~1e-5..1e-4);
+bf16 mode is the throughput mode, its measured error is asserted loosely and printed.
+"""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+from audio2photoreal_amd import _lib
+from audio2photoreal_amd.model.cfg_sampler import ClassifierFreeSampleModel
+from audio2photoreal_amd.model_util import create_model_and_diffusion, default_args, load_model
+from audio2photoreal_amd.spec import face_spec, pose_spec
+from audio2photoreal_amd.synthetic import synthetic_inputs, synthetic_state_dict, synthetic_tensor
+from conftest import rel_l2, rel_max
+
+pytestmark = pytest.mark.gpu
+SEED = 10
+TOL = {"fp32": 1e-3, "bf16": 6e-2}
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "GPU tests need the MI355X"
+    return torch.device("cuda:0")
+
+
+_MODELS = {}
+
+
+def get_model(fmt, precision, dev, respacing="ddim10"):
+    key = (fmt, precision)
+    if key not in _MODELS:
+        spec = face_spec() if fmt == "face" else pose_spec()
+        args = default_args(fmt, timestep_respacing=respacing)
+        model, _ = create_model_and_diffusion(args, "test", precision=precision, max_batch=4)
+        load_model(model, synthetic_state_dict(spec, SEED))
+        _MODELS[key] = (spec, model.to(dev).eval())
+    return _MODELS[key]
+
+
+def make_diffusion(fmt, respacing):
+    from audio2photoreal_amd.model_util import create_gaussian_diffusion
+    return create_gaussian_diffusion(default_args(fmt, timestep_respacing=respacing))
+
+
+def y_for(spec, inp, dev, scale):
+    B = inp["x_T"].shape[0]
+    y = {"cond_embed": inp["cond_embed"].to(dev), "scale": torch.full((B,), scale, device=dev)}
+    if spec.is_pose:
+        y["keyframes"] = inp["keyframes"].clone().to(dev)
+        y["mask"] = inp["mask"].clone().to(dev)
+    return y
+
+
+# ----------------------------------------------------------------------------- kernels
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+def test_gemm_kernel(dev, precision):
+    spec, model = get_model("face", precision, dev)
+    model._ensure_ctx(dev, 1)
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(1)
+    for (M, N, K) in [(300, 512, 512), (129, 104, 256), (64, 1024, 2038), (1000, 256, 104)]:
+        A = torch.randn(M, K, generator=g)
+        W = torch.randn(N, K, generator=g) / K ** 0.5
+        b = torch.randn(N, generator=g)
+        ref = A.double() @ W.double().T + b.double()     # asymmetric operands: catches transposes
+        Ad, Wd, bd = A.to(dev), W.to(dev), b.to(dev)
+        out = torch.empty(M, N, device=dev)
+        _lib.check(lib.a2p_gemm(model._ctx, _lib.ptr(Ad), _lib.ptr(Wd), _lib.ptr(bd), _lib.ptr(out), M, N, K,
+                                _lib.current_stream()), "a2p_gemm")
+        err = rel_l2(out.cpu(), ref)
+        assert err < (2e-6 if precision == "fp32" else 1e-2), (M, N, K, err)
+
+
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+@pytest.mark.parametrize("fmt", ["face", "pose"])
+def test_attention_kernel(dev, precision, fmt):
+    spec, model = get_model(fmt, precision, dev)
+    model._ensure_ctx(dev, 1)
+    lib = _lib.load()
+    d, H = spec.latent_dim, spec.num_heads
+    g = torch.Generator().manual_seed(2)
+    for (N, Tq, S) in [(2, 100, 77), (1, 240, 800), (3, 33, 20)]:
+        q, k, v = (torch.randn(N, L, d, generator=g) for L in (Tq, S, S))
+        k[0, 5] *= 6.0  # spike one key: forces the online-softmax rescale branch
+        dh = d // H
+        qh, kh, vh = (t.view(N, -1, H, dh).transpose(1, 2).double() for t in (q, k, v))
+        ref = (torch.softmax(qh @ kh.transpose(-1, -2) / dh ** 0.5, -1) @ vh).transpose(1, 2).reshape(N, Tq, d)
+        out = torch.empty(N, Tq, d, device=dev)
+        _lib.check(lib.a2p_attention(model._ctx, _lib.ptr(q.to(dev)), _lib.ptr(k.to(dev)), _lib.ptr(v.to(dev)),
+                                     _lib.ptr(out), N, Tq, S, _lib.current_stream()), "a2p_attention")
+        err = rel_l2(out.cpu(), ref)
+        assert err < (5e-6 if precision == "fp32" else 2e-2), (N, Tq, S, err)
+
+
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+@pytest.mark.parametrize("fmt", ["face", "pose"])
+def test_decoder_layer_vs_reference_golden(dev, golden, precision, fmt):
+    spec, model = get_model(fmt, precision, dev)
+    model._ensure_ctx(dev, 2)
+    model._ensure_weights(_lib.load(), dev)
+    d = spec.latent_dim
+    x = synthetic_tensor(SEED, "layer_x", (2, 48, d)).to(dev)
+    mem = synthetic_tensor(SEED, "layer_mem", (2, 80, d)).to(dev)
+    t = synthetic_tensor(SEED, "layer_t", (2, d)).to(dev)
+    mem2 = synthetic_tensor(SEED, "layer_mem2", (2, 8, d)).to(dev) if spec.is_pose else None
+    _lib.check(_lib.load().a2p_decoder_layer_forward(model._ctx, 0, _lib.ptr(x), _lib.ptr(mem), _lib.ptr(t), _lib.ptr(mem2),
+                                                     2, 48, 80, 8 if spec.is_pose else 0, _lib.current_stream()), "layer")
+    err = rel_l2(x.cpu(), golden[f"{fmt}/layer0"])
+    print(f"decoder layer {fmt} {precision}: rel L2 = {err:.3e}")
+    assert err < (1e-4 if precision == "fp32" else 2e-2)
+
+
+# ----------------------------------------------------------------------------- denoiser
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+@pytest.mark.parametrize("fmt", ["face", "pose"])
+def test_forward_vs_reference_golden(dev, golden, precision, fmt):
+    spec, model = get_model(fmt, precision, dev)
+    inp = synthetic_inputs(spec, 2, 240, SEED)
+    if spec.is_pose:
+        inp["mask"][1, :, :, 90:] = False
+    scale = 10.0 if fmt == "face" else 2.0
+    y = y_for(spec, inp, dev, scale)
+    times = torch.tensor([937, 12], device=dev)
+    x = inp["x_T"].to(dev)
+    c = model(x, times, y, cond_drop_prob=0.0)
+    u = model(x, times, y, cond_drop_prob=1.0)
+    g = ClassifierFreeSampleModel(model)(x, times, y)
+    errs = (rel_l2(c.cpu(), golden[f"{fmt}/fwd_cond"]), rel_l2(u.cpu(), golden[f"{fmt}/fwd_uncond"]),
+            rel_l2(g.cpu(), golden[f"{fmt}/fwd_cfg"]))
+    print(f"forward {fmt} {precision}: cond/uncond/cfg rel L2 = {errs}")
+    tol = 2e-4 if precision == "fp32" else 5e-2
+    assert all(e < tol for e in errs[:2]) and errs[2] < 5 * tol, errs
+    if spec.is_pose:   # the reference zeroes masked keyframes in y, in place (model/diffusion.py:320)
+        assert float(y["keyframes"][1, 3:].abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("fmt", ["face", "pose"])
+def test_ddim10_fp32_vs_reference_golden(dev, golden, fmt):
+    """Config 0 (face B=1 T=240) and the pose B=2 T=600 variant, fused path, fp32 mode: <= 1e-3."""
+    spec, model = get_model(fmt, "fp32", dev)
+    B, frames = (1, 240) if fmt == "face" else (2, 600)
+    inp = synthetic_inputs(spec, B, frames, SEED)
+    y = y_for(spec, inp, dev, 10.0 if fmt == "face" else 2.0)
+    diffusion = make_diffusion(fmt, "ddim10")
+    res = diffusion.ddim_sample_loop(ClassifierFreeSampleModel(model), (B, spec.nfeats, 1, frames), clip_denoised=False,
+                                     model_kwargs={"y": y}, noise=inp["x_T"].to(dev))
+    e2, em = rel_l2(res.cpu(), golden[f"{fmt}/ddim10"]), rel_max(res.cpu(), golden[f"{fmt}/ddim10"])
+    print(f"ddim10 {fmt} fp32: rel L2 {e2:.3e} max-norm {em:.3e}")
+    assert e2 < 1e-3 and em < 1e-3
+
+
+@pytest.mark.parametrize("fmt", ["face", "pose"])
+def test_ddpm_restored_noise_fp32_vs_reference_golden(dev, golden, fmt):
+    spec, model = get_model(fmt, "fp32", dev)
+    cfg = ClassifierFreeSampleModel(model)
+    inp = synthetic_inputs(spec, 1, 240, SEED, steps_of_noise=10)
+    y = y_for(spec, inp, dev, 10.0 if fmt == "face" else 2.0)
+    noise = inp["step_noise"].to(dev)
+    res = make_diffusion(fmt, "ddim10").p_sample_loop(cfg, (1, spec.nfeats, 1, 240), clip_denoised=False, model_kwargs={"y": y},
+                                                      noise=inp["x_T"].to(dev), step_noise=lambda n: noise[n])
+    assert rel_l2(res.cpu(), golden[f"{fmt}/ddpm10"]) < 1e-3
+    assert rel_max(res.cpu(), golden[f"{fmt}/ddpm10"]) < 1e-3
+    # first 3 steps of the full 1000-step chain
+    inp = synthetic_inputs(spec, 1, 240, SEED, steps_of_noise=3)
+    y = y_for(spec, inp, dev, 10.0 if fmt == "face" else 2.0)
+    noise = inp["step_noise"].to(dev)
+    gen = make_diffusion(fmt, "").p_sample_loop_progressive(cfg, (1, spec.nfeats, 1, 240), clip_denoised=False,
+                                                            model_kwargs={"y": y}, noise=inp["x_T"].to(dev),
+                                                            step_noise=lambda n: noise[n])
+    for _, out in zip(range(3), gen):
+        last = out
+    assert rel_l2(last["sample"].cpu(), golden[f"{fmt}/ddpm1000_first3"]) < 1e-3
+
+
+def test_generic_path_matches_fused(dev):
+    """p_mean_variance through the model protocol (`model(x, ts, **kw)`, any callable) == fused step."""
+    spec, model = get_model("face", "fp32", dev)
+    cfg = ClassifierFreeSampleModel(model)
+    inp = synthetic_inputs(spec, 2, 64, SEED)
+    y = y_for(spec, inp, dev, 10.0)
+    d = make_diffusion("face", "ddim10")
+    x = inp["x_T"].to(dev)
+    t = torch.tensor([7, 7], device=dev)
+    fused = d.ddim_sample(cfg, x, t, clip_denoised=False, model_kwargs={"y": y})
+    generic = d.ddim_sample(lambda xx, ts, **kw: cfg(xx, ts, **kw), x, t, clip_denoised=False, model_kwargs={"y": y})
+    assert rel_l2(generic["sample"].cpu(), fused["sample"].cpu()) < 1e-6
+    assert rel_l2(generic["pred_xstart"].cpu(), fused["pred_xstart"].cpu()) < 1e-6
+    pf = d.p_sample(cfg, x, t, clip_denoised=True, model_kwargs={"y": y}, noise=torch.ones_like(x))
+    pg = d.p_sample(lambda xx, ts, **kw: cfg(xx, ts, **kw), x, t, clip_denoised=True, model_kwargs={"y": y}, noise=torch.ones_like(x))
+    assert rel_l2(pg["sample"].cpu(), pf["sample"].cpu()) < 1e-6
+    assert float(pf["pred_xstart"].abs().max()) <= 1.0
+
+
+def test_bf16_mode_error_reported(dev, golden):
+    """Throughput mode: measured error of 10 DDIM steps vs the fp32 reference (SURVEY.md §0 fact 3 expects ~7e-3)."""
+    spec, model = get_model("face", "bf16", dev)
+    inp = synthetic_inputs(spec, 1, 240, SEED)
+    y = y_for(spec, inp, dev, 10.0)
+    res = make_diffusion("face", "ddim10").ddim_sample_loop(ClassifierFreeSampleModel(model), (1, spec.nfeats, 1, 240),
+                                                            clip_denoised=False, model_kwargs={"y": y}, noise=inp["x_T"].to(dev))
+    e = rel_l2(res.cpu(), golden["face/ddim10"])
+    print(f"bf16 ddim10 face: rel L2 vs fp32 reference = {e:.3e}")
+    assert e < 0.1
+
+
+def test_properties_full_size(dev):
+    """Size-independent properties at BASELINE config-1 size (face, B=8, T=600), bf16 mode:
+    batch independence (sample b does not depend on its neighbours) and determinism."""
+    spec, _ = get_model("face", "bf16", dev)
+    args = default_args("face", timestep_respacing="")
+    model, _ = create_model_and_diffusion(args, "test", precision="bf16", max_batch=8)
+    load_model(model, synthetic_state_dict(spec, SEED))
+    cfg = ClassifierFreeSampleModel(model.to(dev).eval())
+    inp = synthetic_inputs(spec, 8, 600, SEED)
+    y = y_for(spec, inp, dev, 10.0)
+    x = inp["x_T"].to(dev)
+    t = torch.full((8,), 500, device=dev)
+    full = cfg(x, t, y)
+    again = cfg(x, t, y)
+    assert torch.equal(full, again)
+    y2 = {"cond_embed": y["cond_embed"][2:4].contiguous(), "scale": y["scale"][2:4].contiguous()}
+    part = cfg(x[2:4].contiguous(), t[2:4], y2)
+    assert rel_l2(part.cpu(), full[2:4].cpu()) < 1e-6
+    assert torch.isfinite(full).all()
