@@ -51,6 +51,9 @@ def load() -> C.CDLL:
     global _lib
     if _lib is not None:
         return _lib
+    # torch first: its bundled libamdhip64.so.7 must be the one HIP runtime of the process (the
+    # library shares torch's device pointers and streams; loading /opt/rocm's copy first breaks both)
+    import torch  # noqa: F401
     if not os.path.exists(LIB_PATH):
         raise A2PError(
             f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "

@@ -162,7 +162,8 @@ class GaussianDiffusion:
         noise = self._prep(noise)
         out = th.empty_like(x_start)
         B = x_start.shape[0]
-        _lib.check(_lib.load().a2p_q_sample(_lib.ptr(x_start), _lib.ptr(t.to(th.int64).contiguous()), _lib.ptr(self._tables(x_start.device)),
+        t64 = t.to(th.int64).contiguous()
+        _lib.check(_lib.load().a2p_q_sample(_lib.ptr(x_start), _lib.ptr(t64), _lib.ptr(self._tables(x_start.device)),
                                             self.num_timesteps, _lib.ptr(noise), B, x_start.numel() // B, _lib.ptr(out),
                                             _lib.current_stream()), "a2p_q_sample")
         return out
@@ -174,7 +175,8 @@ class GaussianDiffusion:
         B, C, _, T = x_t.shape
         as_btc = self._prep(x_start).squeeze(2).permute(0, 2, 1).contiguous()
         x0, mean = th.empty_like(x_t), th.empty_like(x_t)
-        _lib.check(_lib.load().a2p_p_mean_variance(_lib.ptr(as_btc), _lib.ptr(x_t), _lib.ptr(t.to(th.int64).contiguous()),
+        t64 = t.to(th.int64).contiguous()
+        _lib.check(_lib.load().a2p_p_mean_variance(_lib.ptr(as_btc), _lib.ptr(x_t), _lib.ptr(t64),
                                                    _lib.ptr(self._tables(x_t.device)), self.num_timesteps, B, C, T, 0,
                                                    _lib.ptr(x0), _lib.ptr(mean), _lib.current_stream()), "a2p_p_mean_variance")
         return mean, self._tab("posterior_variance", t, x_t), self._tab("posterior_log_variance_clipped", t, x_t)
@@ -195,7 +197,8 @@ class GaussianDiffusion:
         T = x.shape[-1]
         assert model_output.shape == (B, T, C), f"{tuple(model_output.shape)} != {(B, T, C)}"
         pred, mean = th.empty_like(x), th.empty_like(x)
-        _lib.check(_lib.load().a2p_p_mean_variance(_lib.ptr(model_output), _lib.ptr(x), _lib.ptr(t.to(th.int64).contiguous()),
+        t64 = t.to(th.int64).contiguous()
+        _lib.check(_lib.load().a2p_p_mean_variance(_lib.ptr(model_output), _lib.ptr(x), _lib.ptr(t64),
                                                    _lib.ptr(self._tables(x.device)), self.num_timesteps, B, C, T,
                                                    int(bool(clip_denoised)), _lib.ptr(pred), _lib.ptr(mean),
                                                    _lib.current_stream()), "a2p_p_mean_variance")
@@ -223,7 +226,8 @@ class GaussianDiffusion:
         x = self._prep(x)
         tmap = self._timestep_map_tensor(x.device) if hasattr(self, "_timestep_map_tensor") else \
             self._dev_cache.setdefault(("tmap", str(x.device)), th.arange(self.num_timesteps, device=x.device, dtype=th.int64))
-        sample, x0 = model.a2p_sample_step(sampler, x, t.to(th.int64).contiguous(), tmap, self._tables(x.device),
+        t64 = t.to(th.int64).contiguous()
+        sample, x0 = model.a2p_sample_step(sampler, x, t64, tmap, self._tables(x.device),
                                            (model_kwargs or {})["y"], noise, eta, clip_denoised)
         return {"sample": sample, "pred_xstart": x0}
 
@@ -241,9 +245,10 @@ class GaussianDiffusion:
         out = self.p_mean_variance(model, x, t, clip_denoised=clip_denoised, denoised_fn=denoised_fn, model_kwargs=model_kwargs)
         sample = th.empty_like(out["mean"])
         B = x.shape[0]
-        _lib.check(_lib.load().a2p_p_sample_update(_lib.ptr(out["mean"]), _lib.ptr(t.to(th.int64).contiguous()),
+        t64, nz = t.to(th.int64).contiguous(), self._prep(noise)
+        _lib.check(_lib.load().a2p_p_sample_update(_lib.ptr(out["mean"]), _lib.ptr(t64),
                                                    _lib.ptr(self._tables(x.device)), self.num_timesteps,
-                                                   _lib.ptr(self._prep(noise)), B, x.numel() // B, _lib.ptr(sample),
+                                                   _lib.ptr(nz), B, x.numel() // B, _lib.ptr(sample),
                                                    _lib.current_stream()), "a2p_p_sample_update")
         return {"sample": sample, "pred_xstart": out["pred_xstart"]}
 
@@ -260,9 +265,10 @@ class GaussianDiffusion:
         x = self._prep(x)
         sample = th.empty_like(x)
         B = x.shape[0]
-        _lib.check(_lib.load().a2p_ddim_update(_lib.ptr(out["pred_xstart"]), _lib.ptr(x), _lib.ptr(t.to(th.int64).contiguous()),
+        t64, nz = t.to(th.int64).contiguous(), (None if noise is None else self._prep(noise))
+        _lib.check(_lib.load().a2p_ddim_update(_lib.ptr(out["pred_xstart"]), _lib.ptr(x), _lib.ptr(t64),
                                                _lib.ptr(self._tables(x.device)), self.num_timesteps,
-                                               _lib.ptr(None if noise is None else self._prep(noise)), float(eta), B,
+                                               _lib.ptr(nz), float(eta), B,
                                                x.numel() // B, _lib.ptr(sample), _lib.current_stream()), "a2p_ddim_update")
         return {"sample": sample, "pred_xstart": out["pred_xstart"]}
 

@@ -91,7 +91,8 @@ def test_attention_kernel(dev, precision, fmt):
         qh, kh, vh = (t.view(N, -1, H, dh).transpose(1, 2).double() for t in (q, k, v))
         ref = (torch.softmax(qh @ kh.transpose(-1, -2) / dh ** 0.5, -1) @ vh).transpose(1, 2).reshape(N, Tq, d)
         out = torch.empty(N, Tq, d, device=dev)
-        _lib.check(lib.a2p_attention(model._ctx, _lib.ptr(q.to(dev)), _lib.ptr(k.to(dev)), _lib.ptr(v.to(dev)),
+        qd, kd, vd = q.to(dev), k.to(dev), v.to(dev)   # keep alive: ptr() of a temporary dangles
+        _lib.check(lib.a2p_attention(model._ctx, _lib.ptr(qd), _lib.ptr(kd), _lib.ptr(vd),
                                      _lib.ptr(out), N, Tq, S, _lib.current_stream()), "a2p_attention")
         err = rel_l2(out.cpu(), ref)
         assert err < (5e-6 if precision == "fp32" else 2e-2), (N, Tq, S, err)
