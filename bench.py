@@ -180,7 +180,7 @@ def main():
     cpu = None
     if rank == 0 and not a.no_cpu_baseline:
         from oracle import a2p_oracle as O
-        cores = os.cpu_count() or 1
+        cores = min(os.cpu_count() or 1, 32)   # torch CPU matmuls at these sizes stop scaling (and thrash) past ~32 threads
         torch.set_num_threads(cores)
         cb = 1   # bounded sample: 1 sample (of the 8), 2 DDPM steps, same T/S, fp32
         den = O.OracleDenoiser(sd, "face", spec.num_layers, spec.num_heads)
