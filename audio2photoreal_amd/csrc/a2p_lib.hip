@@ -138,15 +138,35 @@ static GemmP gemm_base(const void* A, int64_t lda, const void* W, int64_t ldw, c
   return p;
 }
 
+template <typename T, int MT>
+static int gemm_dispatch(const GemmP& p, hipStream_t s) {
+  dim3 grid((p.N + 127) / 128, (p.M + 32 * MT - 1) / (32 * MT));
+#define A2P_GEMM(EPI, ACT, F32) gemm_kernel<T, MT, EPI, ACT, F32><<<grid, 256, 0, s>>>(p)
+  if (p.epi == EPI_FILM_RES) A2P_GEMM(EPI_FILM_RES, ACT_NONE, false);
+  else if (p.epi == EPI_STORE_T && p.act == ACT_NONE) A2P_GEMM(EPI_STORE_T, ACT_NONE, false);
+  else if (p.epi == EPI_CONV && p.act == ACT_LRELU && !p.out_f32) A2P_GEMM(EPI_CONV, ACT_LRELU, false);
+  else if (p.epi == EPI_STORE && p.act == ACT_NONE && p.out_f32) A2P_GEMM(EPI_STORE, ACT_NONE, true);
+  else if (p.epi == EPI_STORE && p.act == ACT_NONE) A2P_GEMM(EPI_STORE, ACT_NONE, false);
+  else if (p.epi == EPI_STORE && p.act == ACT_GELU && !p.out_f32) A2P_GEMM(EPI_STORE, ACT_GELU, false);
+  else {
+    set_err("gemm: no kernel instance for epi=%d act=%d out_f32=%d", p.epi, p.act, p.out_f32);
+    return A2P_ERR_ARG;
+  }
+#undef A2P_GEMM
+  return 0;
+}
+
 static int launch_gemm(a2p_ctx* c, const GemmP& p, hipStream_t s) {
   const int bk = c->bf16 ? 64 : 32;
   ARG(p.K % bk == 0 && p.N % 4 == 0 && p.M > 0, "gemm: bad shape M=%d N=%d K=%d", p.M, p.N, p.K);
-  dim3 grid((p.N + 127) / 128, (p.M + 127) / 128);
+  // 128x128 tiles unless that leaves the 256 CUs under two blocks each: then 64x128
+  const int64_t blocks128 = (int64_t)((p.N + 127) / 128) * ((p.M + 127) / 128);
+  const bool small = blocks128 < 512;
   KernelTimer kt(c, A2P_KERNEL_GEMM, s);
-  if (c->bf16)
-    gemm_kernel<bf16_t><<<grid, 256, 0, s>>>(p);
-  else
-    gemm_kernel<float><<<grid, 256, 0, s>>>(p);
+  int rc;
+  if (c->bf16) rc = small ? gemm_dispatch<bf16_t, 2>(p, s) : gemm_dispatch<bf16_t, 4>(p, s);
+  else rc = small ? gemm_dispatch<float, 2>(p, s) : gemm_dispatch<float, 4>(p, s);
+  CHK(rc);
   HIPCHK(hipGetLastError());
   return 0;
 }

@@ -1,13 +1,17 @@
 // MFMA GEMM kernels for the denoiser:  C[M,N] = A[M,K] * W[N,K]^T (+bias) with fused epilogues.
 //
-//  * gemm_kernel<T>      : 128x128 block tile, 4 waves (2x2), 16x16 MFMA fragments, LDS-staged
-//                          (register prefetch of the next k-tile), T = float (fp32 MFMA, parity mode)
-//                          or bf16 (throughput mode).  Epilogues: bias+activation store, transposed
-//                          store (V^T for attention), FiLM-affine + residual update of the fp32 stream
-//                          (transformer_modules.py:122-124,193), dilated-conv tap accumulation with
-//                          LeakyReLU/avg-skip (model/diffusion.py:214-224).
-//  * skinny_gemm_kernel  : M <= 64 rows (the per-step time/FiLM path), fp32 MFMA, operands straight
-//                          from global memory, split-K over the 4 waves of a block.
+//  * gemm_kernel<T, MT, EPI, ACT, OUTF32>
+//        (32*MT)x128 block tile (MT = 4: 128x128, MT = 2: 64x128 for launches that would not fill
+//        256 CUs), 4 waves as 2x2, 16x16 MFMA fragments, K-step 64 (bf16) / 32 (fp32).
+//        bf16 (throughput mode): operands go HBM -> LDS directly (global_load_lds, 16 B per lane),
+//        double-buffered, XOR-swizzled on the SOURCE address + on the fragment read so ds_read_b128 is
+//        bank-conflict free with unpadded 128-byte rows (cdna_hip_programming.md §5.4 rule 21, T2).
+//        fp32 (parity mode, v_mfma_f32_16x16x4_f32): register-staged single LDS buffer.
+//        Epilogues are compile-time: bias+activation store (T or fp32), transposed store (V^T for
+//        attention), FiLM-affine + residual update of the fp32 stream (transformer_modules.py:122-124,
+//        193), dilated-conv tap accumulation with LeakyReLU / averaged skip (model/diffusion.py:214-224).
+//  * skinny_gemm_kernel : M <= 64 rows (per-step time / FiLM path), fp32 MFMA, operands straight from
+//        global memory, split-K over the 4 waves of a block.
 #pragma once
 #include "a2p_common.h"
 
@@ -35,119 +39,38 @@ struct GemmP {
   int64_t ld_skip;
 };
 
-template <typename T>
-struct GemmTile {
-  static constexpr int BM = 128, BN = 128;
-  static constexpr int BK = sizeof(T) == 2 ? 64 : 32;
-  static constexpr int PAD = sizeof(T) == 2 ? 8 : 2;
-  static constexpr int LS = BK + PAD;       // LDS row stride (elements)
-  static constexpr int VEC = 16 / sizeof(T);
-  static constexpr int VPR = BK / VEC;      // 16-byte vectors per tile row (= 8)
-};
-
-template <typename T>
-__device__ __forceinline__ void lds_store16(T* dst, uint4 v) {
-  if constexpr (sizeof(T) == 2) {
-    *reinterpret_cast<uint4*>(dst) = v;
-  } else {  // fp32 rows are only 8-byte aligned (stride 34 floats)
-    reinterpret_cast<uint2*>(dst)[0] = make_uint2(v.x, v.y);
-    reinterpret_cast<uint2*>(dst)[1] = make_uint2(v.z, v.w);
-  }
+template <int ACT, bool FAST>
+__device__ __forceinline__ float act_ct(float x) {
+  if constexpr (ACT == ACT_GELU) return FAST ? act_gelu_fast(x) : act_gelu(x);
+  else if constexpr (ACT == ACT_MISH) return act_mish(x);
+  else if constexpr (ACT == ACT_SILU) return act_silu(x);
+  else if constexpr (ACT == ACT_LRELU) return act_lrelu02(x);
+  else return x;
 }
 
-template <typename T>
-__global__ __launch_bounds__(256) void gemm_kernel(GemmP p) {
-  using P = Prec<T>;
-  using G = GemmTile<T>;
-  constexpr int BM = G::BM, BN = G::BN, BK = G::BK, LS = G::LS, VEC = G::VEC;
-  __shared__ __attribute__((aligned(16))) T As[BM * LS];
-  __shared__ __attribute__((aligned(16))) T Ws[BN * LS];
-
-  const int tid = threadIdx.x;
-  const int lane = tid & 63, wid = tid >> 6;
-  const int l15 = lane & 15, g = lane >> 4;
-  const int wm = wid >> 1, wn = wid & 1;
-  const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
-
-  const T* __restrict__ A = reinterpret_cast<const T*>(p.A);
-  const T* __restrict__ W = reinterpret_cast<const T*>(p.W);
-
-  f32x4 acc[4][4];
+// ---- epilogue: lane owns row m = m_base + i*16 + l15 and 4 consecutive columns n = n_base + j*16 + g*4 ----
+template <typename T, int MT, int EPI, int ACT, bool OUTF32>
+__device__ __forceinline__ void gemm_epilogue(const GemmP& p, f32x4 (&acc)[MT][4], int m_base, int n_base, int l15, int g) {
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
-#pragma unroll
-    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-  // per-thread staging coordinates: 4 vectors of A and 4 of W per k-tile
-  int srow[4], scv[4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    int v = tid + 256 * i;
-    srow[i] = v >> 3;
-    scv[i] = v & 7;
-  }
-  const int ktiles = p.K / BK;
-  const int total = ktiles * p.ntaps;
-
-  uint4 ra[4], rw[4];
-  auto gload = [&](int it) {
-    const int tap = it / ktiles;
-    const int k0 = (it - tap * ktiles) * BK;
-    const T* At = A + tap * p.a_tap_stride + k0;
-    const T* Wt = W + tap * p.w_tap_stride + k0;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int gm = m0 + srow[i], gn = n0 + srow[i];
-      ra[i] = gm < p.M ? *reinterpret_cast<const uint4*>(At + (int64_t)gm * p.lda + scv[i] * VEC) : make_uint4(0, 0, 0, 0);
-      rw[i] = gn < p.N ? *reinterpret_cast<const uint4*>(Wt + (int64_t)gn * p.ldw + scv[i] * VEC) : make_uint4(0, 0, 0, 0);
-    }
-  };
-
-  gload(0);
-  for (int it = 0; it < total; ++it) {
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      lds_store16<T>(&As[srow[i] * LS + scv[i] * VEC], ra[i]);
-      lds_store16<T>(&Ws[srow[i] * LS + scv[i] * VEC], rw[i]);
-    }
-    __syncthreads();
-    if (it + 1 < total) gload(it + 1);
-#pragma unroll
-    for (int kk = 0; kk < BK / P::KCH; ++kk) {
-      typename P::Frag af[4], wf[4];
-#pragma unroll
-      for (int i = 0; i < 4; ++i) af[i] = P::load(&As[(wm * 64 + i * 16 + l15) * LS + kk * P::KCH + g * P::EPL]);
-#pragma unroll
-      for (int j = 0; j < 4; ++j) wf[j] = P::load(&Ws[(wn * 64 + j * 16 + l15) * LS + kk * P::KCH + g * P::EPL]);
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = P::mfma(wf[j], af[i], acc[i][j]);  // acc[r] = C[m=l15][n=g*4+r]
-    }
-    __syncthreads();
-  }
-
-  // ---- epilogue: lane owns row m = ..+l15 and 4 consecutive columns n = ..+g*4+{0..3} ----
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int m = m0 + wm * 64 + i * 16 + l15;
+  for (int i = 0; i < MT; ++i) {
+    const int m = m_base + i * 16 + l15;
     if (m >= p.M) continue;
     int seq = 0, sm = m;
-    if (p.epi == EPI_FILM_RES || p.epi == EPI_STORE_T || p.out_seq_pad) {
+    if (EPI == EPI_FILM_RES || EPI == EPI_STORE_T || p.out_seq_pad) {
       seq = m / p.rows_per_seq;
       sm = m - seq * p.rows_per_seq;
     }
     const int64_t orow = (int64_t)m + (int64_t)seq * p.out_seq_pad;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      const int n = n0 + wn * 64 + j * 16 + g * 4;
+      const int n = n_base + j * 16 + g * 4;
       if (n >= p.N) continue;
       f32x4 v = acc[i][j];
       if (p.bias) {
         const float4 b = *reinterpret_cast<const float4*>(p.bias + n);
         v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
       }
-      if (p.epi == EPI_FILM_RES) {
+      if constexpr (EPI == EPI_FILM_RES) {
         float4* xp = reinterpret_cast<float4*>(p.resid + (int64_t)m * p.ldx + n);
         float4 x = *xp;
         if (p.film) {
@@ -162,32 +85,197 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmP p) {
           x.x += v[0]; x.y += v[1]; x.z += v[2]; x.w += v[3];
         }
         *xp = x;
-        continue;
-      }
-#pragma unroll
-      for (int r = 0; r < 4; ++r) v[r] = apply_act(v[r], p.act);
-      if (p.epi == EPI_CONV && p.skip) {
-        const T* sp = reinterpret_cast<const T*>(p.skip) + (int64_t)m * p.ld_skip + n;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) v[r] = (to_f32(sp[r]) + v[r]) * 0.5f;
-      }
-      if (p.epi == EPI_STORE_T) {
-        T* op = reinterpret_cast<T*>(p.out) + (int64_t)seq * p.t_seq_stride + (int64_t)n * p.ldo + sm;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) op[(int64_t)r * p.ldo] = from_f32<T>(v[r]);
-      } else if (p.out_f32) {
-        *reinterpret_cast<float4*>(reinterpret_cast<float*>(p.out) + orow * p.ldo + n) = make_float4(v[0], v[1], v[2], v[3]);
       } else {
-        T* op = reinterpret_cast<T*>(p.out) + orow * p.ldo + n;
-        if constexpr (sizeof(T) == 2) {
-          bf16x4 o = {(bf16_t)v[0], (bf16_t)v[1], (bf16_t)v[2], (bf16_t)v[3]};
-          *reinterpret_cast<bf16x4*>(op) = o;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = act_ct<ACT, sizeof(T) == 2>(v[r]);
+        if constexpr (EPI == EPI_CONV) {
+          if (p.skip) {
+            const T* sp = reinterpret_cast<const T*>(p.skip) + (int64_t)m * p.ld_skip + n;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = (to_f32(sp[r]) + v[r]) * 0.5f;
+          }
+        }
+        if constexpr (EPI == EPI_STORE_T) {
+          T* op = reinterpret_cast<T*>(p.out) + (int64_t)seq * p.t_seq_stride + (int64_t)n * p.ldo + sm;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) op[(int64_t)r * p.ldo] = from_f32<T>(v[r]);
+        } else if constexpr (OUTF32) {
+          *reinterpret_cast<float4*>(reinterpret_cast<float*>(p.out) + orow * p.ldo + n) = make_float4(v[0], v[1], v[2], v[3]);
         } else {
-          *reinterpret_cast<float4*>(op) = make_float4(v[0], v[1], v[2], v[3]);
+          T* op = reinterpret_cast<T*>(p.out) + orow * p.ldo + n;
+          if constexpr (sizeof(T) == 2) {
+            bf16x4 o = {(bf16_t)v[0], (bf16_t)v[1], (bf16_t)v[2], (bf16_t)v[3]};
+            *reinterpret_cast<bf16x4*>(op) = o;
+          } else {
+            *reinterpret_cast<float4*>(op) = make_float4(v[0], v[1], v[2], v[3]);
+          }
         }
       }
     }
   }
+}
+
+// ---- fp32 main loop: register-staged, single LDS buffer, padded rows --------------------------------
+template <int MT>
+__device__ __forceinline__ void gemm_mainloop_f32(const GemmP& p, f32x4 (&acc)[MT][4], int m0, int n0) {
+  using P = Prec<float>;
+  constexpr int BM = 32 * MT, BN = 128, BK = 32, LS = BK + 2, VEC = 4;
+  constexpr int AV = BM * 8 / 256;  // 16-byte vectors of A per thread (8 per row)
+  __shared__ __attribute__((aligned(16))) float As[BM * LS];
+  __shared__ __attribute__((aligned(16))) float Ws[BN * LS];
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, l15 = lane & 15, g = lane >> 4;
+  const int wm = wid >> 1, wn = wid & 1;
+  const float* __restrict__ A = reinterpret_cast<const float*>(p.A);
+  const float* __restrict__ W = reinterpret_cast<const float*>(p.W);
+  const int ktiles = p.K / BK;
+  uint4 ra[AV], rw[4];
+  auto gload = [&](const float* At, const float* Wt) {
+#pragma unroll
+    for (int i = 0; i < AV; ++i) {
+      const int v = tid + 256 * i, row = v >> 3, cv = v & 7;
+      int gm = m0 + row;
+      gm = gm < p.M ? gm : p.M - 1;  // clamped rows are never stored
+      ra[i] = *reinterpret_cast<const uint4*>(At + (int64_t)gm * p.lda + cv * VEC);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int v = tid + 256 * i, row = v >> 3, cv = v & 7;
+      int gn = n0 + row;
+      gn = gn < p.N ? gn : p.N - 1;
+      rw[i] = *reinterpret_cast<const uint4*>(Wt + (int64_t)gn * p.ldw + cv * VEC);
+    }
+  };
+  for (int tap = 0; tap < p.ntaps; ++tap) {
+    const float* At = A + tap * p.a_tap_stride;
+    const float* Wt = W + tap * p.w_tap_stride;
+    gload(At, Wt);
+    for (int kt = 0; kt < ktiles; ++kt) {
+#pragma unroll
+      for (int i = 0; i < AV; ++i) {
+        const int v = tid + 256 * i, row = v >> 3, cv = v & 7;
+        reinterpret_cast<uint2*>(&As[row * LS + cv * VEC])[0] = make_uint2(ra[i].x, ra[i].y);
+        reinterpret_cast<uint2*>(&As[row * LS + cv * VEC])[1] = make_uint2(ra[i].z, ra[i].w);
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int v = tid + 256 * i, row = v >> 3, cv = v & 7;
+        reinterpret_cast<uint2*>(&Ws[row * LS + cv * VEC])[0] = make_uint2(rw[i].x, rw[i].y);
+        reinterpret_cast<uint2*>(&Ws[row * LS + cv * VEC])[1] = make_uint2(rw[i].z, rw[i].w);
+      }
+      __syncthreads();
+      if (kt + 1 < ktiles) gload(At + (kt + 1) * BK, Wt + (kt + 1) * BK);
+#pragma unroll
+      for (int kk = 0; kk < BK / P::KCH; ++kk) {
+        float af[MT], wf[4];
+#pragma unroll
+        for (int i = 0; i < MT; ++i) af[i] = As[(wm * 16 * MT + i * 16 + l15) * LS + kk * P::KCH + g];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) wf[j] = Ws[(wn * 64 + j * 16 + l15) * LS + kk * P::KCH + g];
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) acc[i][j] = P::mfma(wf[j], af[i], acc[i][j]);  // acc[r] = C[m=l15][n=g*4+r]
+      }
+      __syncthreads();
+    }
+  }
+}
+
+// ---- bf16 main loop: global_load_lds (16 B / lane), 2 LDS buffers, swizzled unpadded rows -----------
+// LDS tile = [rows][64 bf16] (128-byte rows = 8 chunks of 16 B).  Chunk c of row r lives at chunk
+// position c ^ ((r >> 1) & 7): conflict-free for the 16-lane groups of ds_read_b128.
+__device__ __forceinline__ void glds16(const bf16_t* gsrc, bf16_t* lds_wave_base) {
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
+                                   (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
+
+template <int MT>
+__device__ __forceinline__ void gemm_mainloop_bf16(const GemmP& p, f32x4 (&acc)[MT][4], int m0, int n0) {
+  using P = Prec<bf16_t>;
+  constexpr int BM = 32 * MT, BN = 128, BK = 64;
+  constexpr int AI = BM / 32;  // glds instructions per wave for the A tile (8 rows each, 4 waves)
+  __shared__ __attribute__((aligned(16))) bf16_t smem[2 * (BM + BN) * BK];
+  bf16_t* const As0 = smem;
+  bf16_t* const Ws0 = smem + 2 * BM * BK;
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, l15 = lane & 15, g = lane >> 4;
+  const int wm = wid >> 1, wn = wid & 1;
+  const bf16_t* __restrict__ A = reinterpret_cast<const bf16_t*>(p.A);
+  const bf16_t* __restrict__ W = reinterpret_cast<const bf16_t*>(p.W);
+  const int ktiles = p.K / BK;
+  const int total = ktiles * p.ntaps;
+
+  // per-lane source offsets (elements) of the staging loads: row = grp*8 + lane/8, LDS chunk position lane%8
+  const int lrow = lane >> 3, lpos = lane & 7;
+  int64_t a_off[AI], w_off[4];
+#pragma unroll
+  for (int i = 0; i < AI; ++i) {
+    const int row = (i * 4 + wid) * 8 + lrow;
+    int gm = m0 + row;
+    gm = gm < p.M ? gm : p.M - 1;  // clamped rows are never stored
+    a_off[i] = (int64_t)gm * p.lda + ((lpos ^ ((row >> 1) & 7)) << 3);
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int row = (i * 4 + wid) * 8 + lrow;
+    int gn = n0 + row;
+    gn = gn < p.N ? gn : p.N - 1;
+    w_off[i] = (int64_t)gn * p.ldw + ((lpos ^ ((row >> 1) & 7)) << 3);
+  }
+  auto stage = [&](int it, int buf) {
+    const int tap = it / ktiles;  // ntaps == 1 almost always: the division is off the critical path (loads in flight)
+    const int k0 = (it - tap * ktiles) * BK;
+    const bf16_t* At = A + tap * p.a_tap_stride + k0;
+    const bf16_t* Wt = W + tap * p.w_tap_stride + k0;
+    bf16_t* Ab = As0 + buf * BM * BK;
+    bf16_t* Wb = Ws0 + buf * BN * BK;
+#pragma unroll
+    for (int i = 0; i < AI; ++i) glds16(At + a_off[i], Ab + (i * 4 + wid) * 8 * BK);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) glds16(Wt + w_off[i], Wb + (i * 4 + wid) * 8 * BK);
+  };
+  // fragment read offsets (elements) inside a tile: row R, chunk (kk*4 + g) ^ ((R >> 1) & 7)
+  int a_row[MT], w_row[4];
+#pragma unroll
+  for (int i = 0; i < MT; ++i) a_row[i] = wm * 16 * MT + i * 16 + l15;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) w_row[j] = wn * 64 + j * 16 + l15;
+
+  stage(0, 0);
+  for (int it = 0; it < total; ++it) {
+    const int buf = it & 1;
+    __syncthreads();  // drains vmcnt(0): tile `it` has landed; everyone finished reading buffer buf^1
+    if (it + 1 < total) stage(it + 1, buf ^ 1);
+    const bf16_t* Ab = As0 + buf * BM * BK;
+    const bf16_t* Wb = Ws0 + buf * BN * BK;
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      bf16x8 af[MT], wf[4];
+#pragma unroll
+      for (int i = 0; i < MT; ++i)
+        af[i] = *reinterpret_cast<const bf16x8*>(Ab + a_row[i] * BK + (((kk * 4 + g) ^ ((a_row[i] >> 1) & 7)) << 3));
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        wf[j] = *reinterpret_cast<const bf16x8*>(Wb + w_row[j] * BK + (((kk * 4 + g) ^ ((w_row[j] >> 1) & 7)) << 3));
+#pragma unroll
+      for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = P::mfma(wf[j], af[i], acc[i][j]);
+    }
+  }
+}
+
+template <typename T, int MT, int EPI, int ACT, bool OUTF32>
+__global__ __launch_bounds__(256) void gemm_kernel(GemmP p) {
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const int m0 = blockIdx.y * (32 * MT), n0 = blockIdx.x * 128;
+  f32x4 acc[MT][4];
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  if constexpr (sizeof(T) == 2) gemm_mainloop_bf16<MT>(p, acc, m0, n0);
+  else gemm_mainloop_f32<MT>(p, acc, m0, n0);
+  gemm_epilogue<T, MT, EPI, ACT, OUTF32>(p, acc, m0 + (wid >> 1) * 16 * MT, n0 + (wid & 1) * 64, lane & 15, lane >> 4);
 }
 
 // ---------------------------------------------------------------------------------------------
