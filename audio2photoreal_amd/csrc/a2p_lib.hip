@@ -159,9 +159,11 @@ static int gemm_dispatch(const GemmP& p, hipStream_t s) {
 static int launch_gemm(a2p_ctx* c, const GemmP& p, hipStream_t s) {
   const int bk = c->bf16 ? 64 : 32;
   ARG(p.K % bk == 0 && p.N % 4 == 0 && p.M > 0, "gemm: bad shape M=%d N=%d K=%d", p.M, p.N, p.K);
-  // 128x128 tiles unless that leaves the 256 CUs under two blocks each: then 64x128
+  // bf16: 64x128 tiles at every shape of this path (measured on MI355X, profiles/r01_gemm_ablation.txt: 9600..38400 rows x
+  // 512|1024 cols, 64x128 is 0-25% faster than 128x128 -- three co-resident blocks per CU overlap each other's
+  // load / MFMA / epilogue phases).  fp32: 128x128 unless that leaves the 256 CUs under two blocks each.
   const int64_t blocks128 = (int64_t)((p.N + 127) / 128) * ((p.M + 127) / 128);
-  const bool small = blocks128 < 512;
+  const bool small = c->bf16 || blocks128 < 512;
   KernelTimer kt(c, A2P_KERNEL_GEMM, s);
   int rc;
   if (c->bf16) rc = small ? gemm_dispatch<bf16_t, 2>(p, s) : gemm_dispatch<bf16_t, 4>(p, s);

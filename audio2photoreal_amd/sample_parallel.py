@@ -1,0 +1,87 @@
+"""Sample-parallel sampling over the GPUs of one node.
+
+The reference has no inference parallelism (sample/generate.py:124-144 loops repetitions
+serially on one device).  The path shards embarrassingly over samples: no op mixes batch
+elements, so each rank denoises a contiguous block of the global batch with its own replica
+of the weights and NO per-step communication; one `all_gather` (RCCL over xGMI with the
+"nccl" backend, gloo in the CPU tests) returns the samples at the end.
+
+Noise is indexed by GLOBAL sample id (the caller passes full-batch `noise` / `step_noise`,
+or a per-sample seed list), so 1/2/4/8-GPU runs produce identical samples.
+"""
+from __future__ import annotations
+
+from typing import Callable, Dict, List, Optional, Sequence, Tuple
+
+import torch
+import torch.distributed as dist
+
+_BATCH_KEYS = ("audio", "cond_embed", "keyframes", "mask", "scale", "lengths", "missing", "alengths", "klengths")
+
+
+def shard_bounds(total: int, world: int, rank: int) -> Tuple[int, int]:
+    """Contiguous block [lo, hi) of `total` samples for `rank`; the first total % world ranks get one extra."""
+    base, extra = divmod(total, world)
+    lo = rank * base + min(rank, extra)
+    return lo, lo + base + (1 if rank < extra else 0)
+
+
+def shard_model_kwargs(model_kwargs: Dict, lo: int, hi: int) -> Dict:
+    """Slice every per-sample tensor of y (data_loaders/tensors.py:57-67 layout) to [lo, hi)."""
+    y = model_kwargs["y"]
+    out = {}
+    for k, v in y.items():
+        if torch.is_tensor(v) and v.dim() >= 1 and k in _BATCH_KEYS:
+            out[k] = v[lo:hi].contiguous()
+        else:
+            out[k] = v
+    return {**model_kwargs, "y": out}
+
+
+def per_sample_noise(shape: Sequence[int], seeds: Sequence[int], device="cpu") -> torch.Tensor:
+    """N(0,1) noise [len(seeds), *shape[1:]] where row i depends only on seeds[i] (host generator)."""
+    rows = []
+    for s in seeds:
+        g = torch.Generator().manual_seed(int(s))
+        rows.append(torch.randn(tuple(shape[1:]), generator=g))
+    return torch.stack(rows).to(device)
+
+
+def gather_samples(local: torch.Tensor, total: int, group=None) -> torch.Tensor:
+    """The single end-of-run collective: all ranks receive all samples, in global order."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return local
+    world = dist.get_world_size(group)
+    sizes = [shard_bounds(total, world, r) for r in range(world)]
+    maxn = max(hi - lo for lo, hi in sizes)
+    pad = torch.zeros((maxn,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+    pad[: local.shape[0]] = local
+    bufs = [torch.empty_like(pad) for _ in range(world)]
+    dist.all_gather(bufs, pad, group=group)
+    return torch.cat([bufs[r][: hi - lo] for r, (lo, hi) in enumerate(sizes)], dim=0)
+
+
+def sample_parallel(sample_fn: Callable, model, shape: Sequence[int], model_kwargs: Dict,
+                    noise: Optional[torch.Tensor] = None, step_noise=None, group=None, **kw) -> torch.Tensor:
+    """Run `sample_fn` (e.g. diffusion.ddim_sample_loop / p_sample_loop) on this rank's block of the
+    global batch `shape[0]` and gather.  `noise` / `step_noise[i]` are full-batch tensors (or None)."""
+    world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
+    rank = dist.get_rank(group) if world > 1 else 0
+    total = shape[0]
+    lo, hi = shard_bounds(total, world, rank)
+    kwargs = shard_model_kwargs(model_kwargs, lo, hi)
+    local_shape = (hi - lo,) + tuple(shape[1:])
+    local_noise = None if noise is None else noise[lo:hi].contiguous()
+    local_step = None
+    if step_noise is not None:
+        if callable(step_noise):
+            local_step = lambda n: step_noise(n)[lo:hi].contiguous()
+        else:
+            local_step = [s[lo:hi].contiguous() for s in step_noise]
+    if hi > lo:
+        extra = {} if local_step is None else {"step_noise": local_step}
+        local = sample_fn(model, local_shape, noise=local_noise, model_kwargs=kwargs, **extra, **kw)
+    else:
+        ref = noise if noise is not None else torch.zeros(1)
+        local = torch.zeros((0,) + tuple(shape[1:]), dtype=torch.float32, device=ref.device)
+    return gather_samples(local, total, group)
