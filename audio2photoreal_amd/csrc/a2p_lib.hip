@@ -14,6 +14,7 @@
 #include <math.h>
 #include <stdarg.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <map>
@@ -22,6 +23,7 @@
 
 #include "../../include/a2p_hip.h"
 #include "kernels_attn.h"
+#include "kernels_chain.h"
 #include "kernels_gemm.h"
 #include "kernels_misc.h"
 
@@ -90,6 +92,7 @@ struct a2p_ctx {
   Buf cak_w32, cak_b, cav_w32, cav_b, cak_wt, cav_wt;
   Buf ca2k_wt, ca2v_wt, ca2k_b, ca2v_b;
   Buf conv_wt[7];
+  std::vector<Buf> ch_stream, ch_aux;  // packed weight streams / bias blocks of the chain kernels, [layer*4 + kind]
   Buf hidden, kc, vtc, k2c, vt2c, slot_cond, slot_unc, slot_cfg;
   std::vector<int> h_slots;
   int pB = 0, pS0 = 0, pT = 0, pK = 0;
@@ -381,6 +384,8 @@ extern "C" int a2p_ctx_destroy(a2p_ctx* c) {
                 &c->kf_pack, &c->kf_tok};
   for (Buf* b : all) buf_free(*b);
   for (int i = 0; i < 7; ++i) buf_free(c->conv_wt[i]);
+  for (auto& b : c->ch_stream) buf_free(b);
+  for (auto& b : c->ch_aux) buf_free(b);
   for (auto& e : c->evs) {
     hipEventDestroy(e.first);
     hipEventDestroy(e.second);
@@ -431,6 +436,8 @@ static int project_kv_all(a2p_ctx* c, const void* xr, const void* xn, int rows, 
   CHK(launch_gemm(c, pv, s));
   return 0;
 }
+
+static int chain_build_streams(a2p_ctx* c, hipStream_t s);
 
 extern "C" int a2p_finalize_weights(a2p_ctx* c, void* stream) {
   ARG(c, "null ctx");
@@ -558,6 +565,7 @@ extern "C" int a2p_finalize_weights(a2p_ctx* c, void* stream) {
   HIPCHK(hipStreamSynchronize(s));
   buf_free(ca2k32);
   buf_free(ca2v32);
+  if (c->bf16 && c->d == 512 && c->ff == 1024) CHK(chain_build_streams(c, s));
   c->finalized = true;
   return 0;
 }

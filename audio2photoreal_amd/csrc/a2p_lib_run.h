@@ -94,6 +94,202 @@ static int ffn_block(a2p_ctx* c, const std::string& p, const std::string& norm, 
   return film_gemm(c, c->hff.p, c->ff, p + "linear2.weight", W32(c, p + "linear2.bias"), c->ff, fr, film_idx, M, rows_per_seq, s);
 }
 
+// ------------------------------------------------------------------------------------------------
+// bf16 throughput mode: the decoder layer as row-panel chain kernels (kernels_chain.h) around the attentions
+// ------------------------------------------------------------------------------------------------
+static bool chain_supported(const a2p_ctx* c) { return c->bf16 && c->d == 512 && c->ff == 1024 && !c->ch_stream.empty() && !getenv("A2P_NO_CHAIN"); }
+
+enum { CH_PRE = 0, CH_MID = 1, CH_MID2 = 2, CH_POST = 3 };
+static int ch_index(int layer, int kind) { return layer * 4 + kind; }
+
+// stages of one GEMM: 128-row tiles of W[nrows, ldw] (tile-major), K/64 k-steps each
+static void pk_gemm(std::vector<ChainPackDesc>& v, const void* W, int ldw, int nrows, int K) {
+  for (int t = 0; t < (nrows + 127) / 128; ++t)
+    for (int ks = 0; ks < K / 64; ++ks) v.push_back({reinterpret_cast<const bf16_t*>(W), ldw, t * 128, ks * 64, nrows});
+}
+
+static int chain_pack(a2p_ctx* c, int idx, const std::vector<ChainPackDesc>& descs, const std::vector<std::pair<const float*, int>>& aux,
+                      hipStream_t s) {
+  Buf& st = c->ch_stream[idx];
+  const size_t pad = 8;  // the prefetch runs up to NS-1 (<= 5) stages past the end
+  CHK(buf_alloc(st, (descs.size() + pad) * CHAIN_STAGE_ELEMS * 2));
+  Buf dd;
+  CHK(buf_alloc(dd, descs.size() * sizeof(ChainPackDesc)));
+  HIPCHK(hipMemcpyAsync(dd.p, descs.data(), descs.size() * sizeof(ChainPackDesc), hipMemcpyHostToDevice, s));
+  chain_pack_kernel<<<(int)descs.size(), 256, 0, s>>>(reinterpret_cast<const ChainPackDesc*>(dd.p), reinterpret_cast<bf16_t*>(st.p));
+  HIPCHK(hipGetLastError());
+  Buf& ax = c->ch_aux[idx];
+  CHK(buf_alloc(ax, 2560 * 4 + 1024));
+  size_t off = 0;
+  for (auto& a : aux) {
+    HIPCHK(hipMemcpyAsync(ax.f() + off, a.first, (size_t)a.second * 4, hipMemcpyDeviceToDevice, s));
+    off += a.second;
+  }
+  HIPCHK(hipStreamSynchronize(s));  // descs is host memory of the caller
+  buf_free(dd);
+  return 0;
+}
+
+// pre-pack every chain's weight stream in consumption order (called from a2p_finalize_weights)
+static int chain_build_streams(a2p_ctx* c, hipStream_t s) {
+  const int d = c->d, ff = c->ff, L = c->L;
+  for (auto& b : c->ch_stream) buf_free(b);
+  for (auto& b : c->ch_aux) buf_free(b);
+  c->ch_stream.assign((size_t)L * 4, Buf());
+  c->ch_aux.assign((size_t)L * 4, Buf());
+  auto pf = [&](int l) { return "seqTransDecoder.stack." + std::to_string(l) + "."; };
+  auto add_pre = [&](std::vector<ChainPackDesc>& v, int l) {  // [Q|K] then V of layer l's self attention
+    const Buf& inw = c->wt.at(pf(l) + "self_attn.in_proj_weight");
+    pk_gemm(v, inw.p, d, 2 * d, d);
+    pk_gemm(v, c->offT(inw, (int64_t)2 * d * d), d, d, d);
+  };
+  for (int l = 0; l < L; ++l) {
+    std::vector<ChainPackDesc> v;
+    add_pre(v, l);
+    CHK(chain_pack(c, ch_index(l, CH_PRE), v, {{W32(c, pf(l) + "self_attn.in_proj_bias"), 3 * d}}, s));
+    auto mid = [&](int kind, const std::string& done, const std::string& next) -> int {
+      std::vector<ChainPackDesc> m;
+      pk_gemm(m, c->wt.at(pf(l) + done + ".out_proj.weight").p, d, d, d);
+      pk_gemm(m, c->wt.at(pf(l) + next + ".in_proj_weight").p, d, d, d);  // rows [0, d): the query projection
+      return chain_pack(c, ch_index(l, kind), m, {{W32(c, pf(l) + next + ".in_proj_bias"), d}}, s);
+    };
+    CHK(mid(CH_MID, "self_attn", "multihead_attn"));
+    if (c->pose) CHK(mid(CH_MID2, "multihead_attn", "multihead_attn2"));
+    std::vector<ChainPackDesc> q;
+    pk_gemm(q, c->wt.at(pf(l) + (c->pose ? "multihead_attn2" : "multihead_attn") + ".out_proj.weight").p, d, d, d);
+    const Buf& w1 = c->wt.at(pf(l) + "linear1.weight");
+    const Buf& w2 = c->wt.at(pf(l) + "linear2.weight");
+    for (int h = 0; h < ff / 128; ++h) {
+      for (int ks = 0; ks < d / 64; ++ks) q.push_back({reinterpret_cast<const bf16_t*>(w1.p), d, h * 128, ks * 64, ff});
+      for (int t = 0; t < d / 128; ++t)
+        for (int ks = 0; ks < 2; ++ks) q.push_back({reinterpret_cast<const bf16_t*>(w2.p), ff, t * 128, h * 128 + ks * 64, d});
+    }
+    std::vector<std::pair<const float*, int>> aux = {{W32(c, pf(l) + "linear1.bias"), ff}};
+    if (l + 1 < L) {
+      add_pre(q, l + 1);
+      aux.push_back({W32(c, pf(l + 1) + "self_attn.in_proj_bias"), 3 * d});
+    }
+    CHK(chain_pack(c, ch_index(l, CH_POST), q, aux, s));
+  }
+  return 0;
+}
+
+static void chain_base(a2p_ctx* c, ChainP& p, int N, int T, int idx, int aux_floats) {
+  memset(&p, 0, sizeof(p));
+  p.M = N * T; p.rows_per_seq = T; p.x = c->x.f(); p.cs = reinterpret_cast<const float2*>(c->rope_cs.p);
+  p.ain = reinterpret_cast<const bf16_t*>(c->ao.p); p.ld_ain = c->d;
+  p.stream = reinterpret_cast<const bf16_t*>(c->ch_stream[idx].p);
+  p.aux = c->ch_aux[idx].f(); p.aux_kb = (aux_floats + 255) / 256;
+}
+
+// outputs of the "pre" work of decoder layer l: norm1 -> rotary -> [Q|K], V^T
+static void chain_set_pre(a2p_ctx* c, ChainP& p, int l, int T) {
+  const int d = c->d;
+  const std::string pf = "seqTransDecoder.stack." + std::to_string(l) + ".";
+  p.lnB_g = W32(c, pf + "norm1.weight"); p.lnB_b = W32(c, pf + "norm1.bias");
+  p.qk_out = reinterpret_cast<bf16_t*>(c->qk.p); p.ld_qk = 2 * d;
+  p.vt_out = reinterpret_cast<bf16_t*>(c->vt.p);
+  const int Tld = rup(T, 64);
+  p.vt_seq_stride = (int64_t)d * Tld; p.ld_vt = Tld;
+}
+
+static void chain_set_out_proj(a2p_ctx* c, ChainP& p, const std::string& attn, const FilmRef& fr, int film_idx) {
+  const int d = c->d;
+  p.bias_o = W32(c, attn + ".out_proj.bias");
+  if (fr.base) {
+    p.film_o = fr.base + (int64_t)film_idx * 2 * d; p.film_seq_stride = fr.seq_stride; p.film_shift_off = d;
+  }
+}
+
+static int launch_chain(a2p_ctx* c, int mode, const ChainP& p, hipStream_t s) {
+  const char* env_mt = getenv("A2P_CHAIN_MT");  // tuning / test override of the panel height (rows = 16 * MT)
+  int mt = env_mt ? atoi(env_mt) : 0;
+  if (mt < 2 || mt > 4) {  // fewest rounds over the 256 CUs, then the taller panel (every panel streams all weights once)
+    int best = 1 << 30;
+    for (int cand = 4; cand >= 2; --cand) {
+      const int blocks = (p.M + 16 * cand - 1) / (16 * cand);
+      const int cost = ((blocks + 255) / 256) * (16 + 4 * cand);
+      if (cost < best) { best = cost; mt = cand; }
+    }
+  }
+  const int grid = (p.M + 16 * mt - 1) / (16 * mt);
+  KernelTimer kt(c, A2P_KERNEL_CHAIN, s);
+#define A2P_CHAIN(MT)                                                                                   \
+  do {                                                                                                  \
+    if (mode == CHAIN_PRE) chain_kernel<512, MT, CHAIN_PRE><<<grid, 256, 0, s>>>(p);                    \
+    else if (mode == CHAIN_MID) chain_kernel<512, MT, CHAIN_MID><<<grid, 256, 0, s>>>(p);               \
+    else chain_kernel<512, MT, CHAIN_POST><<<grid, 256, 0, s>>>(p);                                     \
+  } while (0)
+  if (mt == 2) A2P_CHAIN(2);
+  else if (mt == 3) A2P_CHAIN(3);
+  else A2P_CHAIN(4);
+#undef A2P_CHAIN
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+static int launch_self_attention(a2p_ctx* c, int N, int T, hipStream_t s) {
+  const int d = c->d, Tld = rup(T, 64);
+  AttnP a;
+  memset(&a, 0, sizeof(a));
+  a.Q = c->qk.p; a.q_seq_stride = (int64_t)T * 2 * d; a.ldq = 2 * d;
+  a.K = c->offT(c->qk, d); a.k_slot_stride = (int64_t)T * 2 * d; a.ldk = 2 * d;
+  a.VT = c->vt.p; a.vt_slot_stride = (int64_t)d * Tld; a.ldvt = Tld;
+  a.O = c->ao.p; a.o_seq_stride = (int64_t)T * d; a.ldo = d;
+  a.tail_mod = 1; a.Tq = T; a.S_main = T; a.S_tail = 0;
+  a.scale_log2e = 1.4426950408889634f / sqrtf((float)c->DH);
+  return launch_attn(c, a, N, A2P_KERNEL_ATTN_SELF, s);
+}
+
+static int launch_cross_attention(a2p_ctx* c, int N, int T, const CrossKV& kv, hipStream_t s) {
+  const int d = c->d;
+  AttnP a;
+  memset(&a, 0, sizeof(a));
+  a.Q = c->qk.p; a.q_seq_stride = (int64_t)T * d; a.ldq = d;
+  a.K = kv.K; a.k_slot_stride = kv.k_slot_stride; a.ldk = kv.ldk;
+  a.VT = kv.VT; a.vt_slot_stride = kv.vt_slot_stride; a.ldvt = kv.ldvt;
+  a.O = c->ao.p; a.o_seq_stride = (int64_t)T * d; a.ldo = d;
+  a.ktail = kv.ktail; a.vtail = kv.vtail; a.tail_sample_stride = kv.tail_sample_stride; a.tail_row_stride = kv.tail_row_stride;
+  a.kv_slot = kv.slots; a.tail_mod = kv.tail_mod; a.Tq = T; a.S_main = kv.S_main; a.S_tail = kv.S_tail;
+  a.scale_log2e = 1.4426950408889634f / sqrtf((float)c->DH);
+  return launch_attn(c, a, N, A2P_KERNEL_ATTN_CROSS, s);
+}
+
+// FiLMTransformerDecoderLayer.forward as PRE? | self attention | MID | cross attention | (MID | cross attention 2) | POST
+static int decoder_layer_chain(a2p_ctx* c, int l, int N, int T, const CrossKV& kv, const CrossKV* kv2, const FilmRef& fr, bool first,
+                               bool has_next, hipStream_t s) {
+  const int d = c->d;
+  const std::string pf = "seqTransDecoder.stack." + std::to_string(l) + ".";
+  ChainP p;
+  if (first) {
+    chain_base(c, p, N, T, ch_index(l, CH_PRE), 3 * d);
+    chain_set_pre(c, p, l, T);
+    CHK(launch_chain(c, CHAIN_PRE, p, s));
+  }
+  CHK(launch_self_attention(c, N, T, s));
+  auto mid = [&](int kind, const std::string& attn_done, int film_idx, const std::string& norm) -> int {
+    chain_base(c, p, N, T, ch_index(l, kind), d);
+    chain_set_out_proj(c, p, pf + attn_done, fr, film_idx);
+    p.lnA_g = W32(c, pf + norm + ".weight"); p.lnA_b = W32(c, pf + norm + ".bias");
+    p.q_out = reinterpret_cast<bf16_t*>(c->qk.p); p.ld_q = d;
+    return launch_chain(c, CHAIN_MID, p, s);
+  };
+  CHK(mid(CH_MID, "self_attn", 0, "norm2"));
+  CHK(launch_cross_attention(c, N, T, kv, s));
+  if (kv2) {
+    CHK(mid(CH_MID2, "multihead_attn", 1, "norm2a"));
+    CHK(launch_cross_attention(c, N, T, *kv2, s));
+  }
+  chain_base(c, p, N, T, ch_index(l, CH_POST), c->ff + (has_next ? 3 * d : 0));
+  chain_set_out_proj(c, p, pf + (kv2 ? "multihead_attn2" : "multihead_attn"), fr, kv2 ? 3 : 1);
+  p.lnA_g = W32(c, pf + "norm3.weight"); p.lnA_b = W32(c, pf + "norm3.bias");
+  p.bias_2 = W32(c, pf + "linear2.bias");
+  if (fr.base) p.film_f = fr.base + (int64_t)2 * 2 * d;
+  p.has_next = has_next ? 1 : 0;
+  if (has_next) chain_set_pre(c, p, l + 1, T);
+  return launch_chain(c, CHAIN_POST, p, s);
+}
+
 // FiLMTransformerDecoderLayer.forward (transformer_modules.py:178-217) on c->x
 static int decoder_layer(a2p_ctx* c, int l, int N, int T, const CrossKV& kv, const CrossKV* kv2, const FilmRef& fr, hipStream_t s) {
   const std::string p = "seqTransDecoder.stack." + std::to_string(l) + ".";
@@ -265,7 +461,8 @@ static int run_forward(a2p_ctx* c, const float* x_in, const int64_t* t_orig, int
     FilmRef fr;
     fr.base = c->film.f() + (size_t)l * F * 2 * d;
     fr.seq_stride = (int64_t)L * F * 2 * d;
-    CHK(decoder_layer(c, l, N, T, kv, c->pose ? &kv2 : nullptr, fr, s));
+    if (chain_supported(c)) CHK(decoder_layer_chain(c, l, N, T, kv, c->pose ? &kv2 : nullptr, fr, l == 0, l + 1 < L, s));
+    else CHK(decoder_layer(c, l, N, T, kv, c->pose ? &kv2 : nullptr, fr, s));
   }
   // final_layer (model/diffusion.py:397): cast the stream, GEMM
   CHK(launch_ln_rope(c, false, c->x.f(), d, nullptr, nullptr, c->xn.p, nullptr, d, N * T, T, 0, s));
@@ -506,7 +703,8 @@ extern "C" int a2p_decoder_layer_forward(a2p_ctx* c, int32_t layer, float* x, co
   fr.base = flm.f();
   fr.seq_stride = (int64_t)F * 2 * d;
   HIPCHK(hipMemcpyAsync(c->x.p, x, (size_t)N * T * d * 4, hipMemcpyDeviceToDevice, s));
-  int rc = decoder_layer(c, layer, N, T, kv, memory2 ? &kv2 : nullptr, fr, s);
+  int rc = chain_supported(c) ? decoder_layer_chain(c, layer, N, T, kv, memory2 ? &kv2 : nullptr, fr, true, false, s)
+                              : decoder_layer(c, layer, N, T, kv, memory2 ? &kv2 : nullptr, fr, s);
   if (rc == 0) hipMemcpyAsync(x, c->x.p, (size_t)N * T * d * 4, hipMemcpyDeviceToDevice, s);
   hipStreamSynchronize(s);
   buf_free(kb); buf_free(vb); buf_free(k2b); buf_free(v2b); buf_free(mtb); buf_free(flm);

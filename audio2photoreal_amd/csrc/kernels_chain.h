@@ -1,0 +1,461 @@
+// Row-panel "chain" kernels of the FiLM decoder layer (bf16 throughput mode).
+//
+// One workgroup owns BM = 16*MT rows of the fp32 residual stream for a whole CHAIN of dependent
+// row-local operations (FiLMTransformerDecoderLayer.forward, transformer_modules.py:178-267):
+//
+//   MODE_PRE  : x -> LayerNorm(norm1) -> rotary -> [Q|K] projection, V projection (transposed store)
+//   MODE_MID  : attention output -> out_proj -> FiLM affine + residual -> LayerNorm -> rotary -> Q projection
+//   MODE_POST : attention output -> out_proj -> FiLM + residual -> LayerNorm(norm3) -> linear1 -> GELU ->
+//               linear2 -> FiLM + residual [-> next layer's MODE_PRE work]
+//
+// instead of one launch (and one HBM round trip of the [rows, d] activation) per GEMM / LayerNorm:
+// 5 launches per decoder layer instead of 12, the FFN hidden activation never leaves the CU, and the
+// LayerNorm statistics are taken on the fp32 rows while they are still in registers.
+//
+// Data movement per workgroup (4 waves, one per SIMD):
+//   * A operand: a bf16 [BM][d] panel in LDS (attention output fetched with global_load_lds, or the
+//     LayerNorm output written from registers); 16-byte chunks XOR-swizzled by (row & 15) so the
+//     ds_read_b128 fragment reads of 16 consecutive rows hit 16 different bank groups.
+//   * W operand: all weight matrices of a chain are PRE-PACKED (a2p_finalize_weights, chain_pack_kernel)
+//     into one contiguous stream of 16 KiB stages in exactly the order the chain consumes them; stage =
+//     [wave 0..3][32 out-cols][64 k], already in the swizzled LDS image.  Wave w copies only ITS 4 KiB
+//     slice (4 x global_load_lds of 1 KiB, perfectly sequential in HBM/L2) into a wave-private ring of NS
+//     slots and waits with a counted s_waitcnt vmcnt -- no workgroup barrier in the GEMM loops, the DMA
+//     queue is never drained, and the prefetch runs ahead across tiles, GEMMs and epilogues alike.
+//   * No global load is issued while the stream is in flight except at the two "turn-around" points of a
+//     chain (FiLM + LayerNorm after out_proj / after linear2), where the FiLM, LayerNorm and rotary
+//     operands are fetched together; per-tile biases sit in LDS (DMA'd at kernel start).
+//   * The residual rows live in registers (fp32) from load to final store; FFN hidden activations go
+//     GELU -> bf16 -> a [BM][128] LDS chunk that linear2 consumes immediately (split-K over the 8 chunks).
+//
+// Wave w owns output columns [tile*128 + w*32, +32) of every 128-column tile, all BM rows: MT x 2 MFMA
+// 16x16x32 fragments per k-chunk.  Accumulator layout (operands swapped, D = C^T): lane (l15 = lane & 15,
+// g = lane >> 4) holds C[m = mt*16 + l15][n = ... + j*16 + g*4 + r], r = 0..3.
+#pragma once
+#include "a2p_common.h"
+
+enum { CHAIN_PRE = 0, CHAIN_MID = 1, CHAIN_POST = 2 };
+#define CHAIN_STAGE_ELEMS 8192  // 128 out-cols x 64 k bf16 = 16 KiB; 2048 elements (4 KiB) per wave
+
+struct ChainP {
+  int M, rows_per_seq, has_next, aux_kb;
+  float* x;               // fp32 residual stream [M][D], updated in place
+  const bf16_t* stream;   // packed weight stream of this chain
+  const float* aux;       // per-tile biases of this chain, aux_kb KiB: POST [bias_1 | bias_qk' | bias_v'], MID [bias_q], PRE [bias_qk | bias_v]
+  // MID / POST: attention output panel
+  const bf16_t* ain;
+  int64_t ld_ain;
+  // out_proj epilogue
+  const float* bias_o;
+  const float* film_o;  // scale at film_o[seq*film_seq_stride + n], shift at + film_shift_off; NULL = plain residual
+  int64_t film_seq_stride;
+  int film_shift_off;
+  // LayerNorm after out_proj (norm2 / norm2a / norm3)
+  const float* lnA_g;
+  const float* lnA_b;
+  // MID: query projection of the following cross attention
+  bf16_t* q_out;
+  int64_t ld_q;
+  // POST: feed forward
+  const float* bias_2;
+  const float* film_f;
+  // PRE work (MODE_PRE, or the tail of MODE_POST when has_next): norm1 -> rotary -> [Q|K], V^T
+  const float* lnB_g;
+  const float* lnB_b;
+  bf16_t* qk_out;
+  int64_t ld_qk;
+  bf16_t* vt_out;
+  int64_t vt_seq_stride, ld_vt;
+  const float2* cs;  // rotary table [pos][D/2]
+};
+
+// one 16 KiB stage of a packed stream: stage = rows [row0, row0+128) x k [k0, k0+64) of W[., ldw]
+struct ChainPackDesc {
+  const bf16_t* W;
+  int ldw, row0, k0, nrows;  // rows >= nrows are zero-filled
+};
+
+__global__ __launch_bounds__(256) void chain_pack_kernel(const ChainPackDesc* __restrict__ descs, bf16_t* __restrict__ dst) {
+  const ChainPackDesc d = descs[blockIdx.x];
+  uint4* out = reinterpret_cast<uint4*>(dst + (int64_t)blockIdx.x * CHAIN_STAGE_ELEMS);
+  for (int q = threadIdx.x; q < 1024; q += 256) {  // 16-byte chunk q = (wave, row-in-slice, chunk position)
+    const int w = q >> 8, r = (q & 255) >> 3, pos = q & 7;
+    const int row = d.row0 + w * 32 + r, chunk = pos ^ ((r >> 1) & 7);
+    uint4 v = make_uint4(0, 0, 0, 0);
+    if (row < d.nrows) v = *reinterpret_cast<const uint4*>(d.W + (int64_t)row * d.ldw + d.k0 + chunk * 8);
+    out[q] = v;
+  }
+}
+
+__device__ __forceinline__ void chain_glds16(const void* gsrc, void* lds_wave_base) {
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
+                                   (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
+
+// LDS-only barrier: never waits for the DMA queue
+__device__ __forceinline__ void chain_bar() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+// ABL: ablation switches for scratch/chain_bench.hip only (the library instantiates ABL = 0):
+//   1 = no global stores, 2 = no MFMA, 4 = no weight DMA / waits, 8 = no workgroup barriers in the FFN
+template <int D, int MT, int MODE, int ABL = 0>
+__global__ __launch_bounds__(256, 1) void chain_kernel(const ChainP p) {
+  constexpr int BM = 16 * MT;
+  constexpr int CPR = D / 8;     // 16-byte chunks per panel row
+  constexpr int NT = D / 128;    // 128-column tiles of a D-wide output
+  constexpr int KS = D / 64;     // k-steps of a D-deep contraction
+  constexpr int NSUB = 2 * NT;   // 16-column sub-tiles a wave owns of a D-wide output
+  constexpr int FT = 8;          // ff_size / 128
+  constexpr int HLD = 128;       // hidden chunk row stride
+  constexpr int AUX_F = 2560;    // floats of per-tile biases (10 KiB)
+  constexpr int FIXED = BM * D + BM * HLD + 16 * BM + 2 * AUX_F;  // bf16 elements before the ring
+  constexpr int NS = (160 * 1024 / 2 - FIXED) / CHAIN_STAGE_ELEMS > 6 ? 6 : (160 * 1024 / 2 - FIXED) / CHAIN_STAGE_ELEMS;
+  static_assert(NS >= 3, "panel too tall for a 3-deep weight ring");
+  constexpr int WSLICE = CHAIN_STAGE_ELEMS / 4;  // elements per wave per stage
+  __shared__ __attribute__((aligned(16))) bf16_t smem[FIXED + NS * CHAIN_STAGE_ELEMS];
+  bf16_t* const panelA = smem;
+  bf16_t* const panelH = panelA + BM * D;
+  float* const red = reinterpret_cast<float*>(panelH + BM * HLD);  // [2][4][BM]
+  float* const aux = red + 8 * BM;                                  // [AUX_F]
+  bf16_t* const ring = reinterpret_cast<bf16_t*>(aux + AUX_F);      // [wave][NS][32][64]
+
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int l15 = lane & 15, g = lane >> 4;
+  const int m0 = blockIdx.x * BM;
+  bf16_t* const myring = ring + wid * NS * WSLICE;
+
+  // ---- weight stream ---------------------------------------------------------------------------------------
+  const bf16_t* wsrc = p.stream + wid * WSLICE + lane * 8;  // this lane's 16 bytes of instruction 0 of stage 0
+  int issued = 0;
+  auto issue_stage = [&]() __attribute__((always_inline)) {
+    bf16_t* buf = myring + (issued % NS) * WSLICE;
+    if constexpr (!(ABL & 4)) {  // 4 x 1 KiB; the instruction offset advances the global AND the LDS address (one M0 write per stage)
+      const auto gp = (const __attribute__((address_space(1))) void*)wsrc;
+      const auto lp = (__attribute__((address_space(3))) void*)buf;
+      __builtin_amdgcn_global_load_lds(gp, lp, 16, 0, 0);
+      __builtin_amdgcn_global_load_lds(gp, lp, 16, 1024, 0);
+      __builtin_amdgcn_global_load_lds(gp, lp, 16, 2048, 0);
+      __builtin_amdgcn_global_load_lds(gp, lp, 16, 3072, 0);
+    }
+    wsrc += CHAIN_STAGE_ELEMS;  // past the end of the stream: the host pads NS stages
+    ++issued;
+  };
+  int consumed = 0;
+  // wait for this wave's oldest slice (NS-2 newer ones stay in flight), hand the just-freed slot to the DMA
+  auto stage_begin = [&]() __attribute__((always_inline)) -> const bf16_t* {
+    // lgkmcnt(0): the fragment reads of the slot that is about to be refilled have returned
+    if constexpr (!(ABL & 4)) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(4 * (NS - 2)) : "memory");
+    // pin the step boundary: hipcc otherwise hoists the NEXT step's MFMAs above this wait, right behind their fragment
+    // reads, which un-pipelines the loop (cdna_hip_programming.md §5.4 rule 18)
+    __builtin_amdgcn_sched_barrier(0);
+    issue_stage();
+    const bf16_t* wb = myring + (consumed % NS) * WSLICE;
+    ++consumed;
+    return wb;
+  };
+  // one k-step (64) of a [BM x 128] tile = this wave's fragments of 2 MFMA k-chunks.  Reads and MFMAs are split so the
+  // reads of step s+1 are in flight while the MFMAs of step s issue (one wave per SIMD: nobody else hides LDS latency).
+  struct Frags {
+    bf16x8 a[2][MT], w[2][2];
+  };
+  auto load_frags = [&](Frags& f, const bf16_t* P, int pld, int kchunk0, const bf16_t* wb) __attribute__((always_inline)) {
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt)
+        f.a[kk][mt] = *reinterpret_cast<const bf16x8*>(P + (mt * 16 + l15) * pld + (((kchunk0 + kk * 4 + g) ^ l15) << 3));
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int wrow = j * 16 + l15;
+        f.w[kk][j] = *reinterpret_cast<const bf16x8*>(wb + wrow * 64 + (((kk * 4 + g) ^ ((wrow >> 1) & 7)) << 3));
+      }
+    }
+  };
+  auto mma_frags = [&](f32x4(&acc)[MT][2], const Frags& f) __attribute__((always_inline)) {
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          if constexpr (!(ABL & 2)) acc[mt][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f.w[kk][j], f.a[kk][mt], acc[mt][j], 0, 0, 0);
+          else asm volatile("" ::"v"(f.w[kk][j]), "v"(f.a[kk][mt]));
+        }
+  };
+  // acc += P[:, 0:64*nks] * (the next nks stream stages)^T, nks even
+  auto gemm_tile = [&](f32x4(&acc)[MT][2], const bf16_t* P, int pld, int nks) __attribute__((always_inline)) {
+    // Issue order inside one step (one wave per SIMD, in-order issue): each MFMA occupies the matrix pipe for 16 cycles
+    // but its issue slot for 4, so the DMA pieces and fragment reads of the NEXT step are slotted between the MFMAs
+    // of the current one instead of in front of them.
+    auto interleave = [&]() __attribute__((always_inline)) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);  // VMEM read (LDS-DMA piece)
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // MFMA
+      }
+#pragma unroll
+      for (int i = 0; i < 2 * MT + 4; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);  // DS read
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // MFMA
+      }
+    };
+    Frags f0, f1;
+    load_frags(f0, P, pld, 0, stage_begin());
+    for (int ks = 0; ks < nks; ks += 2) {
+      load_frags(f1, P, pld, (ks + 1) * 8, stage_begin());
+      mma_frags(acc, f0);
+      interleave();
+      if (ks + 2 < nks) {
+        load_frags(f0, P, pld, (ks + 2) * 8, stage_begin());
+        mma_frags(acc, f1);
+        interleave();
+      } else {
+        mma_frags(acc, f1);
+      }
+    }
+  };
+  auto zero = [&](f32x4(&acc)[MT][2]) __attribute__((always_inline)) {
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) acc[mt][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  };
+  // accumulators start at the per-column bias held in the LDS aux block
+  auto init_bias = [&](f32x4(&acc)[MT][2], const float* bias_lds) __attribute__((always_inline)) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const float4 b = *reinterpret_cast<const float4*>(bias_lds + wid * 32 + j * 16 + g * 4);
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) acc[mt][j] = f32x4{b.x, b.y, b.z, b.w};
+    }
+  };
+  // column of sub-tile (tile t, half j) for this lane
+  auto col_of = [&](int t, int j) __attribute__((always_inline)) { return t * 128 + wid * 32 + j * 16 + g * 4; };
+
+  // ---- kernel start: panel + aux DMA, residual rows, stream prefetch ----------------------------------------
+  f32x4 xrow[MT][NSUB];
+  int row_m[MT], row_seq[MT];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) {
+    int m = m0 + mt * 16 + l15;
+    m = m < p.M ? m : p.M - 1;
+    row_m[mt] = m;
+    row_seq[mt] = m / p.rows_per_seq;
+  }
+  if constexpr (MODE != CHAIN_PRE) {  // attention output panel: one global_load_lds per 64 chunks
+    constexpr int RPI = 64 / CPR;     // rows per wave instruction (1 for d = 512, 2 for d = 256)
+    for (int r0 = wid * RPI; r0 < BM; r0 += 4 * RPI) {
+      const int row = r0 + lane / CPR, pos = lane % CPR;
+      int m = m0 + row;
+      m = m < p.M ? m : p.M - 1;
+      chain_glds16(p.ain + (int64_t)m * p.ld_ain + ((pos ^ (row & 15)) << 3), panelA + r0 * D);
+    }
+  }
+  for (int kb = wid; kb < p.aux_kb; kb += 4) chain_glds16(p.aux + kb * 256 + lane * 4, aux + kb * 256);
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+    for (int ns = 0; ns < NSUB; ++ns) {
+      const float4 v = *reinterpret_cast<const float4*>(p.x + (int64_t)row_m[mt] * D + col_of(ns >> 1, ns & 1));
+      xrow[mt][ns] = f32x4{v.x, v.y, v.z, v.w};
+    }
+#pragma unroll
+  for (int i = 0; i < NS - 1; ++i) issue_stage();
+  // everything older than the NS-1 weight slices (panel, aux, residual rows) has landed for this wave ...
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * (NS - 1)) : "memory");
+  chain_bar();  // ... and for every other wave
+
+  // ---- epilogue helpers ---------------------------------------------------------------------------------------
+  // FiLM affine + residual (transformer_modules.py:122-124,193): x += (scale + 1) * (acc + bias) + shift
+  auto film_res = [&](f32x4(&acc)[MT][2], int t, const float* bias, const float* film) __attribute__((always_inline)) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int n = col_of(t, j);
+      const float4 b = *reinterpret_cast<const float4*>(bias + n);
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) {
+        f32x4 v = acc[mt][j];
+        v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
+        f32x4& xr = xrow[mt][t * 2 + j];
+        if (film) {
+          const float* fp = film + (int64_t)row_seq[mt] * p.film_seq_stride + n;
+          const float4 sc = *reinterpret_cast<const float4*>(fp);
+          const float4 sh = *reinterpret_cast<const float4*>(fp + p.film_shift_off);
+          xr[0] += (sc.x + 1.0f) * v[0] + sh.x;
+          xr[1] += (sc.y + 1.0f) * v[1] + sh.y;
+          xr[2] += (sc.z + 1.0f) * v[2] + sh.z;
+          xr[3] += (sc.w + 1.0f) * v[3] + sh.w;
+        } else {
+          xr[0] += v[0]; xr[1] += v[1]; xr[2] += v[2]; xr[3] += v[3];
+        }
+      }
+    }
+  };
+  // LayerNorm statistics of the register rows (eps 1e-5, biased variance, two-pass like ln_rope_kernel)
+  float ln_mean[MT], ln_rstd[MT];
+  auto ln_stats = [&]() __attribute__((always_inline)) {
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+      float s = 0.f;
+#pragma unroll
+      for (int ns = 0; ns < NSUB; ++ns) s += (xrow[mt][ns][0] + xrow[mt][ns][1]) + (xrow[mt][ns][2] + xrow[mt][ns][3]);
+      s += __shfl_xor(s, 16, 64);
+      s += __shfl_xor(s, 32, 64);
+      if (g == 0) red[wid * BM + mt * 16 + l15] = s;
+    }
+    chain_bar();
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+      const int r = mt * 16 + l15;
+      ln_mean[mt] = ((red[r] + red[BM + r]) + (red[2 * BM + r] + red[3 * BM + r])) * (1.0f / D);
+      float q = 0.f;
+#pragma unroll
+      for (int ns = 0; ns < NSUB; ++ns)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float dlt = xrow[mt][ns][e] - ln_mean[mt];
+          q += dlt * dlt;
+        }
+      q += __shfl_xor(q, 16, 64);
+      q += __shfl_xor(q, 32, 64);
+      if (g == 0) red[4 * BM + wid * BM + r] = q;
+    }
+    chain_bar();
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+      const int r = mt * 16 + l15;
+      const float var = ((red[4 * BM + r] + red[5 * BM + r]) + (red[6 * BM + r] + red[7 * BM + r])) * (1.0f / D);
+      ln_rstd[mt] = 1.0f / sqrtf(var + 1e-5f);
+    }
+  };
+  // normalised (optionally rotated, rotary_embedding_torch.py:46-66) rows -> bf16 A panel
+  auto ln_write = [&](const float* gamma, const float* beta, bool rope) __attribute__((always_inline)) {
+#pragma unroll
+    for (int ns = 0; ns < NSUB; ++ns) {
+      const int n = col_of(ns >> 1, ns & 1);
+      const float4 ga = *reinterpret_cast<const float4*>(gamma + n);
+      const float4 be = *reinterpret_cast<const float4*>(beta + n);
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) {
+        float v0 = (xrow[mt][ns][0] - ln_mean[mt]) * ln_rstd[mt] * ga.x + be.x;
+        float v1 = (xrow[mt][ns][1] - ln_mean[mt]) * ln_rstd[mt] * ga.y + be.y;
+        float v2 = (xrow[mt][ns][2] - ln_mean[mt]) * ln_rstd[mt] * ga.z + be.z;
+        float v3 = (xrow[mt][ns][3] - ln_mean[mt]) * ln_rstd[mt] * ga.w + be.w;
+        if (rope) {
+          const int pos = row_m[mt] - row_seq[mt] * p.rows_per_seq;
+          const float4 t = *reinterpret_cast<const float4*>(p.cs + (int64_t)pos * (D / 2) + (n >> 1));  // (cos,sin) x 2
+          const float r0 = v0 * t.x - v1 * t.y, r1 = v1 * t.x + v0 * t.y;
+          const float r2 = v2 * t.z - v3 * t.w, r3 = v3 * t.z + v2 * t.w;
+          v0 = r0; v1 = r1; v2 = r2; v3 = r3;
+        }
+        const bf16x4 o = {(bf16_t)v0, (bf16_t)v1, (bf16_t)v2, (bf16_t)v3};
+        *reinterpret_cast<bf16x4*>(panelA + (mt * 16 + l15) * D + ((((n >> 3) ^ l15) << 3) | (n & 7))) = o;
+      }
+    }
+    chain_bar();  // the panel is complete before any wave's fragment reads
+  };
+  auto store_x = [&]() __attribute__((always_inline)) {
+    if constexpr (ABL & 1) return;
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+      if (m0 + mt * 16 + l15 >= p.M) continue;
+#pragma unroll
+      for (int ns = 0; ns < NSUB; ++ns)
+        *reinterpret_cast<float4*>(p.x + (int64_t)row_m[mt] * D + col_of(ns >> 1, ns & 1)) =
+            make_float4(xrow[mt][ns][0], xrow[mt][ns][1], xrow[mt][ns][2], xrow[mt][ns][3]);
+    }
+  };
+  // D-deep GEMM over `ntiles` output tiles with a per-tile bf16 store: out[m][n] (row-major) or out^T
+  auto gemm_store = [&](int ntiles, const float* bias_lds, bf16_t* out, int64_t ldo, bool transposed) __attribute__((always_inline)) {
+    for (int t = 0; t < ntiles; ++t) {
+      f32x4 acc[MT][2];
+      init_bias(acc, bias_lds + t * 128);
+      gemm_tile(acc, panelA, D, KS);
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int n = col_of(t, j);
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+          if (m0 + mt * 16 + l15 >= p.M) continue;
+          const f32x4 v = acc[mt][j];
+          if constexpr (ABL & 1) {
+            asm volatile("" ::"v"(v));
+            continue;
+          }
+          if (!transposed) {
+            const bf16x4 o = {(bf16_t)v[0], (bf16_t)v[1], (bf16_t)v[2], (bf16_t)v[3]};
+            *reinterpret_cast<bf16x4*>(out + (int64_t)row_m[mt] * ldo + n) = o;
+          } else {
+            bf16_t* op = out + (int64_t)row_seq[mt] * p.vt_seq_stride + (int64_t)n * ldo + (row_m[mt] - row_seq[mt] * p.rows_per_seq);
+            op[0] = (bf16_t)v[0];
+            op[ldo] = (bf16_t)v[1];
+            op[2 * ldo] = (bf16_t)v[2];
+            op[3 * ldo] = (bf16_t)v[3];
+          }
+        }
+      }
+    }
+  };
+  // norm1 -> rotary -> [Q|K] ; norm1 -> V^T          (aux: bias_qk at aq, bias_v right after)
+  auto pre_work = [&](const float* aq) __attribute__((always_inline)) {
+    ln_stats();
+    ln_write(p.lnB_g, p.lnB_b, true);
+    gemm_store(2 * NT, aq, p.qk_out, p.ld_qk, false);
+    chain_bar();  // every wave is done reading the rotated panel
+    ln_write(p.lnB_g, p.lnB_b, false);
+    gemm_store(NT, aq + 2 * D, p.vt_out, p.ld_vt, true);
+  };
+
+  // ================================================================================================
+  if constexpr (MODE == CHAIN_PRE) {
+    pre_work(aux);
+  } else {
+    // out_proj of the attention that produced `ain`; FiLM + residual into the register rows once all tiles are done
+    {
+      f32x4 oacc[NT][MT][2];
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+        zero(oacc[t]);
+        gemm_tile(oacc[t], panelA, D, KS);
+      }
+#pragma unroll
+      for (int t = 0; t < NT; ++t) film_res(oacc[t], t, p.bias_o, p.film_o);
+    }
+    ln_stats();
+    if constexpr (MODE == CHAIN_MID) {
+      store_x();
+      ln_write(p.lnA_g, p.lnA_b, true);
+      gemm_store(NT, aux, p.q_out, p.ld_q, false);
+    } else {
+      ln_write(p.lnA_g, p.lnA_b, false);
+      // feed forward, split-K over the 8 hidden chunks: linear1 chunk -> GELU -> LDS -> linear2 partial
+      f32x4 facc[NT][MT][2];
+#pragma unroll
+      for (int t = 0; t < NT; ++t) zero(facc[t]);
+      for (int h = 0; h < FT; ++h) {
+        f32x4 acc[MT][2];
+        init_bias(acc, aux + h * 128);
+        gemm_tile(acc, panelA, D, KS);
+        if (h > 0 && !(ABL & 8)) chain_bar();  // every wave finished the linear2 partial of the previous chunk
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          const int c = wid * 32 + j * 16 + g * 4;  // column inside the hidden chunk
+#pragma unroll
+          for (int mt = 0; mt < MT; ++mt) {
+            const f32x4 v = acc[mt][j];
+            const bf16x4 o = {(bf16_t)act_gelu_fast(v[0]), (bf16_t)act_gelu_fast(v[1]), (bf16_t)act_gelu_fast(v[2]),
+                              (bf16_t)act_gelu_fast(v[3])};
+            *reinterpret_cast<bf16x4*>(panelH + (mt * 16 + l15) * HLD + ((((c >> 3) ^ l15) << 3) | (c & 7))) = o;
+          }
+        }
+        if (!(ABL & 8)) chain_bar();  // the hidden chunk is complete
+#pragma unroll
+        for (int t = 0; t < NT; ++t) gemm_tile(facc[t], panelH, HLD, 2);
+      }
+#pragma unroll
+      for (int t = 0; t < NT; ++t) film_res(facc[t], t, p.bias_2, p.film_f);
+      store_x();
+      if (p.has_next) pre_work(aux + FT * 128);
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the run-ahead DMA slices must land before the LDS is released
+}

@@ -44,7 +44,9 @@ def algorithmic_flops(spec, T, S, nseq):
         gemm += 2.0 * T * d * (d + d)
     else:
         ca_attn2 = 0.0
-    return {"gemm": nseq * L * gemm, "attn_self": nseq * L * sa_attn, "attn_cross": nseq * L * (ca_attn + ca_attn2)}
+    io = 2.0 * T * d * spec.nfeats * 1.5      # input_projection (once per sample) + final_layer (per sequence)
+    return {"decoder_gemm": nseq * L * gemm, "io_gemm": nseq * io, "attn_self": nseq * L * sa_attn,
+            "attn_cross": nseq * L * (ca_attn + ca_attn2)}
 
 
 def main():
@@ -154,7 +156,13 @@ def main():
         import ctypes as C
         flops = algorithmic_flops(spec, T, S0 + 2, 2 * B)
         ksteps = min(a.steps, 5)
-        for name, kind in (("gemm", _lib.KERNEL_GEMM), ("attn_self", _lib.KERNEL_ATTN_SELF),
+        # bf16 mode runs the decoder-layer GEMMs inside the fused "chain" kernels (projections + FiLM + LayerNorm + FFN);
+        # fp32 mode (and A2P_NO_CHAIN=1) runs them as separate GEMM launches
+        chained = a.precision == "bf16" and not os.environ.get("A2P_NO_CHAIN")
+        flops["chain" if chained else "gemm"] = flops.pop("decoder_gemm") + (0.0 if chained else flops["io_gemm"])
+        if chained:
+            flops["gemm"] = flops["io_gemm"]
+        for name, kind in (("chain", _lib.KERNEL_CHAIN), ("gemm", _lib.KERNEL_GEMM), ("attn_self", _lib.KERNEL_ATTN_SELF),
                            ("attn_cross", _lib.KERNEL_ATTN_CROSS), ("ln_rope", _lib.KERNEL_LNROPE)):
             _lib.check(lib.a2p_kernel_timing(model._ctx, kind, 1), "a2p_kernel_timing")
             with torch.no_grad():
@@ -162,6 +170,8 @@ def main():
             ms, n = C.c_double(), C.c_int64()
             _lib.check(lib.a2p_kernel_time_ms(model._ctx, C.byref(ms), C.byref(n)), "a2p_kernel_time_ms")
             _lib.check(lib.a2p_kernel_timing(model._ctx, kind, 0), "a2p_kernel_timing")
+            if n.value == 0:
+                continue
             per_step_ms = ms.value / ksteps
             ent = {"ms_per_step": round(per_step_ms, 4), "launches_per_step": n.value // ksteps,
                    "avg_launch_us": round(1e3 * ms.value / max(n.value, 1), 2)}
@@ -201,7 +211,8 @@ def main():
 
     if rank == 0:
         value = world * a.steps / dt
-        step_flops = sum(algorithmic_flops(spec, T, S0 + 2, 2 * B).values())
+        fl = algorithmic_flops(spec, T, S0 + 2, 2 * B)
+        step_flops = fl["decoder_gemm"] + fl["attn_self"] + fl["attn_cross"]   # decoder attention + FFN + projections
         line = {
             "metric": "diffusion denoise steps/sec (face, 600-frame seq, batch 8 per GPU, CFG)", "value": round(value, 4),
             "unit": "steps/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,

@@ -167,6 +167,7 @@ int a2p_attention(a2p_ctx* ctx, const float* q, const float* k, const float* v, 
 #define A2P_KERNEL_ATTN_SELF 1
 #define A2P_KERNEL_ATTN_CROSS 2
 #define A2P_KERNEL_LNROPE 3
+#define A2P_KERNEL_CHAIN 4 /* fused row-panel chain kernels (projections + FiLM + LayerNorm + FFN), bf16 mode */
 int a2p_kernel_timing(a2p_ctx* ctx, int32_t kind, int32_t enable);
 int a2p_kernel_time_ms(a2p_ctx* ctx, double* total_ms, int64_t* launches);
 

@@ -1,0 +1,70 @@
+// Ablation bench of the chain kernels on synthetic buffers (scratch; not product).
+// hipcc --offload-arch=gfx950 -O3 -std=c++17 scratch/chain_bench.hip -o scratch/chain_bench
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <vector>
+#include "../audio2photoreal_amd/csrc/kernels_chain.h"
+#define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); exit(1);} } while (0)
+template <typename F>
+float time_it(F f, int iters = 10) {
+  hipEvent_t e0, e1;
+  CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+  for (int i = 0; i < 2; ++i) f();
+  CK(hipEventRecord(e0));
+  for (int i = 0; i < iters; ++i) f();
+  CK(hipEventRecord(e1));
+  CK(hipEventSynchronize(e1));
+  float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+  return ms / iters * 1e3f;
+}
+static int g_cycle = 1;  // number of distinct weight streams cycled through (1 = always L2-hot)
+template <int MT, int MODE, int ABL>
+void run(const char* name, ChainP p, int stages) {
+  const int grid = (p.M + 16 * MT - 1) / (16 * MT);
+  int it = 0;
+  const bf16_t* base = p.stream;
+  float us = time_it([&] { p.stream = base + (size_t)(it++ % g_cycle) * (256 + 8) * 8192; chain_kernel<512, MT, MODE, ABL><<<grid, 256>>>(p); });
+  CK(hipDeviceSynchronize());
+  printf("  MT=%d mode=%d abl=%2d %-28s %8.1f us  (%d blocks, %.3f us/stage)\n", MT, MODE, ABL, name, us, grid, us / stages / ((grid + 255) / 256));
+}
+template <int MT>
+void all(ChainP p) {
+  p.has_next = 1;
+  run<MT, CHAIN_PRE, 0>("full", p, 96);
+  run<MT, CHAIN_PRE, 1>("no stores", p, 96);
+  run<MT, CHAIN_MID, 0>("full", p, 64);
+  run<MT, CHAIN_MID, 1>("no stores", p, 64);
+  run<MT, CHAIN_POST, 0>("full", p, 256);
+  run<MT, CHAIN_POST, 1>("no stores", p, 256);
+  run<MT, CHAIN_POST, 3>("no stores, no mfma", p, 256);
+  run<MT, CHAIN_POST, 5>("no stores, no dma", p, 256);
+}
+int main(int argc, char** argv) {
+  for (int M : {9600}) {
+    const int D = 512;
+    float *x, *aux, *vec, *film; bf16_t *ain, *stream, *qk, *vt; float2* cs;
+    CK(hipMalloc(&x, (size_t)M * D * 4)); CK(hipMalloc(&ain, (size_t)M * D * 2)); CK(hipMalloc(&stream, (size_t)16 * (256 + 8) * 16384));
+    CK(hipMalloc(&aux, 16384)); CK(hipMalloc(&vec, 8192 * 4)); CK(hipMalloc(&film, (size_t)64 * 4 * D * 4));
+    CK(hipMalloc(&qk, (size_t)M * 2 * D * 2)); CK(hipMalloc(&vt, (size_t)M * D * 2 + (1 << 20))); CK(hipMalloc(&cs, (size_t)640 * 256 * 8));
+    std::vector<uint16_t> h((size_t)16 * (256 + 8) * 8192);
+    for (auto& v : h) v = 0x3c00 + (rand() & 0x3ff) - ((rand() & 1) << 15);
+    CK(hipMemcpy(stream, h.data(), h.size() * 2, hipMemcpyHostToDevice));
+    h.resize((size_t)M * D);
+    CK(hipMemcpy(ain, h.data(), h.size() * 2, hipMemcpyHostToDevice));
+    CK(hipMemset(x, 0, (size_t)M * D * 4)); CK(hipMemset(aux, 0, 16384)); CK(hipMemset(vec, 0, 8192 * 4)); CK(hipMemset(film, 0, (size_t)64 * 4 * D * 4));
+    CK(hipMemset(cs, 0, (size_t)640 * 256 * 8));
+    ChainP p; memset(&p, 0, sizeof(p));
+    p.M = M; p.rows_per_seq = 600; p.aux_kb = 10; p.x = x; p.stream = stream; p.aux = aux; p.ain = ain; p.ld_ain = D;
+    p.bias_o = vec; p.film_o = film; p.film_seq_stride = 4 * D; p.film_shift_off = D; p.lnA_g = vec + 512; p.lnA_b = vec + 1024;
+    p.q_out = qk; p.ld_q = D; p.bias_2 = vec + 1536; p.film_f = film + 2 * D; p.lnB_g = vec + 2048; p.lnB_b = vec + 2560;
+    p.qk_out = qk; p.ld_qk = 2 * D; p.vt_out = vt; p.vt_seq_stride = (int64_t)D * 640; p.ld_vt = 640; p.cs = cs;
+    for (int cyc : {1, 16}) {
+      g_cycle = cyc;
+      printf("M=%d weight streams cycled=%d\n", M, cyc);
+      all<2>(p); all<3>(p); all<4>(p);
+    }
+  }
+  return 0;
+}

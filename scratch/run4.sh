@@ -1,0 +1,5 @@
+R=$GRAFT_REPO_ROOT
+cd $R
+./scratch/chain_bench > gpurun_out/chain_bench.log 2>&1; grep -E "^M=|MT=" gpurun_out/chain_bench.log | grep -v "cycled=16" | head -26
+timeout 600 python -m pytest tests -m gpu -x -q -k "chain or decoder_layer or forward_vs" 2>&1 | tail -3
+A2P_CHAIN_MT=3 timeout 300 python bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-kernel-timing 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('bench mt3', d['value'], d['ms_per_step'])"
