@@ -170,19 +170,25 @@ __global__ __launch_bounds__(256, 1) void chain_kernel(const ChainP p) {
       }
     }
   };
-  auto mma_frags = [&](f32x4(&acc)[MT][2], const Frags& f) __attribute__((always_inline)) {
+  // swap = false: D = C^T, lane holds 4 consecutive columns n of row m = l15 (row-major consumers);
+  // swap = true : D = C,   lane holds 4 consecutive rows m = g*4 + r of column n = l15 (the transposed V^T store)
+  auto mma_frags = [&](f32x4(&acc)[MT][2], const Frags& f, bool swap) __attribute__((always_inline)) {
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk)
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
-          if constexpr (!(ABL & 2)) acc[mt][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f.w[kk][j], f.a[kk][mt], acc[mt][j], 0, 0, 0);
-          else asm volatile("" ::"v"(f.w[kk][j]), "v"(f.a[kk][mt]));
+          if constexpr (!(ABL & 2)) {
+            if (swap) acc[mt][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f.a[kk][mt], f.w[kk][j], acc[mt][j], 0, 0, 0);
+            else acc[mt][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f.w[kk][j], f.a[kk][mt], acc[mt][j], 0, 0, 0);
+          } else {
+            asm volatile("" ::"v"(f.w[kk][j]), "v"(f.a[kk][mt]));
+          }
         }
   };
   // acc += P[:, 0:64*nks] * (the next nks stream stages)^T, nks even
-  auto gemm_tile = [&](f32x4(&acc)[MT][2], const bf16_t* P, int pld, int nks) __attribute__((always_inline)) {
+  auto gemm_tile = [&](f32x4(&acc)[MT][2], const bf16_t* P, int pld, int nks, bool swap = false) __attribute__((always_inline)) {
     // Issue order inside one step (one wave per SIMD, in-order issue): each MFMA occupies the matrix pipe for 16 cycles
     // but its issue slot for 4, so the DMA pieces and fragment reads of the NEXT step are slotted between the MFMAs
     // of the current one instead of in front of them.
@@ -202,14 +208,14 @@ __global__ __launch_bounds__(256, 1) void chain_kernel(const ChainP p) {
     load_frags(f0, P, pld, 0, stage_begin());
     for (int ks = 0; ks < nks; ks += 2) {
       load_frags(f1, P, pld, (ks + 1) * 8, stage_begin());
-      mma_frags(acc, f0);
+      mma_frags(acc, f0, swap);
       interleave();
       if (ks + 2 < nks) {
         load_frags(f0, P, pld, (ks + 2) * 8, stage_begin());
-        mma_frags(acc, f1);
+        mma_frags(acc, f1, swap);
         interleave();
       } else {
-        mma_frags(acc, f1);
+        mma_frags(acc, f1, swap);
       }
     }
   };
@@ -364,32 +370,40 @@ __global__ __launch_bounds__(256, 1) void chain_kernel(const ChainP p) {
             make_float4(xrow[mt][ns][0], xrow[mt][ns][1], xrow[mt][ns][2], xrow[mt][ns][3]);
     }
   };
-  // D-deep GEMM over `ntiles` output tiles with a per-tile bf16 store: out[m][n] (row-major) or out^T
+  // D-deep GEMM over `ntiles` output tiles with a per-tile bf16 store: out[m][n] (row-major, 4 columns per lane) or the
+  // transposed V^T layout out[seq][n][t] (operands swapped: 4 consecutive frames t per lane, one 8-byte store each)
   auto gemm_store = [&](int ntiles, const float* bias_lds, bf16_t* out, int64_t ldo, bool transposed) __attribute__((always_inline)) {
     for (int t = 0; t < ntiles; ++t) {
       f32x4 acc[MT][2];
-      init_bias(acc, bias_lds + t * 128);
-      gemm_tile(acc, panelA, D, KS);
+      if (!transposed) {
+        init_bias(acc, bias_lds + t * 128);
+      } else {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          const float b = bias_lds[t * 128 + wid * 32 + j * 16 + l15];
+#pragma unroll
+          for (int mt = 0; mt < MT; ++mt) acc[mt][j] = f32x4{b, b, b, b};
+        }
+      }
+      gemm_tile(acc, panelA, D, KS, transposed);
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
-        const int n = col_of(t, j);
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
-          if (m0 + mt * 16 + l15 >= p.M) continue;
           const f32x4 v = acc[mt][j];
           if constexpr (ABL & 1) {
             asm volatile("" ::"v"(v));
             continue;
           }
+          const bf16x4 o = {(bf16_t)v[0], (bf16_t)v[1], (bf16_t)v[2], (bf16_t)v[3]};
           if (!transposed) {
-            const bf16x4 o = {(bf16_t)v[0], (bf16_t)v[1], (bf16_t)v[2], (bf16_t)v[3]};
-            *reinterpret_cast<bf16x4*>(out + (int64_t)row_m[mt] * ldo + n) = o;
-          } else {
-            bf16_t* op = out + (int64_t)row_seq[mt] * p.vt_seq_stride + (int64_t)n * ldo + (row_m[mt] - row_seq[mt] * p.rows_per_seq);
-            op[0] = (bf16_t)v[0];
-            op[ldo] = (bf16_t)v[1];
-            op[2 * ldo] = (bf16_t)v[2];
-            op[3 * ldo] = (bf16_t)v[3];
+            if (m0 + mt * 16 + l15 >= p.M) continue;
+            *reinterpret_cast<bf16x4*>(out + (int64_t)row_m[mt] * ldo + col_of(t, j)) = o;
+          } else {  // rows m .. m+3 (m % 4 == 0, rows_per_seq % 4 == 0: never straddle a sequence), column n
+            const int m = m0 + mt * 16 + g * 4;
+            if (m >= p.M) continue;
+            const int sq = m / p.rows_per_seq, n = t * 128 + wid * 32 + j * 16 + l15;
+            *reinterpret_cast<bf16x4*>(out + (int64_t)sq * p.vt_seq_stride + (int64_t)n * ldo + (m - sq * p.rows_per_seq)) = o;
           }
         }
       }
