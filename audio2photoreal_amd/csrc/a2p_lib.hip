@@ -11,6 +11,7 @@
 //   FiLM scale|shift         fp32 [N][L][F][2d]      regenerated every step from the time path
 //   time-token K / V tail    fp32 [B*2][L*d]
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <math.h>
 #include <stdarg.h>
 #include <stdio.h>
@@ -112,25 +113,28 @@ struct a2p_ctx {
 // ------------------------------------------------------------------------------------------------
 // launch helpers
 // ------------------------------------------------------------------------------------------------
+// Per-kernel timing for bench.py's roofline leg: when enabled for a kernel class, the launch goes through
+// hipExtLaunchKernelGGL, which stamps the start/stop events from the dispatch packet itself (the kernel's own begin/end
+// on the launch stream) -- bracketing hipEventRecord calls would add ~20-35 us of marker-packet latency per launch.
 struct KernelTimer {
   a2p_ctx* c;
-  hipStream_t s;
   bool on;
-  hipEvent_t e0, e1;
-  KernelTimer(a2p_ctx* ctx, int kind, hipStream_t st) : c(ctx), s(st), on(ctx && ctx->time_kind == kind) {
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  KernelTimer(a2p_ctx* ctx, int kind) : c(ctx), on(ctx && ctx->time_kind == kind) {
     if (on) {
-      hipEventCreate(&e0);
-      hipEventCreate(&e1);
-      hipEventRecord(e0, s);
+      (void)hipEventCreate(&e0);
+      (void)hipEventCreate(&e1);
     }
   }
   ~KernelTimer() {
-    if (on) {
-      hipEventRecord(e1, s);
-      c->evs.push_back({e0, e1});
-    }
+    if (on) c->evs.push_back({e0, e1});
   }
 };
+#define A2P_LAUNCH(kt, kernel, grid, block, stream, ...)                                                        \
+  do {                                                                                                          \
+    if ((kt).on) hipExtLaunchKernelGGL(kernel, dim3(grid), dim3(block), 0, stream, (kt).e0, (kt).e1, 0, __VA_ARGS__); \
+    else hipLaunchKernelGGL(kernel, dim3(grid), dim3(block), 0, stream, __VA_ARGS__);                           \
+  } while (0)
 
 static GemmP gemm_base(const void* A, int64_t lda, const void* W, int64_t ldw, const float* bias, void* out, int64_t ldo,
                        int M, int N, int K) {
@@ -142,9 +146,9 @@ static GemmP gemm_base(const void* A, int64_t lda, const void* W, int64_t ldw, c
 }
 
 template <typename T, int MT>
-static int gemm_dispatch(const GemmP& p, hipStream_t s) {
+static int gemm_dispatch(KernelTimer& kt, const GemmP& p, hipStream_t s) {
   dim3 grid((p.N + 127) / 128, (p.M + 32 * MT - 1) / (32 * MT));
-#define A2P_GEMM(EPI, ACT, F32) gemm_kernel<T, MT, EPI, ACT, F32><<<grid, 256, 0, s>>>(p)
+#define A2P_GEMM(EPI, ACT, F32) A2P_LAUNCH(kt, (gemm_kernel<T, MT, EPI, ACT, F32>), grid, 256, s, p)
   if (p.epi == EPI_FILM_RES) A2P_GEMM(EPI_FILM_RES, ACT_NONE, false);
   else if (p.epi == EPI_STORE_T && p.act == ACT_NONE) A2P_GEMM(EPI_STORE_T, ACT_NONE, false);
   else if (p.epi == EPI_CONV && p.act == ACT_LRELU && !p.out_f32) A2P_GEMM(EPI_CONV, ACT_LRELU, false);
@@ -167,10 +171,10 @@ static int launch_gemm(a2p_ctx* c, const GemmP& p, hipStream_t s) {
   // load / MFMA / epilogue phases).  fp32: 128x128 unless that leaves the 256 CUs under two blocks each.
   const int64_t blocks128 = (int64_t)((p.N + 127) / 128) * ((p.M + 127) / 128);
   const bool small = c->bf16 || blocks128 < 512;
-  KernelTimer kt(c, A2P_KERNEL_GEMM, s);
+  KernelTimer kt(c, A2P_KERNEL_GEMM);
   int rc;
-  if (c->bf16) rc = small ? gemm_dispatch<bf16_t, 2>(p, s) : gemm_dispatch<bf16_t, 4>(p, s);
-  else rc = small ? gemm_dispatch<float, 2>(p, s) : gemm_dispatch<float, 4>(p, s);
+  if (c->bf16) rc = small ? gemm_dispatch<bf16_t, 2>(kt, p, s) : gemm_dispatch<bf16_t, 4>(kt, p, s);
+  else rc = small ? gemm_dispatch<float, 2>(kt, p, s) : gemm_dispatch<float, 4>(kt, p, s);
   CHK(rc);
   HIPCHK(hipGetLastError());
   return 0;
@@ -195,14 +199,14 @@ static int launch_ln_rope(a2p_ctx* c, bool as_f32, const float* x, int64_t ldx, 
   p.x = x; p.ldx = ldx; p.gamma = gamma; p.beta = beta; p.cs = reinterpret_cast<const float2*>(c->rope_cs.p);
   p.out_n = out_n; p.out_r = out_r; p.ldo = ldo; p.rows = rows; p.rows_per_seq = rows_per_seq; p.pos_off = pos_off;
   const int grid = (rows + 3) / 4;
-  KernelTimer kt(c, A2P_KERNEL_LNROPE, s);
+  KernelTimer kt(c, A2P_KERNEL_LNROPE);
   const bool b16 = c->bf16 && !as_f32;
   if (c->d == 512) {
-    if (b16) ln_rope_kernel<bf16_t, 8><<<grid, 256, 0, s>>>(p);
-    else ln_rope_kernel<float, 8><<<grid, 256, 0, s>>>(p);
+    if (b16) A2P_LAUNCH(kt, (ln_rope_kernel<bf16_t, 8>), grid, 256, s, p);
+    else A2P_LAUNCH(kt, (ln_rope_kernel<float, 8>), grid, 256, s, p);
   } else {
-    if (b16) ln_rope_kernel<bf16_t, 4><<<grid, 256, 0, s>>>(p);
-    else ln_rope_kernel<float, 4><<<grid, 256, 0, s>>>(p);
+    if (b16) A2P_LAUNCH(kt, (ln_rope_kernel<bf16_t, 4>), grid, 256, s, p);
+    else A2P_LAUNCH(kt, (ln_rope_kernel<float, 4>), grid, 256, s, p);
   }
   HIPCHK(hipGetLastError());
   return 0;
@@ -210,13 +214,13 @@ static int launch_ln_rope(a2p_ctx* c, bool as_f32, const float* x, int64_t ldx, 
 
 static int launch_attn(a2p_ctx* c, const AttnP& p, int nseq, int kind, hipStream_t s) {
   dim3 grid((p.Tq + 127) / 128, c->H, nseq);
-  KernelTimer kt(c, kind, s);
+  KernelTimer kt(c, kind);
   if (c->DH == 64) {
-    if (c->bf16) attn_kernel<bf16_t, 64><<<grid, 256, 0, s>>>(p);
-    else attn_kernel<float, 64><<<grid, 256, 0, s>>>(p);
+    if (c->bf16) A2P_LAUNCH(kt, (attn_kernel<bf16_t, 64>), grid, 256, s, p);
+    else A2P_LAUNCH(kt, (attn_kernel<float, 64>), grid, 256, s, p);
   } else {
-    if (c->bf16) attn_kernel<bf16_t, 32><<<grid, 256, 0, s>>>(p);
-    else attn_kernel<float, 32><<<grid, 256, 0, s>>>(p);
+    if (c->bf16) A2P_LAUNCH(kt, (attn_kernel<bf16_t, 32>), grid, 256, s, p);
+    else A2P_LAUNCH(kt, (attn_kernel<float, 32>), grid, 256, s, p);
   }
   HIPCHK(hipGetLastError());
   return 0;

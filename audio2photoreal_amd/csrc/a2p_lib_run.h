@@ -213,12 +213,12 @@ static int launch_chain(a2p_ctx* c, int mode, const ChainP& p, hipStream_t s) {
     }
   }
   const int grid = (p.M + 16 * mt - 1) / (16 * mt);
-  KernelTimer kt(c, A2P_KERNEL_CHAIN, s);
+  KernelTimer kt(c, A2P_KERNEL_CHAIN);
 #define A2P_CHAIN(MT)                                                                                   \
   do {                                                                                                  \
-    if (mode == CHAIN_PRE) chain_kernel<512, MT, CHAIN_PRE><<<grid, 256, 0, s>>>(p);                    \
-    else if (mode == CHAIN_MID) chain_kernel<512, MT, CHAIN_MID><<<grid, 256, 0, s>>>(p);               \
-    else chain_kernel<512, MT, CHAIN_POST><<<grid, 256, 0, s>>>(p);                                     \
+    if (mode == CHAIN_PRE) A2P_LAUNCH(kt, (chain_kernel<512, MT, CHAIN_PRE, 0>), grid, 256, s, p);      \
+    else if (mode == CHAIN_MID) A2P_LAUNCH(kt, (chain_kernel<512, MT, CHAIN_MID, 0>), grid, 256, s, p); \
+    else A2P_LAUNCH(kt, (chain_kernel<512, MT, CHAIN_POST, 0>), grid, 256, s, p);                       \
   } while (0)
   if (mt == 2) A2P_CHAIN(2);
   else if (mt == 3) A2P_CHAIN(3);

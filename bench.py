@@ -181,8 +181,14 @@ def main():
             kernels[name] = ent
         dom = max((k for k in kernels if k in flops), key=lambda k: kernels[k]["ms_per_step"])
         peak = PEAK_BF16_TFLOPS if a.precision == "bf16" else PEAK_F32_TFLOPS
+        # HBM bytes per launch of that kernel class from the rocprofv3 PMC passes (FETCH_SIZE doubled per the gfx950 note
+        # of MI355X_MICROARCH.md + WRITE_SIZE; scratch/run_pmc.sh writes the file) -- null when not collected
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+        if os.path.exists(tpath) and B == 8 and T == 600 and a.precision == "bf16":
+            traffic = json.load(open(tpath)).get(dom)
         roofline = {"kernel": dom, "bound": "mfma", "achieved": kernels[dom]["tflops"], "peak": peak, "unit": "TFLOP/s",
-                    "frac": round(kernels[dom]["tflops"] / peak, 4), "traffic": None,
+                    "frac": round(kernels[dom]["tflops"] / peak, 4), "traffic": traffic,
                     "avg_launch_us": kernels[dom]["avg_launch_us"],
                     "algorithmic_gflop_per_launch": round(flops[dom] / 1e9 / kernels[dom]["launches_per_step"], 3)}
 
@@ -197,17 +203,18 @@ def main():
         ce, xc = cond[:cb].cpu(), x[:cb].cpu()
         fn = lambda xx, ts: den.forward_cfg(xx, ts, ce, torch.full((cb,), 10.0))
         smp = O.OracleSampler("")
-        nz = [torch.randn(xc.shape) for _ in range(3)]
+        CPU_STEPS = 8   # ~10-20 s on the box's host cores
+        nz = [torch.randn(xc.shape) for _ in range(CPU_STEPS + 1)]
         with torch.no_grad():
             smp.p_sample_loop(fn, xc, nz, max_steps=1)      # warm-up
             t0 = time.perf_counter()
-            smp.p_sample_loop(fn, xc, nz, max_steps=2)
+            smp.p_sample_loop(fn, xc, nz, max_steps=CPU_STEPS)
             cdt = time.perf_counter() - t0
-        sample_steps_per_s = cb * 2 / cdt
+        sample_steps_per_s = cb * CPU_STEPS / cdt
         cpu = {"value": round(sample_steps_per_s / B, 5), "unit": f"denoise steps/sec at batch {B} (scaled from sample-steps/sec)",
                "cores": torch.get_num_threads(), "kind": "port",
                "sample": f"oracle (torch CPU fp32 restatement, conditioning path recomputed every forward like the reference's "
-                         f"decoder-only path), {cb} sample x 2 DDPM steps, T={T}, S={S0 + 2}: {cdt:.2f} s"}
+                         f"decoder-only path), {cb} sample x {CPU_STEPS} DDPM steps, T={T}, S={S0 + 2}: {cdt:.2f} s"}
 
     if rank == 0:
         value = world * a.steps / dt
