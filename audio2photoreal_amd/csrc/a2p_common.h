@@ -8,6 +8,7 @@ typedef __bf16 bf16_t;
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(2))) float f32x2;
 
 // One MFMA "k-chunk": KCH k-values per instruction, each lane holding EPL contiguous
 // k-values of row/col (lane & 15), k-group (lane >> 4).  C/D layout for both:

@@ -569,7 +569,7 @@ extern "C" int a2p_finalize_weights(a2p_ctx* c, void* stream) {
   HIPCHK(hipStreamSynchronize(s));
   buf_free(ca2k32);
   buf_free(ca2v32);
-  if (c->bf16 && c->d == 512 && c->ff == 1024) CHK(chain_build_streams(c, s));
+  if (c->bf16 && (c->d == 512 || c->d == 256) && c->ff == 1024) CHK(chain_build_streams(c, s));
   c->finalized = true;
   return 0;
 }

@@ -97,7 +97,9 @@ static int ffn_block(a2p_ctx* c, const std::string& p, const std::string& norm, 
 // ------------------------------------------------------------------------------------------------
 // bf16 throughput mode: the decoder layer as row-panel chain kernels (kernels_chain.h) around the attentions
 // ------------------------------------------------------------------------------------------------
-static bool chain_supported(const a2p_ctx* c) { return c->bf16 && c->d == 512 && c->ff == 1024 && !c->ch_stream.empty() && !getenv("A2P_NO_CHAIN"); }
+static bool chain_supported(const a2p_ctx* c) {
+  return c->bf16 && (c->d == 512 || c->d == 256) && c->ff == 1024 && !c->ch_stream.empty() && !getenv("A2P_NO_CHAIN");
+}
 
 enum { CH_PRE = 0, CH_MID = 1, CH_MID2 = 2, CH_POST = 3 };
 static int ch_index(int layer, int kind) { return layer * 4 + kind; }
@@ -204,25 +206,39 @@ static void chain_set_out_proj(a2p_ctx* c, ChainP& p, const std::string& attn, c
 static int launch_chain(a2p_ctx* c, int mode, const ChainP& p, hipStream_t s) {
   const char* env_mt = getenv("A2P_CHAIN_MT");  // tuning / test override of the panel height (rows = 16 * MT)
   int mt = env_mt ? atoi(env_mt) : 0;
-  if (mt < 2 || mt > 4) {  // fewest rounds over the 256 CUs, then the taller panel (every panel streams all weights once)
+  // panel heights instantiated per width (LDS: the [16*MT][d] bf16 panel + hidden chunk + >= 3 ring slots must fit 160 KiB)
+  static const int kMt512[] = {4, 3, 2}, kMt256[] = {6, 5, 4, 3, 2};
+  const int* cands = c->d == 512 ? kMt512 : kMt256;
+  const int ncand = c->d == 512 ? 3 : 5;
+  bool ok = false;
+  for (int i = 0; i < ncand; ++i) ok = ok || cands[i] == mt;
+  if (!ok) {  // fewest rounds over the 256 CUs, then the cheaper (shorter) panel: every panel streams all weights once
     int best = 1 << 30;
-    for (int cand = 4; cand >= 2; --cand) {
-      const int blocks = (p.M + 16 * cand - 1) / (16 * cand);
-      const int cost = ((blocks + 255) / 256) * (16 + 4 * cand);
-      if (cost < best) { best = cost; mt = cand; }
+    for (int i = 0; i < ncand; ++i) {
+      const int blocks = (p.M + 16 * cands[i] - 1) / (16 * cands[i]);
+      const int cost = ((blocks + 255) / 256) * (16 + 4 * cands[i]);
+      if (cost < best) { best = cost; mt = cands[i]; }
     }
   }
   const int grid = (p.M + 16 * mt - 1) / (16 * mt);
   KernelTimer kt(c, A2P_KERNEL_CHAIN);
-#define A2P_CHAIN(MT)                                                                                   \
-  do {                                                                                                  \
-    if (mode == CHAIN_PRE) A2P_LAUNCH(kt, (chain_kernel<512, MT, CHAIN_PRE, 0>), grid, 256, s, p);      \
-    else if (mode == CHAIN_MID) A2P_LAUNCH(kt, (chain_kernel<512, MT, CHAIN_MID, 0>), grid, 256, s, p); \
-    else A2P_LAUNCH(kt, (chain_kernel<512, MT, CHAIN_POST, 0>), grid, 256, s, p);                       \
+#define A2P_CHAIN(D, MT)                                                                                   \
+  do {                                                                                                     \
+    if (mode == CHAIN_PRE) A2P_LAUNCH(kt, (chain_kernel<D, MT, CHAIN_PRE, 0>), grid, 256, s, p);           \
+    else if (mode == CHAIN_MID) A2P_LAUNCH(kt, (chain_kernel<D, MT, CHAIN_MID, 0>), grid, 256, s, p);      \
+    else A2P_LAUNCH(kt, (chain_kernel<D, MT, CHAIN_POST, 0>), grid, 256, s, p);                            \
   } while (0)
-  if (mt == 2) A2P_CHAIN(2);
-  else if (mt == 3) A2P_CHAIN(3);
-  else A2P_CHAIN(4);
+  if (c->d == 512) {
+    if (mt == 2) A2P_CHAIN(512, 2);
+    else if (mt == 3) A2P_CHAIN(512, 3);
+    else A2P_CHAIN(512, 4);
+  } else {
+    if (mt == 2) A2P_CHAIN(256, 2);
+    else if (mt == 3) A2P_CHAIN(256, 3);
+    else if (mt == 4) A2P_CHAIN(256, 4);
+    else if (mt == 5) A2P_CHAIN(256, 5);
+    else A2P_CHAIN(256, 6);
+  }
 #undef A2P_CHAIN
   HIPCHK(hipGetLastError());
   return 0;

@@ -18,6 +18,8 @@
 // on the source address + on the read (conflict-free ds_read_b128 / ds_read_b64).  fp32 (parity
 // mode) stages through registers into padded rows.
 #pragma once
+#include <type_traits>
+
 #include "a2p_common.h"
 
 struct AttnP {
@@ -48,9 +50,18 @@ struct AttnLds {
   static constexpr int LSV = DMA ? KV : KV + 2;
   static constexpr int KSZ = KV * LSK, VSZ = DH * LSV;
   // swizzle of the 16-byte chunk index (bf16 only)
+  // bf16: S^T tile kt takes the keys with (key % 8) / 4 == (kt & 1) of 32-key chunk kt / 2, so that a lane's P fragment of
+  // a chunk (accumulator rows g*4..g*4+3 of tiles 2c and 2c+1) covers the 8 CONTIGUOUS keys 32c + 8g .. +7 and the
+  // matching V^T fragment is one aligned ds_read_b128.  krow = K-tile row (key) feeding A-operand row i of tile kt.
+  __device__ static __forceinline__ int krow(int kt, int i) {
+    if constexpr (DMA) return 32 * (kt >> 1) + 8 * (i >> 2) + 4 * (kt & 1) + (i & 3);
+    else return kt * 16 + i;
+  }
+  // 16-byte chunk swizzle of the K tile: the 16 rows {8j + 4b + r} read by one ds_read_b128 group must hit 16 distinct
+  // 16-byte bank slots (slot = (row * row_bytes + pos * 16) mod 256)
   __device__ static __forceinline__ int kswz(int row) {
-    if constexpr (DH == 64) return (row >> 1) & 7;
-    else return (-(row >> 2)) & 3;
+    if constexpr (DH == 64) return (((row >> 3) & 3) << 1) | ((row >> 1) & 1);
+    else return (row >> 3) & 3;
   }
   __device__ static __forceinline__ int vswz(int row) { return (row >> 1) & 7; }
   __device__ static __forceinline__ int kidx(int row, int c) {
@@ -68,7 +79,9 @@ __device__ __forceinline__ void attn_glds16(const bf16_t* gsrc, bf16_t* lds_wave
                                    (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
 }
 
-template <typename T, int DH>
+// ABL: ablation switches for scratch/attn_bench.hip only (the library instantiates ABL = 0):
+//   1 = no exp, 2 = no running-max reduction, 4 = no staging / barriers after tile 0, 8 = no PV MFMAs, 16 = no QK^T MFMAs
+template <typename T, int DH, int ABL = 0>
 __global__ __launch_bounds__(256, 3) void attn_kernel(AttnP p) {
   using P = Prec<T>;
   using L = AttnLds<T, DH>;
@@ -160,17 +173,23 @@ __global__ __launch_bounds__(256, 3) void attn_kernel(AttnP p) {
     }
   };
 
-  if constexpr (L::DMA) stage_dma(0, 0);
-  for (int tile = 0; tile < ntiles; ++tile) {
+  // One 64-key tile.  BUF (LDS ring slot) and MASKED (tile reaches past the last key) are compile-time so the
+  // fragment addresses fold into immediates and the -inf masking costs nothing on full tiles (this loop is
+  // instruction-issue bound: ~250 VALU + 32 MFMA per tile per wave before, 3 waves per SIMD).
+  auto tile_body = [&](int tile, auto buf_c, auto masked_c) __attribute__((always_inline)) {
+    constexpr int BUF = decltype(buf_c)::value;
+    constexpr bool MASKED = decltype(masked_c)::value;
     const int kv0 = tile * KV;
-    const int buf = L::DMA ? (tile & 1) : 0;
+    constexpr int buf = L::DMA ? BUF : 0;
     T* Ks = smem + buf * (L::KSZ + L::VSZ);
     T* Vs = Ks + L::KSZ;
-    __syncthreads();  // bf16: tile landed (vmcnt(0)) and the other buffer is free; fp32: previous tile consumed
-    if constexpr (L::DMA) {
-      if (tile + 1 < ntiles) stage_dma(tile + 1, buf ^ 1);
-    } else {
-      stage_regs(tile);
+    if (!(ABL & 4) || tile == 0) {
+      __syncthreads();  // bf16: tile landed (vmcnt(0)) and the other buffer is free; fp32: previous tile consumed
+      if constexpr (L::DMA) {
+        if (tile + 1 < ntiles) stage_dma(tile + 1, buf ^ 1);
+      } else {
+        stage_regs(tile);
+      }
     }
     if (p.S_tail > 0 && kv0 + KV > p.S_main) {  // block-uniform: patch the time-token rows into the tile
       if constexpr (!L::DMA) __syncthreads();
@@ -199,21 +218,24 @@ __global__ __launch_bounds__(256, 3) void attn_kernel(AttnP p) {
     for (int kc = 0; kc < KC; ++kc) {
 #pragma unroll
       for (int kt = 0; kt < 4; ++kt) {
-        const typename P::Frag kf = P::load(&Ks[L::kidx(kt * 16 + l15, kc * P::KCH + g * P::EPL)]);
+        const typename P::Frag kf = P::load(&Ks[L::kidx(L::krow(kt, l15), kc * P::KCH + g * P::EPL)]);
 #pragma unroll
-        for (int qt = 0; qt < QT; ++qt) s[kt][qt] = P::mfma(kf, qf[qt][kc], s[kt][qt]);
+        for (int qt = 0; qt < QT; ++qt) {
+          if constexpr (!(ABL & 16)) s[kt][qt] = P::mfma(kf, qf[qt][kc], s[kt][qt]);
+          else asm volatile("" : "+v"(s[kt][qt]) : "v"(kf));
+        }
       }
     }
     // ---- online softmax (log2 domain); lane owns query l15, keys kt*16 + g*4 + r ----
     // VALU diet (this loop is VALU-bound, not MFMA-bound): masking only on the last tile, the
     // 1/sqrt(dh)*log2(e) scale folded into the exp2 argument (one fma per score), and the O rescale
     // skipped (wave-uniform branch) unless some running max actually moved.
-    if (kv0 + KV > S_total) {
+    if constexpr (MASKED) {
 #pragma unroll
       for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
         for (int r = 0; r < 4; ++r)
-          if (kv0 + kt * 16 + g * 4 + r >= S_total) {
+          if (kv0 + L::krow(kt, g * 4 + r) >= S_total) {
 #pragma unroll
             for (int qt = 0; qt < QT; ++qt) s[kt][qt][r] = -INFINITY;
           }
@@ -221,25 +243,37 @@ __global__ __launch_bounds__(256, 3) void attn_kernel(AttnP p) {
 #pragma unroll
     for (int qt = 0; qt < QT; ++qt) {
       float mx = s[0][qt][0];
+      if constexpr (!(ABL & 2)) {
 #pragma unroll
-      for (int kt = 0; kt < 4; ++kt)
+        for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) mx = fmaxf(mx, s[kt][qt][r]);
-      mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+          for (int r = 0; r < 4; ++r) mx = fmaxf(mx, s[kt][qt][r]);
+        mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+      }
       const float mnew = fmaxf(mrun[qt], mx * p.scale_log2e);
       const float alpha = __builtin_amdgcn_exp2f(mrun[qt] - mnew);
       const bool moved = mnew > mrun[qt];
       mrun[qt] = mnew;
-      float ps = 0.f;
+      // two scores per VALU instruction where the ISA has a packed form (v_pk_fma_f32 / v_pk_add_f32): this loop is
+      // instruction-issue bound (profiles/r01_attn_ablation.txt), the exp2 itself has no packed form
+      f32x2 ps2 = {0.f, 0.f};
+      const f32x2 sc2 = {p.scale_log2e, p.scale_log2e}, mn2 = {-mnew, -mnew};
 #pragma unroll
       for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const float e = __builtin_amdgcn_exp2f(fmaf(s[kt][qt][r], p.scale_log2e, -mnew));
-          s[kt][qt][r] = e;
-          ps += e;
+        for (int h = 0; h < 2; ++h) {
+          f32x2 v = {s[kt][qt][2 * h], s[kt][qt][2 * h + 1]};
+          v = __builtin_elementwise_fma(v, sc2, mn2);
+          if constexpr (!(ABL & 1)) {
+            v[0] = __builtin_amdgcn_exp2f(v[0]);
+            v[1] = __builtin_amdgcn_exp2f(v[1]);
+          }
+          ps2 += v;
+          s[kt][qt][2 * h] = v[0];
+          s[kt][qt][2 * h + 1] = v[1];
         }
+      const float ps = ps2[0] + ps2[1];
       lsum[qt] = lsum[qt] * alpha + ps;
       if (__any(moved)) {
 #pragma unroll
@@ -251,7 +285,7 @@ __global__ __launch_bounds__(256, 3) void attn_kernel(AttnP p) {
     // ---- O^T += V^T P^T ----
     if constexpr (sizeof(T) == 2) {
 #pragma unroll
-      for (int c = 0; c < 2; ++c) {  // 32-key chunk: element e -> key c*32 + (e>>2)*16 + g*4 + (e&3)
+      for (int c = 0; c < 2; ++c) {  // 32-key chunk: k-slot e of lane group g -> key c*32 + g*8 + e (see AttnLds::krow)
         bf16x8 pf[QT];
 #pragma unroll
         for (int qt = 0; qt < QT; ++qt) {
@@ -263,12 +297,12 @@ __global__ __launch_bounds__(256, 3) void attn_kernel(AttnP p) {
         }
 #pragma unroll
         for (int dv = 0; dv < DVT; ++dv) {
-          const int row = dv * 16 + l15;
-          const bf16x4 lo = *reinterpret_cast<const bf16x4*>(&Vs[L::vidx(row, c * 32 + g * 4)]);
-          const bf16x4 hi = *reinterpret_cast<const bf16x4*>(&Vs[L::vidx(row, c * 32 + 16 + g * 4)]);
-          const bf16x8 vf = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+          const bf16x8 vf = *reinterpret_cast<const bf16x8*>(&Vs[L::vidx(dv * 16 + l15, c * 32 + g * 8)]);
 #pragma unroll
-          for (int qt = 0; qt < QT; ++qt) o[qt][dv] = P::mfma(vf, pf[qt], o[qt][dv]);
+          for (int qt = 0; qt < QT; ++qt) {
+            if constexpr (!(ABL & 8)) o[qt][dv] = P::mfma(vf, pf[qt], o[qt][dv]);
+            else asm volatile("" : "+v"(o[qt][dv]) : "v"(vf), "v"(pf[qt]));
+          }
         }
       }
     } else {
@@ -284,6 +318,16 @@ __global__ __launch_bounds__(256, 3) void attn_kernel(AttnP p) {
           }
         }
     }
+  };
+  using std::integral_constant;
+  if constexpr (L::DMA) stage_dma(0, 0);
+  for (int tile = 0; tile < ntiles; tile += 2) {
+    const bool last0 = tile + 1 >= ntiles;
+    if (last0 && ntiles * KV > S_total) tile_body(tile, integral_constant<int, 0>{}, integral_constant<bool, true>{});
+    else tile_body(tile, integral_constant<int, 0>{}, integral_constant<bool, false>{});
+    if (last0) break;
+    if (tile + 2 >= ntiles && ntiles * KV > S_total) tile_body(tile + 1, integral_constant<int, 1>{}, integral_constant<bool, true>{});
+    else tile_body(tile + 1, integral_constant<int, 1>{}, integral_constant<bool, false>{});
   }
 
   // ---- normalise and store: lane owns query l15, rows dv*16 + g*4 + {0..3} ----

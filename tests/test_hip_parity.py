@@ -230,15 +230,18 @@ def test_properties_full_size(dev):
     assert torch.isfinite(full).all()
 
 
-@pytest.mark.parametrize("mt", ["2", "3", "4"])
-def test_chain_kernels_match_the_per_op_kernels_bf16(dev, golden, mt, monkeypatch):
+@pytest.mark.parametrize("fmt,mt", [("face", "2"), ("face", "3"), ("face", "4"), ("pose", "2"), ("pose", "3"), ("pose", "5"), ("pose", "6")])
+def test_chain_kernels_match_the_per_op_kernels_bf16(dev, golden, fmt, mt, monkeypatch):
     """bf16 mode runs the decoder layers as fused row-panel chain kernels (csrc/kernels_chain.h); the per-op
     kernels (GEMM / LayerNorm launches) must give the same answer to bf16 rounding, for every panel height,
-    including a ragged last panel (2*2*240 = 960 rows is not a multiple of 64)."""
-    import os
-    spec, model = get_model("face", "bf16", dev)
+    including a ragged last panel (2*2*240 = 960 rows is not a multiple of 64 / 80 / 96) and a panel that
+    straddles two sequences."""
+    spec, model = get_model(fmt, "bf16", dev)
     inp = synthetic_inputs(spec, 2, 240, SEED)
-    y = y_for(spec, inp, dev, 10.0)
+    if spec.is_pose:
+        inp["mask"][1, :, :, 90:] = False
+    scale = 10.0 if fmt == "face" else 2.0
+    y = y_for(spec, inp, dev, scale)
     times = torch.tensor([937, 12], device=dev)
     x = inp["x_T"].to(dev)
     cfg = ClassifierFreeSampleModel(model)
@@ -248,6 +251,7 @@ def test_chain_kernels_match_the_per_op_kernels_bf16(dev, golden, mt, monkeypatc
     monkeypatch.setenv("A2P_NO_CHAIN", "1")
     per_op = cfg(x, times, y).cpu()
     monkeypatch.delenv("A2P_NO_CHAIN")
-    e_pair, e_gold, e_old = rel_l2(chained, per_op), rel_l2(chained, golden["face/fwd_cfg"]), rel_l2(per_op, golden["face/fwd_cfg"])
-    print(f"chain MT={mt}: vs per-op {e_pair:.3e}; vs fp32 reference: chain {e_gold:.3e}, per-op {e_old:.3e}")
+    ref = golden[f"{fmt}/fwd_cfg"]
+    e_pair, e_gold, e_old = rel_l2(chained, per_op), rel_l2(chained, ref), rel_l2(per_op, ref)
+    print(f"chain {fmt} MT={mt}: vs per-op {e_pair:.3e}; vs fp32 reference: chain {e_gold:.3e}, per-op {e_old:.3e}")
     assert e_pair < 3e-2 and e_gold < 0.25 and e_gold < 2.0 * e_old + 1e-3
