@@ -105,6 +105,9 @@ struct a2p_ctx {
   int time_kind = -1;
   std::vector<std::pair<hipEvent_t, hipEvent_t>> evs;
   std::vector<hipEvent_t> ev_pool;
+  // side stream: the per-step time path (t -> FiLM scale/shift, time-token K/V) overlaps the first projections / self attention
+  hipStream_t side = nullptr;
+  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
 
   void* offT(const Buf& b, int64_t elems) const { return reinterpret_cast<char*>(b.p) + elems * (int64_t)esz; }
   void* offT(void* p, int64_t elems) const { return reinterpret_cast<char*>(p) + elems * (int64_t)esz; }
@@ -367,6 +370,12 @@ extern "C" int a2p_ctx_create(const a2p_config* cfg, a2p_ctx** out) {
     A(c->kf_pack, (size_t)B * c->KFmax * c->KdPad * c->esz); A(c->kf_tok, (size_t)B * c->KFmax * d * 4);
   }
   A(c->slot_cond, B * 4); A(c->slot_unc, B * 4); A(c->slot_cfg, N * 4);
+  if (rc == 0 && (hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking) != hipSuccess ||
+                  hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) != hipSuccess ||
+                  hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming) != hipSuccess)) {
+    set_err("side stream / event creation failed");
+    rc = A2P_ERR_HIP;
+  }
   if (rc != 0) {
     a2p_ctx_destroy(c);
     return rc;
@@ -390,6 +399,9 @@ extern "C" int a2p_ctx_destroy(a2p_ctx* c) {
   for (int i = 0; i < 7; ++i) buf_free(c->conv_wt[i]);
   for (auto& b : c->ch_stream) buf_free(b);
   for (auto& b : c->ch_aux) buf_free(b);
+  if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
+  if (c->ev_join) (void)hipEventDestroy(c->ev_join);
+  if (c->side) (void)hipStreamDestroy(c->side);
   for (auto& e : c->evs) {
     hipEventDestroy(e.first);
     hipEventDestroy(e.second);

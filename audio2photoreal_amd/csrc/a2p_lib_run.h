@@ -170,6 +170,9 @@ static int chain_build_streams(a2p_ctx* c, hipStream_t s) {
     if (l + 1 < L) {
       add_pre(q, l + 1);
       aux.push_back({W32(c, pf(l + 1) + "self_attn.in_proj_bias"), 3 * d});
+    } else if (!c->pose) {  // last layer of the face model: final_layer rides on the same stream (pose feeds the conv tail instead)
+      pk_gemm(q, c->wt.at("final_layer.weight").p, d, c->C, d);
+      aux.push_back({W32(c, "final_layer.bias"), c->C});
     }
     CHK(chain_pack(c, ch_index(l, CH_POST), q, aux, s));
   }
@@ -273,7 +276,7 @@ static int launch_cross_attention(a2p_ctx* c, int N, int T, const CrossKV& kv, h
 
 // FiLMTransformerDecoderLayer.forward as PRE? | self attention | MID | cross attention | (MID | cross attention 2) | POST
 static int decoder_layer_chain(a2p_ctx* c, int l, int N, int T, const CrossKV& kv, const CrossKV* kv2, const FilmRef& fr, bool first,
-                               bool has_next, hipStream_t s) {
+                               bool has_next, hipStream_t s, hipEvent_t film_ready = nullptr, bool fuse_final = false) {
   const int d = c->d;
   const std::string pf = "seqTransDecoder.stack." + std::to_string(l) + ".";
   ChainP p;
@@ -283,6 +286,7 @@ static int decoder_layer_chain(a2p_ctx* c, int l, int N, int T, const CrossKV& k
     CHK(launch_chain(c, CHAIN_PRE, p, s));
   }
   CHK(launch_self_attention(c, N, T, s));
+  if (film_ready) HIPCHK(hipStreamWaitEvent(s, film_ready, 0));  // FiLM / time-token K,V of this step (side stream)
   auto mid = [&](int kind, const std::string& attn_done, int film_idx, const std::string& norm) -> int {
     chain_base(c, p, N, T, ch_index(l, kind), d);
     chain_set_out_proj(c, p, pf + attn_done, fr, film_idx);
@@ -303,6 +307,10 @@ static int decoder_layer_chain(a2p_ctx* c, int l, int N, int T, const CrossKV& k
   if (fr.base) p.film_f = fr.base + (int64_t)2 * 2 * d;
   p.has_next = has_next ? 1 : 0;
   if (has_next) chain_set_pre(c, p, l + 1, T);
+  if (!has_next && fuse_final) {  // model output rows straight from the last POST kernel (c->x is NOT updated)
+    p.has_next = 2; p.fin_out = c->mo.f(); p.ld_fin = c->C; p.fin_n = c->C;
+    p.aux_kb = (c->ff + c->C + 255) / 256;
+  }
   return launch_chain(c, CHAIN_POST, p, s);
 }
 
@@ -449,6 +457,17 @@ static int run_forward(a2p_ctx* c, const float* x_in, const int64_t* t_orig, int
   const int d = c->d, B = c->pB, T = c->pT, L = c->L, F = c->F;
   const int N = pass == A2P_PASS_CFG ? 2 * B : B;
   const int* slots = (const int*)(pass == A2P_PASS_CFG ? c->slot_cfg.p : (pass == A2P_PASS_COND ? c->slot_cond.p : c->slot_unc.p));
+  // chain mode: nothing before the first out_proj epilogue needs the time path, so it runs on the side stream next to
+  // input projection / norm1+QKV / self attention of layer 0 (7 latency-bound launches, ~70 us at B=8)
+  const bool overlap_tpath = chain_supported(c) && !getenv("A2P_NO_SIDE_STREAM");
+  if (overlap_tpath) {
+    HIPCHK(hipEventRecord(c->ev_fork, s));  // orders the side stream behind t_orig AND behind the previous step's readers
+    HIPCHK(hipStreamWaitEvent(c->side, c->ev_fork, 0));
+    CHK(time_path(c, t_orig, N, slots, c->side));
+    HIPCHK(hipEventRecord(c->ev_join, c->side));
+  } else {
+    CHK(time_path(c, t_orig, N, slots, s));
+  }
   // input permute + projection (model/diffusion.py:345-346,364)
   {
     dim3 grid((T + 31) / 32, (c->Cpad + 31) / 32, B);
@@ -461,7 +480,6 @@ static int run_forward(a2p_ctx* c, const float* x_in, const int64_t* t_orig, int
     if (N == 2 * B)
       HIPCHK(hipMemcpyAsync(c->x.f() + (size_t)B * T * d, c->x.p, (size_t)B * T * d * 4, hipMemcpyDeviceToDevice, s));
   }
-  CHK(time_path(c, t_orig, N, slots, s));
   CrossKV kv, kv2;
   for (int l = 0; l < L; ++l) {
     kv.K = c->offT(c->kc, (int64_t)l * d); kv.k_slot_stride = (int64_t)c->Sld * L * d; kv.ldk = (int64_t)L * d;
@@ -477,10 +495,16 @@ static int run_forward(a2p_ctx* c, const float* x_in, const int64_t* t_orig, int
     FilmRef fr;
     fr.base = c->film.f() + (size_t)l * F * 2 * d;
     fr.seq_stride = (int64_t)L * F * 2 * d;
-    if (chain_supported(c)) CHK(decoder_layer_chain(c, l, N, T, kv, c->pose ? &kv2 : nullptr, fr, l == 0, l + 1 < L, s));
+    if (chain_supported(c))
+      CHK(decoder_layer_chain(c, l, N, T, kv, c->pose ? &kv2 : nullptr, fr, l == 0, l + 1 < L, s, (overlap_tpath && l == 0) ? c->ev_join : nullptr,
+                              /*fuse_final=*/!c->pose));
     else CHK(decoder_layer(c, l, N, T, kv, c->pose ? &kv2 : nullptr, fr, s));
   }
-  // final_layer (model/diffusion.py:397): cast the stream, GEMM
+  // final_layer (model/diffusion.py:397): cast the stream, GEMM   (face + chain mode: already done by the last POST kernel)
+  if (chain_supported(c) && !c->pose) {
+    *mo_seq_rows = T;
+    return 0;
+  }
   CHK(launch_ln_rope(c, false, c->x.f(), d, nullptr, nullptr, c->xn.p, nullptr, d, N * T, T, 0, s));
   if (!c->pose) {
     GemmP p = gemm_base(c->xn.p, d, c->wt.at("final_layer.weight").p, d, W32(c, "final_layer.bias"), c->mo.p, c->C, N * T, c->C, d);

@@ -67,6 +67,11 @@ struct ChainP {
   bf16_t* vt_out;
   int64_t vt_seq_stride, ld_vt;
   const float2* cs;  // rotary table [pos][D/2]
+  // has_next == 2 (last decoder layer): final_layer (model/diffusion.py:397) instead of the next layer's PRE work;
+  // fp32 rows out[m][0..fin_n), bias in aux after bias_1; the residual stream itself is not written back
+  float* fin_out;
+  int64_t ld_fin;
+  int fin_n;
 };
 
 // one 16 KiB stage of a packed stream: stage = rows [row0, row0+128) x k [k0, k0+64) of W[., ldw]
@@ -467,8 +472,38 @@ __global__ __launch_bounds__(256, 1) void chain_kernel(const ChainP p) {
       }
 #pragma unroll
       for (int t = 0; t < NT; ++t) film_res(facc[t], t, p.bias_2, p.film_f);
-      store_x();
-      if (p.has_next) pre_work(aux + FT * 128);
+      if (p.has_next == 2) {
+        // final_layer on the finished rows: plain bf16 cast into the A panel, [BM x fin_n] GEMM, fp32 store
+#pragma unroll
+        for (int ns = 0; ns < NSUB; ++ns) {
+          const int n = col_of(ns >> 1, ns & 1);
+#pragma unroll
+          for (int mt = 0; mt < MT; ++mt) {
+            const bf16x4 o = {(bf16_t)xrow[mt][ns][0], (bf16_t)xrow[mt][ns][1], (bf16_t)xrow[mt][ns][2], (bf16_t)xrow[mt][ns][3]};
+            *reinterpret_cast<bf16x4*>(panelA + (mt * 16 + l15) * D + ((((n >> 3) ^ l15) << 3) | (n & 7))) = o;
+          }
+        }
+        chain_bar();
+        for (int t = 0; t < (p.fin_n + 127) / 128; ++t) {
+          f32x4 acc[MT][2];
+          init_bias(acc, aux + FT * 128 + t * 128);
+          gemm_tile(acc, panelA, D, KS);
+#pragma unroll
+          for (int j = 0; j < 2; ++j) {
+            const int n = col_of(t, j);
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+              if (m0 + mt * 16 + l15 >= p.M || n >= p.fin_n) continue;
+              if constexpr (!(ABL & 1))
+                *reinterpret_cast<float4*>(p.fin_out + (int64_t)row_m[mt] * p.ld_fin + n) =
+                    make_float4(acc[mt][j][0], acc[mt][j][1], acc[mt][j][2], acc[mt][j][3]);
+            }
+          }
+        }
+      } else {
+        store_x();
+        if (p.has_next) pre_work(aux + FT * 128);
+      }
     }
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the run-ahead DMA slices must land before the LDS is released
