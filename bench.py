@@ -57,6 +57,8 @@ def main():
     ap.add_argument("--batch", type=int, default=8)
     ap.add_argument("--frames", type=int, default=600)
     ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--model", default="face", choices=["face", "pose"],
+                    help="face = BASELINE configs[1] (the metric's config, default); pose = configs[2] shape (body model, keyframes, scale 2)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
     a = ap.parse_args()
@@ -81,14 +83,14 @@ def main():
     from audio2photoreal_amd import _lib
     from audio2photoreal_amd.model.cfg_sampler import ClassifierFreeSampleModel
     from audio2photoreal_amd.model_util import create_model_and_diffusion, default_args, load_model
-    from audio2photoreal_amd.spec import face_spec
+    from audio2photoreal_amd.spec import face_spec, pose_spec
     from audio2photoreal_amd.synthetic import cond_tokens_for_frames, synthetic_state_dict, synthetic_tensor
 
-    spec = face_spec()
+    spec = face_spec() if a.model == "face" else pose_spec()
     B, T = a.batch, a.frames
     S0 = cond_tokens_for_frames(T)
     sd = synthetic_state_dict(spec, 10)
-    model, diffusion = create_model_and_diffusion(default_args("face", timestep_respacing=""), "test",
+    model, diffusion = create_model_and_diffusion(default_args(a.model, timestep_respacing=""), "test",
                                                   precision=a.precision, max_batch=B)
     load_model(model, sd)
     model = model.to(dev).eval()
@@ -98,7 +100,11 @@ def main():
     g0 = rank * B
     cond = torch.stack([synthetic_tensor(10, f"cond_embed/{g0 + i}", (S0, spec.cond_feature_dim)) for i in range(B)]).to(dev)
     x = torch.stack([synthetic_tensor(10, f"x_T/{g0 + i}", (spec.nfeats, 1, T)) for i in range(B)]).to(dev)
-    y = {"cond_embed": cond, "scale": torch.full((B,), 10.0, device=dev)}
+    y = {"cond_embed": cond, "scale": torch.full((B,), 10.0 if a.model == "face" else 2.0, device=dev)}
+    if spec.is_pose:
+        nk = len(range(T)[:: spec.keyframe_step])
+        y["keyframes"] = torch.stack([synthetic_tensor(10, f"keyframes/{g0 + i}", (nk, spec.keyframe_dim)) for i in range(B)]).to(dev)
+        y["mask"] = torch.ones(B, 1, 1, T, dtype=torch.bool, device=dev)
     gen = torch.Generator(device=dev).manual_seed(1234 + rank)
 
     model.prepare(x, y)                       # context + weight upload + first conditioning pass (untimed setup)
@@ -194,7 +200,7 @@ def main():
 
     # ---- CPU baseline: the oracle (port of the reference algorithm) on this box's host cores ----
     cpu = None
-    if rank == 0 and not a.no_cpu_baseline:
+    if rank == 0 and not a.no_cpu_baseline and a.model == "face":
         from oracle import a2p_oracle as O
         cores = min(os.cpu_count() or 1, 32)   # torch CPU matmuls at these sizes stop scaling (and thrash) past ~32 threads
         torch.set_num_threads(cores)
@@ -221,11 +227,11 @@ def main():
         fl = algorithmic_flops(spec, T, S0 + 2, 2 * B)
         step_flops = fl["decoder_gemm"] + fl["attn_self"] + fl["attn_cross"]   # decoder attention + FFN + projections
         line = {
-            "metric": "diffusion denoise steps/sec (face, 600-frame seq, batch 8 per GPU, CFG)", "value": round(value, 4),
+            "metric": f"diffusion denoise steps/sec ({a.model}, {T}-frame seq, batch {B} per GPU, CFG)", "value": round(value, 4),
             "unit": "steps/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": round(1e3 * dt / a.steps, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": a.precision, "data": "synthetic",
-            "config": {"workload": f"face FiLM denoiser 8L/8H d512, 1000-step DDPM p_sample chain, B={B}/GPU x2 CFG, "
+            "config": {"workload": f"{a.model} FiLM denoiser {spec.num_layers}L/{spec.num_heads}H d{spec.latent_dim}, 1000-step DDPM p_sample chain, B={B}/GPU x2 CFG, "
                                    f"T={T}, {S0}+2 cond tokens", "global_batch": B * world, "parallelism": f"sample-parallel x{world}"},
             "sample_steps_per_sec": round(value * B, 3),
             "decoder_tflops": round(world * step_flops * a.steps / dt / 1e12, 2),

@@ -255,3 +255,95 @@ def test_chain_kernels_match_the_per_op_kernels_bf16(dev, golden, fmt, mt, monke
     e_pair, e_gold, e_old = rel_l2(chained, per_op), rel_l2(chained, ref), rel_l2(per_op, ref)
     print(f"chain {fmt} MT={mt}: vs per-op {e_pair:.3e}; vs fp32 reference: chain {e_gold:.3e}, per-op {e_old:.3e}")
     assert e_pair < 3e-2 and e_gold < 0.25 and e_gold < 2.0 * e_old + 1e-3
+
+
+# ----------------------------------------------------------------------------- edge shapes / sampler API surface
+@pytest.mark.parametrize("fmt,B,frames", [("face", 1, 100), ("pose", 3, 64), ("face", 2, 4)])
+def test_edge_shapes_fp32_vs_oracle(dev, fmt, B, frames):
+    """Ragged sizes the reference accepts: frames not a multiple of the 64/128 tile sizes, token counts not a multiple of
+    64, odd batch, partially masked keyframes, the minimum frame count.  fp32 mode vs the pinned oracle, <= 1e-3."""
+    from oracle import a2p_oracle as O
+    from audio2photoreal_amd.synthetic import cond_tokens_for_frames
+    spec, model = get_model(fmt, "fp32", dev)
+    n_tok = max(cond_tokens_for_frames(frames), 3)
+    x = synthetic_tensor(SEED, "edge_x", (B, spec.nfeats, 1, frames))
+    ce = synthetic_tensor(SEED, "edge_ce", (B, n_tok, spec.cond_feature_dim))
+    scale = torch.full((B,), 10.0 if fmt == "face" else 2.0)
+    y = {"cond_embed": ce.to(dev), "scale": scale.to(dev)}
+    kf = mk = None
+    if spec.is_pose:
+        nk = len(range(frames)[:: spec.keyframe_step])
+        kf = synthetic_tensor(SEED, "edge_kf", (B, nk, spec.keyframe_dim))
+        mk = torch.ones(B, 1, 1, frames, dtype=torch.bool)
+        mk[0, :, :, 30:] = False
+        y["keyframes"], y["mask"] = kf.clone().to(dev), mk.clone().to(dev)
+    times = torch.tensor([999, 0, 500][:B])
+    got = ClassifierFreeSampleModel(model)(x.to(dev), times.to(dev), y).cpu()
+    den = O.OracleDenoiser(synthetic_state_dict(spec, SEED), fmt, spec.num_layers, spec.num_heads)
+    want = den.forward_cfg(x, times, ce, scale, kf, mk)
+    e2, em = rel_l2(got, want), rel_max(got, want)
+    print(f"edge {fmt} B={B} T={frames} S={n_tok}: rel L2 {e2:.3e} max-norm {em:.3e}")
+    assert e2 < 1e-3 and em < 1e-3
+
+
+def test_sampler_api_surface(dev):
+    """dump_steps / const_noise / init_image + skip_timesteps / progressive generators behave like the reference's loops
+    (gaussian_diffusion.py:525-665, :815-936), all arithmetic on the GPU."""
+    spec, model = get_model("face", "fp32", dev)
+    cfg = ClassifierFreeSampleModel(model)
+    d = make_diffusion("face", "ddim10")
+    inp = synthetic_inputs(spec, 2, 64, SEED, steps_of_noise=10)
+    y = y_for(spec, inp, dev, 10.0)
+    shape, x_T, nz = (2, spec.nfeats, 1, 64), inp["x_T"].to(dev), inp["step_noise"].to(dev)
+    kw = dict(clip_denoised=False, model_kwargs={"y": y}, noise=x_T, step_noise=lambda n: nz[n])
+    prog = [o["sample"].clone() for o in d.p_sample_loop_progressive(cfg, shape, **kw)]
+    assert len(prog) == 10
+    final = d.p_sample_loop(cfg, shape, **kw)
+    assert torch.equal(final, prog[-1])
+    dumped = d.p_sample_loop(cfg, shape, dump_steps=[0, 4, 9], **kw)
+    assert len(dumped) == 3 and all(torch.equal(a, prog[i]) for a, i in zip(dumped, (0, 4, 9)))
+    # const_noise: every sample of the batch receives sample 0's noise
+    c1 = d.p_sample(cfg, x_T, torch.tensor([5, 5], device=dev), clip_denoised=False, model_kwargs={"y": y}, noise=nz[0], const_noise=True)
+    c2 = d.p_sample(cfg, x_T, torch.tensor([5, 5], device=dev), clip_denoised=False, model_kwargs={"y": y},
+                    noise=nz[0][[0]].repeat(2, 1, 1, 1))
+    assert torch.equal(c1["sample"], c2["sample"])
+    # ddim loop returns pred_xstart and refuses dump_steps / const_noise like the reference (:839-842)
+    with pytest.raises(NotImplementedError):
+        d.ddim_sample_loop(cfg, shape, dump_steps=[1], clip_denoised=False, model_kwargs={"y": y}, noise=x_T)
+    with pytest.raises(NotImplementedError):
+        d.ddim_sample_loop(cfg, shape, const_noise=True, clip_denoised=False, model_kwargs={"y": y}, noise=x_T)
+    # init_image + skip_timesteps: the chain starts from q_sample(init_image, t_start, noise)   (:625-632)
+    init = synthetic_tensor(SEED, "init_image", shape).to(dev)
+    t_start = torch.full((2,), 10 - 4 - 1, device=dev)
+    x_start = d.q_sample(init, t_start, x_T)
+    tab = d._tables(dev)
+    want = tab[8][4 + 1] * init + tab[9][4 + 1] * x_T          # sqrt(abar) x0 + sqrt(1 - abar) noise at step index 5
+    assert rel_l2(x_start.cpu(), want.cpu()) < 1e-6
+    outs = list(d.ddim_sample_loop_progressive(cfg, shape, clip_denoised=False, model_kwargs={"y": y}, noise=x_T,
+                                               init_image=init, skip_timesteps=4))
+    assert len(outs) == 6
+    first = d.ddim_sample(cfg, x_start, t_start, clip_denoised=False, model_kwargs={"y": y})
+    assert rel_l2(outs[0]["sample"].cpu(), first["sample"].cpu()) < 1e-6
+
+
+def test_sample_parallel_world_size_1_and_generate_surface(dev):
+    """`_generate_sequences` / `_run_single_diffusion` (sample/generate.py:74-152) over the accelerated path:
+    results dict keys, un-normalisation, identical to calling the sampler directly."""
+    import argparse
+    from audio2photoreal_amd.sample.generate import _generate_sequences, make_inv_transform
+    spec, model = get_model("face", "fp32", dev)
+    cfg = ClassifierFreeSampleModel(model)
+    d = make_diffusion("face", "ddim10")
+    inp = synthetic_inputs(spec, 2, 64, SEED)
+    stats = {"code_mean": np.full(256, 0.5), "code_std": np.full(256, 2.0), "pose_mean": np.zeros(104), "pose_std": np.ones(104),
+             "audio_mean": np.zeros(2, np.float32), "audio_std": np.ones(2, np.float32)}
+    args = argparse.Namespace(batch_size=2, curr_seq_length=64, data_format="face", num_repetitions=2, guidance_param=10.0, device=dev)
+    torch.manual_seed(0)
+    res = _generate_sequences(args, {"y": {"cond_embed": inp["cond_embed"].to(dev), "lengths": torch.tensor([64, 64])}}, d, cfg,
+                              make_inv_transform(stats))
+    assert set(res) == {"motions", "audio", "gt", "lengths", "keyframes"}
+    assert res["motions"].shape == (4, 256, 1, 64) and res["lengths"].shape == (4,) and res["audio"] is None
+    torch.manual_seed(0)
+    y = {"cond_embed": inp["cond_embed"].to(dev), "scale": torch.full((2,), 10.0, device=dev)}
+    direct = d.ddim_sample_loop(cfg, (2, 256, 1, 64), clip_denoised=False, model_kwargs={"y": y}).cpu().numpy() * 2.0 + 0.5
+    assert np.allclose(res["motions"][:2], direct, rtol=1e-5, atol=1e-5)
