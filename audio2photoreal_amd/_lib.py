@@ -11,7 +11,7 @@ import os
 from typing import Optional
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "liba2p_hip.so")
+LIB_PATH = os.environ.get("A2P_LIB") or os.path.join(_HERE, "liba2p_hip.so")   # A2P_LIB: A/B builds of the kernels
 
 FACE, POSE = 0, 1
 PREC_F32, PREC_BF16 = 0, 1

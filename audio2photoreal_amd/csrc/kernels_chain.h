@@ -97,6 +97,27 @@ __device__ __forceinline__ void chain_glds16(const void* gsrc, void* lds_wave_ba
                                    (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
 }
 
+// Activation accesses go through these helpers so their cache policy is one switch.  Non-temporal (-DCHAIN_NT_ACT) was
+// measured and rejected: 2.42 vs 2.37 ms per step at B=8 (same box, 3 alternating runs) -- the activations are re-read by
+// the next kernel from L2/MALL, and evict-first costs more there than it saves on the weight stream.
+#ifdef CHAIN_NT_ACT
+#define CHAIN_NT 1
+#else
+#define CHAIN_NT 0
+#endif
+__device__ __forceinline__ f32x4 chain_ld4(const float* p) {
+  if constexpr (CHAIN_NT) return __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(p));
+  else return *reinterpret_cast<const f32x4*>(p);
+}
+__device__ __forceinline__ void chain_st4(float* p, f32x4 v) {
+  if constexpr (CHAIN_NT) __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(p));
+  else *reinterpret_cast<f32x4*>(p) = v;
+}
+__device__ __forceinline__ void chain_st_bf4(bf16_t* p, bf16x4 v) {
+  if constexpr (CHAIN_NT) __builtin_nontemporal_store(v, reinterpret_cast<bf16x4*>(p));
+  else *reinterpret_cast<bf16x4*>(p) = v;
+}
+
 // LDS-only barrier: never waits for the DMA queue
 __device__ __forceinline__ void chain_bar() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
@@ -258,7 +279,8 @@ __global__ __launch_bounds__(256, 1) void chain_kernel(const ChainP p) {
       const int row = r0 + lane / CPR, pos = lane % CPR;
       int m = m0 + row;
       m = m < p.M ? m : p.M - 1;
-      chain_glds16(p.ain + (int64_t)m * p.ld_ain + ((pos ^ (row & 15)) << 3), panelA + r0 * D);
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(p.ain + (int64_t)m * p.ld_ain + ((pos ^ (row & 15)) << 3)),
+                                       (__attribute__((address_space(3))) void*)(panelA + r0 * D), 16, 0, CHAIN_NT ? 2 : 0);
     }
   }
   for (int kb = wid; kb < p.aux_kb; kb += 4) chain_glds16(p.aux + kb * 256 + lane * 4, aux + kb * 256);
@@ -266,8 +288,7 @@ __global__ __launch_bounds__(256, 1) void chain_kernel(const ChainP p) {
   for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
     for (int ns = 0; ns < NSUB; ++ns) {
-      const float4 v = *reinterpret_cast<const float4*>(p.x + (int64_t)row_m[mt] * D + col_of(ns >> 1, ns & 1));
-      xrow[mt][ns] = f32x4{v.x, v.y, v.z, v.w};
+      xrow[mt][ns] = chain_ld4(p.x + (int64_t)row_m[mt] * D + col_of(ns >> 1, ns & 1));
     }
 #pragma unroll
   for (int i = 0; i < NS - 1; ++i) issue_stage();
@@ -371,8 +392,7 @@ __global__ __launch_bounds__(256, 1) void chain_kernel(const ChainP p) {
       if (m0 + mt * 16 + l15 >= p.M) continue;
 #pragma unroll
       for (int ns = 0; ns < NSUB; ++ns)
-        *reinterpret_cast<float4*>(p.x + (int64_t)row_m[mt] * D + col_of(ns >> 1, ns & 1)) =
-            make_float4(xrow[mt][ns][0], xrow[mt][ns][1], xrow[mt][ns][2], xrow[mt][ns][3]);
+        chain_st4(p.x + (int64_t)row_m[mt] * D + col_of(ns >> 1, ns & 1), xrow[mt][ns]);
     }
   };
   // D-deep GEMM over `ntiles` output tiles with a per-tile bf16 store: out[m][n] (row-major, 4 columns per lane) or the
@@ -403,12 +423,12 @@ __global__ __launch_bounds__(256, 1) void chain_kernel(const ChainP p) {
           const bf16x4 o = {(bf16_t)v[0], (bf16_t)v[1], (bf16_t)v[2], (bf16_t)v[3]};
           if (!transposed) {
             if (m0 + mt * 16 + l15 >= p.M) continue;
-            *reinterpret_cast<bf16x4*>(out + (int64_t)row_m[mt] * ldo + col_of(t, j)) = o;
+            chain_st_bf4(out + (int64_t)row_m[mt] * ldo + col_of(t, j), o);
           } else {  // rows m .. m+3 (m % 4 == 0, rows_per_seq % 4 == 0: never straddle a sequence), column n
             const int m = m0 + mt * 16 + g * 4;
             if (m >= p.M) continue;
             const int sq = m / p.rows_per_seq, n = t * 128 + wid * 32 + j * 16 + l15;
-            *reinterpret_cast<bf16x4*>(out + (int64_t)sq * p.vt_seq_stride + (int64_t)n * ldo + (m - sq * p.rows_per_seq)) = o;
+            chain_st_bf4(out + (int64_t)sq * p.vt_seq_stride + (int64_t)n * ldo + (m - sq * p.rows_per_seq), o);
           }
         }
       }
@@ -495,8 +515,7 @@ __global__ __launch_bounds__(256, 1) void chain_kernel(const ChainP p) {
             for (int mt = 0; mt < MT; ++mt) {
               if (m0 + mt * 16 + l15 >= p.M || n >= p.fin_n) continue;
               if constexpr (!(ABL & 1))
-                *reinterpret_cast<float4*>(p.fin_out + (int64_t)row_m[mt] * p.ld_fin + n) =
-                    make_float4(acc[mt][j][0], acc[mt][j][1], acc[mt][j][2], acc[mt][j][3]);
+                chain_st4(p.fin_out + (int64_t)row_m[mt] * p.ld_fin + n, acc[mt][j]);
             }
           }
         }

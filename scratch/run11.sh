@@ -1,0 +1,8 @@
+R=$GRAFT_REPO_ROOT
+cd $R
+timeout 600 python -m pytest tests -m gpu -x -q 2>&1 | tail -2
+for i in 1 2 3; do
+for v in "A2P_X=1" "A2P_LIB=$R/scratch/liba2p_nont.so" "A2P_NO_CHAIN=1"; do
+env $v timeout 300 python bench.py --steps 30 --warmup 5 --no-cpu-baseline --no-kernel-timing 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('$i $v', d['value'], d['ms_per_step'])"
+done
+done
