@@ -194,7 +194,8 @@ def main():
         if os.path.exists(tpath) and B == 8 and T == 600 and a.precision == "bf16":
             traffic = json.load(open(tpath)).get(dom)
         roofline = {"kernel": dom, "bound": "mfma", "achieved": kernels[dom]["tflops"], "peak": peak, "unit": "TFLOP/s",
-                    "frac": round(kernels[dom]["tflops"] / peak, 4), "traffic": traffic,
+                    "frac": round(kernels[dom]["tflops"] / peak, 4), "traffic": traffic and traffic["total_bytes"],
+                    "traffic_detail": traffic,
                     "avg_launch_us": kernels[dom]["avg_launch_us"],
                     "algorithmic_gflop_per_launch": round(flops[dom] / 1e9 / kernels[dom]["launches_per_step"], 3)}
 
@@ -241,6 +242,7 @@ def main():
         }
         print(json.dumps(line), flush=True)
     if world > 1:
+        dist.barrier()   # rank 0 may still be in its post-run measurement legs
         dist.destroy_process_group()
 
 
