@@ -459,7 +459,11 @@ static int run_forward(a2p_ctx* c, const float* x_in, const int64_t* t_orig, int
   const int* slots = (const int*)(pass == A2P_PASS_CFG ? c->slot_cfg.p : (pass == A2P_PASS_COND ? c->slot_cond.p : c->slot_unc.p));
   // chain mode: nothing before the first out_proj epilogue needs the time path, so it runs on the side stream next to
   // input projection / norm1+QKV / self attention of layer 0 (7 latency-bound launches, ~70 us at B=8)
-  const bool overlap_tpath = chain_supported(c) && !getenv("A2P_NO_SIDE_STREAM");
+  // Row panels pay off once there are enough of them: every workgroup streams the whole weight set of its chain, so a
+  // forward of < ~1000 rows (config 0: B=1, T=240 -> 480 rows = 10 panels) is faster as many small 2-D tiles
+  // (measured: 0.99 vs 1.10 ms per step at 480 rows, equal at 1200, chain ahead from 2400 rows on).
+  const bool use_chain = chain_supported(c) && ((int64_t)N * T >= 960 || getenv("A2P_CHAIN_MT"));
+  const bool overlap_tpath = use_chain && !getenv("A2P_NO_SIDE_STREAM");
   if (overlap_tpath) {
     HIPCHK(hipEventRecord(c->ev_fork, s));  // orders the side stream behind t_orig AND behind the previous step's readers
     HIPCHK(hipStreamWaitEvent(c->side, c->ev_fork, 0));
@@ -495,13 +499,13 @@ static int run_forward(a2p_ctx* c, const float* x_in, const int64_t* t_orig, int
     FilmRef fr;
     fr.base = c->film.f() + (size_t)l * F * 2 * d;
     fr.seq_stride = (int64_t)L * F * 2 * d;
-    if (chain_supported(c))
+    if (use_chain)
       CHK(decoder_layer_chain(c, l, N, T, kv, c->pose ? &kv2 : nullptr, fr, l == 0, l + 1 < L, s, (overlap_tpath && l == 0) ? c->ev_join : nullptr,
                               /*fuse_final=*/!c->pose));
     else CHK(decoder_layer(c, l, N, T, kv, c->pose ? &kv2 : nullptr, fr, s));
   }
   // final_layer (model/diffusion.py:397): cast the stream, GEMM   (face + chain mode: already done by the last POST kernel)
-  if (chain_supported(c) && !c->pose) {
+  if (use_chain && !c->pose) {
     *mo_seq_rows = T;
     return 0;
   }

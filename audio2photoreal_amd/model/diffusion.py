@@ -177,6 +177,7 @@ class FiLMTransformer(nn.Module):
         self.final_layer.apply(init_weight)
 
         self._ctx: Optional[C.c_void_p] = None
+        self._param_list = None
         self._ctx_key = None
         self._weights_key = None
         self._cond_key = None
@@ -211,11 +212,24 @@ class FiLMTransformer(nn.Module):
         self._ctx, self._ctx_key, self._weights_key, self._cond_key = ctx, key, None, None
         return lib
 
+    def _apply(self, fn, *args, **kwargs):
+        """`.to()/.cuda()/.float()` re-seat parameter storage without touching the version counters: mark the device copy stale."""
+        self._weights_key = None
+        return super()._apply(fn, *args, **kwargs)
+
+    def _weights_signature(self):
+        # runs every denoising step: must stay cheap (building the state_dict here cost ~0.5-1.3 ms per step and made
+        # small configurations host-bound).  In-place updates (load_state_dict, optimisers) bump `_version`;
+        # storage re-seating goes through `_apply` above.
+        if self._param_list is None:
+            self._param_list = list(self.parameters()) + list(self.buffers())
+        return (len(self._param_list), sum(p._version for p in self._param_list))
+
     def _ensure_weights(self, lib, device):
-        state = self._hot_state()
-        key = tuple((k, v.data_ptr(), v._version) for k, v in state.items())
+        key = self._weights_signature()
         if key == self._weights_key:
             return
+        state = self._hot_state()
         stream = _lib.current_stream()
         keep = []
         for name, t in state.items():
@@ -224,6 +238,11 @@ class FiLMTransformer(nn.Module):
             _lib.check(lib.a2p_set_weight(self._ctx, name.encode(), _lib.ptr(t), t.numel(), stream), f"a2p_set_weight({name})")
         _lib.check(lib.a2p_finalize_weights(self._ctx, stream), "a2p_finalize_weights")
         self._weights_key, self._cond_key = key, None
+
+    def invalidate_weights(self):
+        """Force a re-upload on the next call (needed only after writes that bypass the version counters, e.g. `p.data.copy_`)."""
+        self._weights_key = None
+        self._param_list = None
 
     def release(self):
         if self._ctx is not None:

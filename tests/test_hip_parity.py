@@ -347,3 +347,28 @@ def test_sample_parallel_world_size_1_and_generate_surface(dev):
     y = {"cond_embed": inp["cond_embed"].to(dev), "scale": torch.full((2,), 10.0, device=dev)}
     direct = d.ddim_sample_loop(cfg, (2, 256, 1, 64), clip_denoised=False, model_kwargs={"y": y}).cpu().numpy() * 2.0 + 0.5
     assert np.allclose(res["motions"][:2], direct, rtol=1e-5, atol=1e-5)
+
+
+def test_weight_updates_are_picked_up(dev):
+    """The device copy of the weights follows the module's parameters like a plain nn.Module would: in-place updates under
+    no_grad / load_state_dict (version counters), `.to()` re-seating (`_apply`), and the explicit `invalidate_weights()`."""
+    spec = face_spec(num_layers=1)
+    model, _ = create_model_and_diffusion(default_args("face", layers=1), "test", precision="fp32", max_batch=1)
+    sd = synthetic_state_dict(spec, 7)
+    load_model(model, sd)
+    model = model.to(dev).eval()
+    inp = synthetic_inputs(spec, 1, 64, SEED)
+    y = y_for(spec, inp, dev, 10.0)
+    x, t = inp["x_T"].to(dev), torch.tensor([100], device=dev)
+    base = model(x, t, y).clone()
+    assert torch.equal(model(x, t, y), base)
+    with torch.no_grad():
+        model.final_layer.bias.add_(1.0)
+    assert torch.allclose(model(x, t, y), base + 1.0, atol=1e-5)
+    sd2 = {k: v.clone() for k, v in sd.items()}
+    sd2["final_layer.bias"] = sd["final_layer.bias"] - 2.0
+    load_model(model, sd2)
+    assert torch.allclose(model(x, t, y), base - 2.0, atol=1e-5)
+    model.final_layer.bias.data.copy_(sd["final_layer.bias"].to(dev))     # bypasses the version counter ...
+    model.invalidate_weights()                                             # ... so the caller says so
+    assert torch.allclose(model(x, t, y), base, atol=1e-5)
