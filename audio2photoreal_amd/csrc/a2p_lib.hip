@@ -59,29 +59,76 @@ static void set_err(const char* fmt, ...) {
 struct Buf {
   void* p = nullptr;
   size_t bytes = 0;
+  bool pooled = false;  // carved from the context's arena: released with it, not individually
   float* f() const { return reinterpret_cast<float*>(p); }
 };
 
-static int buf_alloc(Buf& b, size_t bytes) {
-  if (b.p) {
-    hipFree(b.p);
-    b.p = nullptr;
-  }
+// Device memory of a context comes from a few 512 MiB slabs instead of ~700 individual hipMallocs (one per parameter,
+// per packed copy, per workspace): one contiguous range per context, context creation ~10x fewer driver calls.
+// (Measured: no effect on kernel time -- A2P_NO_ARENA=1 restores per-buffer hipMalloc for A/B runs.)
+struct Arena {
+  std::vector<void*> slabs;
+  char* cur = nullptr;
+  size_t left = 0;
+  static constexpr size_t kSlab = (size_t)512 << 20;
+};
+static thread_local Arena* g_arena = nullptr;  // set while a context allocates its long-lived buffers
+
+static int buf_alloc_tmp(Buf& b, size_t bytes) {  // short-lived scratch of the unit / setup entry points
+  if (b.p && !b.pooled) (void)hipFree(b.p);
+  b.p = nullptr;
   if (bytes == 0) bytes = 16;
   HIPCHK(hipMalloc(&b.p, bytes));
   HIPCHK(hipMemset(b.p, 0, bytes));
   b.bytes = bytes;
+  b.pooled = false;
+  return 0;
+}
+static int buf_alloc(Buf& b, size_t bytes) {
+  Arena* a = g_arena;
+  if (!a) return buf_alloc_tmp(b, bytes);
+  if (bytes == 0) bytes = 16;
+  if (b.p && b.pooled && b.bytes >= bytes) {  // re-finalisation after a weight update: same slot
+    HIPCHK(hipMemset(b.p, 0, bytes));
+    return 0;
+  }
+  if (b.p && !b.pooled) (void)hipFree(b.p);
+  const size_t align = bytes >= ((size_t)2 << 20) ? ((size_t)2 << 20) : 256;
+  size_t pad = (align - (reinterpret_cast<uintptr_t>(a->cur) & (align - 1))) & (align - 1);
+  if (!a->cur || pad + bytes > a->left) {
+    const size_t slab = bytes + align > Arena::kSlab ? bytes + align : Arena::kSlab;
+    void* p = nullptr;
+    HIPCHK(hipMalloc(&p, slab));
+    a->slabs.push_back(p);
+    a->cur = reinterpret_cast<char*>(p);
+    a->left = slab;
+    pad = (align - (reinterpret_cast<uintptr_t>(a->cur) & (align - 1))) & (align - 1);
+  }
+  b.p = a->cur + pad;
+  a->cur += pad + bytes;
+  a->left -= pad + bytes;
+  HIPCHK(hipMemset(b.p, 0, bytes));
+  b.bytes = bytes;
+  b.pooled = true;
   return 0;
 }
 static void buf_free(Buf& b) {
-  if (b.p) hipFree(b.p);
+  if (b.p && !b.pooled) (void)hipFree(b.p);
   b.p = nullptr;
   b.bytes = 0;
+  b.pooled = false;
 }
+struct ArenaScope {  // RAII: route buf_alloc to a context's arena for the duration of an entry point
+  Arena* prev;
+  explicit ArenaScope(Arena* a) : prev(g_arena) { g_arena = a; }
+  ~ArenaScope() { g_arena = prev; }
+};
 static inline int rup(int v, int m) { return (v + m - 1) / m * m; }
 
 struct a2p_ctx {
   a2p_config cfg;
+  Arena arena;
+  bool use_arena = true;
   int d, H, DH, L, C, Cpad, ff, F, Fc, FcPad, Kd, KdPad, Tmax, Tld, S0max, Sld, Bmax, Nmax, KFmax;
   bool bf16, pose;
   size_t esz;
@@ -333,6 +380,8 @@ extern "C" int a2p_ctx_create(const a2p_config* cfg, a2p_ctx** out) {
   ARG(cfg->precision == A2P_PREC_F32 || cfg->precision == A2P_PREC_BF16, "bad precision");
   a2p_ctx* c = new a2p_ctx();
   c->cfg = *cfg;
+  c->use_arena = !getenv("A2P_NO_ARENA");
+  ArenaScope scope(c->use_arena ? &c->arena : nullptr);
   c->d = cfg->latent_dim; c->H = cfg->num_heads; c->DH = dh; c->L = cfg->num_layers; c->C = cfg->nfeats;
   c->Cpad = rup(cfg->nfeats, 64); c->ff = cfg->ff_size; c->pose = cfg->data_format == A2P_POSE; c->F = c->pose ? 4 : 3;
   c->Fc = cfg->cond_feature_dim; c->FcPad = rup(c->Fc, 64); c->Kd = cfg->keyframe_dim; c->KdPad = rup(c->Kd, 64);
@@ -399,6 +448,7 @@ extern "C" int a2p_ctx_destroy(a2p_ctx* c) {
   for (int i = 0; i < 7; ++i) buf_free(c->conv_wt[i]);
   for (auto& b : c->ch_stream) buf_free(b);
   for (auto& b : c->ch_aux) buf_free(b);
+  for (void* slab : c->arena.slabs) (void)hipFree(slab);
   if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
   if (c->ev_join) (void)hipEventDestroy(c->ev_join);
   if (c->side) (void)hipStreamDestroy(c->side);
@@ -426,7 +476,8 @@ extern "C" int a2p_set_weight(a2p_ctx* c, const char* name, const float* data, i
     return A2P_ERR_NOWEIGHT;
   }
   Buf& b = c->w[n];
-  CHK(buf_alloc(b, (size_t)numel * 4));
+  ArenaScope scope(c->use_arena && !b.p ? &c->arena : nullptr);  // re-uploads reuse the slot (same size by contract)
+  if (!b.p) CHK(buf_alloc(b, (size_t)numel * 4));
   HIPCHK(hipMemcpyAsync(b.p, data, (size_t)numel * 4, hipMemcpyDefault, (hipStream_t)stream));
   c->finalized = false;
   c->prepared = false;
@@ -457,6 +508,7 @@ static int chain_build_streams(a2p_ctx* c, hipStream_t s);
 
 extern "C" int a2p_finalize_weights(a2p_ctx* c, void* stream) {
   ARG(c, "null ctx");
+  ArenaScope scope(c->use_arena ? &c->arena : nullptr);
   hipStream_t s = (hipStream_t)stream;
   std::map<std::string, int64_t> e;
   expected_weights(c, e);
@@ -471,7 +523,7 @@ extern "C" int a2p_finalize_weights(a2p_ctx* c, void* stream) {
     std::vector<float> fr(d / 2);
     for (int i = 0; i < d / 2; ++i) fr[i] = 1.0f / powf(10000.0f, (float)(2 * i) / (float)d);
     Buf tmp;
-    CHK(buf_alloc(tmp, fr.size() * 4));
+    CHK(buf_alloc_tmp(tmp, fr.size() * 4));
     HIPCHK(hipMemcpy(tmp.p, fr.data(), fr.size() * 4, hipMemcpyHostToDevice));
     const int npos = c->Sld > c->Tld ? c->Sld : c->Tld;
     CHK(buf_alloc(c->rope_cs, (size_t)npos * (d / 2) * 8));
@@ -509,7 +561,7 @@ extern "C" int a2p_finalize_weights(a2p_ctx* c, void* stream) {
   CHK(buf_alloc(c->cak_b, (size_t)L * d * 4)); CHK(buf_alloc(c->cav_b, (size_t)L * d * 4));
   Buf ca2k32, ca2v32;
   if (c->pose) {
-    CHK(buf_alloc(ca2k32, (size_t)L * d * d * 4)); CHK(buf_alloc(ca2v32, (size_t)L * d * d * 4));
+    CHK(buf_alloc_tmp(ca2k32, (size_t)L * d * d * 4)); CHK(buf_alloc_tmp(ca2v32, (size_t)L * d * d * 4));
     CHK(buf_alloc(c->ca2k_b, (size_t)L * d * 4)); CHK(buf_alloc(c->ca2v_b, (size_t)L * d * 4));
   }
   auto d2d = [&](void* dst, const void* src, size_t bytes) { return hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, s); };

@@ -116,7 +116,7 @@ static int chain_pack(a2p_ctx* c, int idx, const std::vector<ChainPackDesc>& des
   const size_t pad = 8;  // the prefetch runs up to NS-1 (<= 5) stages past the end
   CHK(buf_alloc(st, (descs.size() + pad) * CHAIN_STAGE_ELEMS * 2));
   Buf dd;
-  CHK(buf_alloc(dd, descs.size() * sizeof(ChainPackDesc)));
+  CHK(buf_alloc_tmp(dd, descs.size() * sizeof(ChainPackDesc)));
   HIPCHK(hipMemcpyAsync(dd.p, descs.data(), descs.size() * sizeof(ChainPackDesc), hipMemcpyHostToDevice, s));
   chain_pack_kernel<<<(int)descs.size(), 256, 0, s>>>(reinterpret_cast<const ChainPackDesc*>(dd.p), reinterpret_cast<bf16_t*>(st.p));
   HIPCHK(hipGetLastError());
@@ -135,10 +135,10 @@ static int chain_pack(a2p_ctx* c, int idx, const std::vector<ChainPackDesc>& des
 // pre-pack every chain's weight stream in consumption order (called from a2p_finalize_weights)
 static int chain_build_streams(a2p_ctx* c, hipStream_t s) {
   const int d = c->d, ff = c->ff, L = c->L;
-  for (auto& b : c->ch_stream) buf_free(b);
-  for (auto& b : c->ch_aux) buf_free(b);
-  c->ch_stream.assign((size_t)L * 4, Buf());
-  c->ch_aux.assign((size_t)L * 4, Buf());
+  if (c->ch_stream.size() != (size_t)L * 4) {  // first build; later builds (weight updates) refill the same buffers
+    c->ch_stream.assign((size_t)L * 4, Buf());
+    c->ch_aux.assign((size_t)L * 4, Buf());
+  }
   auto pf = [&](int l) { return "seqTransDecoder.stack." + std::to_string(l) + "."; };
   auto add_pre = [&](std::vector<ChainPackDesc>& v, int l) {  // [Q|K] then V of layer l's self attention
     const Buf& inw = c->wt.at(pf(l) + "self_attn.in_proj_weight");
@@ -628,8 +628,8 @@ extern "C" int a2p_gemm(a2p_ctx* c, const float* A, const float* W, const float*
   hipStream_t s = (hipStream_t)stream;
   const int kp = rup(K, 64);
   Buf a, w;
-  CHK(buf_alloc(a, (size_t)M * kp * c->esz));
-  CHK(buf_alloc(w, (size_t)N * kp * c->esz));
+  CHK(buf_alloc_tmp(a, (size_t)M * kp * c->esz));
+  CHK(buf_alloc_tmp(w, (size_t)N * kp * c->esz));
   CHK(launch_cast(c, A, K, a.p, kp, M, K, kp, nullptr, s));
   CHK(launch_cast(c, W, K, w.p, kp, N, K, kp, nullptr, s));
   GemmP p = gemm_base(a.p, kp, w.p, kp, bias, C, N, M, N, kp);
@@ -662,10 +662,10 @@ extern "C" int a2p_attention(a2p_ctx* c, const float* q, const float* k, const f
   hipStream_t s = (hipStream_t)stream;
   const int d = c->d, Sld = rup(S, 64);
   Buf qb, kb, vb, ob;
-  CHK(buf_alloc(qb, (size_t)N * Tq * d * c->esz));
-  CHK(buf_alloc(kb, ((size_t)N * Sld + 64) * d * c->esz));
-  CHK(buf_alloc(vb, (size_t)N * d * Sld * c->esz));
-  CHK(buf_alloc(ob, (size_t)N * Tq * d * c->esz));
+  CHK(buf_alloc_tmp(qb, (size_t)N * Tq * d * c->esz));
+  CHK(buf_alloc_tmp(kb, ((size_t)N * Sld + 64) * d * c->esz));
+  CHK(buf_alloc_tmp(vb, (size_t)N * d * Sld * c->esz));
+  CHK(buf_alloc_tmp(ob, (size_t)N * Tq * d * c->esz));
   CHK(launch_cast(c, q, d, qb.p, d, (int64_t)N * Tq, d, d, nullptr, s));
   for (int n = 0; n < N; ++n)
     CHK(launch_cast(c, k + (size_t)n * S * d, d, c->offT(kb, (int64_t)n * Sld * d), d, S, d, d, nullptr, s));
@@ -709,10 +709,10 @@ extern "C" int a2p_decoder_layer_forward(a2p_ctx* c, int32_t layer, float* x, co
   const int d = c->d, F = c->F, Sld = rup(S, 64);
   const std::string p = "seqTransDecoder.stack." + std::to_string(layer) + ".";
   Buf kb, vb, k2b, v2b, mtb, flm;
-  CHK(buf_alloc(kb, ((size_t)N * Sld + 64) * d * c->esz));
-  CHK(buf_alloc(vb, (size_t)N * d * Sld * c->esz));
-  CHK(buf_alloc(mtb, (size_t)N * d * 4));
-  CHK(buf_alloc(flm, (size_t)N * F * 2 * d * 4));
+  CHK(buf_alloc_tmp(kb, ((size_t)N * Sld + 64) * d * c->esz));
+  CHK(buf_alloc_tmp(vb, (size_t)N * d * Sld * c->esz));
+  CHK(buf_alloc_tmp(mtb, (size_t)N * d * 4));
+  CHK(buf_alloc_tmp(flm, (size_t)N * F * 2 * d * 4));
   // K = rot(mem) Wk + bk ; V^T = (mem Wv + bv)^T   for this layer
   auto kvproj = [&](const float* mem, int len, int ld_rows, const std::string& an, Buf& kdst, Buf& vdst) -> int {
     CHK(launch_ln_rope(c, false, mem, d, nullptr, nullptr, c->xn.p, c->xr.p, d, N * len, len, 0, s));
@@ -733,8 +733,8 @@ extern "C" int a2p_decoder_layer_forward(a2p_ctx* c, int32_t layer, float* x, co
   kv.K = kb.p; kv.k_slot_stride = (int64_t)Sld * d; kv.ldk = d; kv.VT = vb.p; kv.vt_slot_stride = (int64_t)d * Sld; kv.ldvt = Sld;
   kv.S_main = S;
   if (memory2) {
-    CHK(buf_alloc(k2b, ((size_t)N * 64 + 64) * d * c->esz));
-    CHK(buf_alloc(v2b, (size_t)N * d * 64 * c->esz));
+    CHK(buf_alloc_tmp(k2b, ((size_t)N * 64 + 64) * d * c->esz));
+    CHK(buf_alloc_tmp(v2b, (size_t)N * d * 64 * c->esz));
     CHK(kvproj(memory2, S2, 64, "multihead_attn2", k2b, v2b));
     kv2.K = k2b.p; kv2.k_slot_stride = (int64_t)64 * d; kv2.ldk = d; kv2.VT = v2b.p; kv2.vt_slot_stride = (int64_t)d * 64; kv2.ldvt = 64;
     kv2.S_main = S2;
