@@ -68,12 +68,22 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     assert world == a.gpus, f"--gpus {a.gpus} but WORLD_SIZE={world}"
     assert torch.cuda.is_available(), "bench.py needs an MI355X (the product has no CPU path)"
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # test hooks (single-GPU boxes): A2P_BENCH_SHARE_GPU=1 maps every rank to cuda:0 and A2P_BENCH_BACKEND=gloo carries the
+    # three collectives (barrier, max-reduce of the time, final gather) over host memory, so the N>1 control flow can be
+    # exercised without N GPUs.  Production: one rank per GPU, backend "nccl" (= RCCL over xGMI on ROCm).
+    share = bool(os.environ.get("A2P_BENCH_SHARE_GPU"))
+    backend = os.environ.get("A2P_BENCH_BACKEND", "nccl")
+    dev_index = 0 if share else local_rank
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
+    coll_dev = dev if backend == "nccl" else torch.device("cpu")
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)   # nccl == RCCL on ROCm
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)   # nccl == RCCL on ROCm
+        else:
+            dist.init_process_group(backend)
 
     import __graft_entry__ as ge
     if rank == 0:
@@ -140,7 +150,7 @@ def main():
         barrier()
         dt = time.perf_counter() - t0
     if world > 1:
-        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+        tt = torch.tensor([dt], device=coll_dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
     assert torch.isfinite(state["x"]).all(), "non-finite samples"
@@ -148,10 +158,11 @@ def main():
     # ---- single end-of-run gather of the samples over RCCL/xGMI (outside the timed region) ----
     gather_ms = None
     if world > 1:
-        outs = [torch.empty_like(state["x"]) for _ in range(world)]
+        mine = state["x"].contiguous().to(coll_dev)
+        outs = [torch.empty_like(mine) for _ in range(world)]
         barrier()
         t0 = time.perf_counter()
-        dist.all_gather(outs, state["x"].contiguous())
+        dist.all_gather(outs, mine)
         torch.cuda.synchronize()
         gather_ms = (time.perf_counter() - t0) * 1e3
 

@@ -1,0 +1,3 @@
+R=$GRAFT_REPO_ROOT
+cd $R
+A2P_BENCH_SHARE_GPU=1 A2P_BENCH_BACKEND=gloo timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29511 bench.py --gpus 2 --steps 10 --warmup 3 --no-cpu-baseline 2>&1 | tail -3
