@@ -251,14 +251,38 @@ __global__ __launch_bounds__(256, 1) void chain_kernel(const ChainP p) {
 #pragma unroll
       for (int j = 0; j < 2; ++j) acc[mt][j] = f32x4{0.f, 0.f, 0.f, 0.f};
   };
+  // Per-tile bias reads from the LDS aux block go through inline asm: a compiler-visible ds_read at a runtime offset makes
+  // hipcc emit s_waitcnt vmcnt(0) first (it cannot prove the read does not alias a pending LDS-DMA slice), which drained
+  // the weight ring once per tile -- ~1 us x 20 tiles per POST kernel.  The aux block was written before the kernel's
+  // first barrier, so no DMA ever targets it again.
+  auto lds_off = [&](const float* q) __attribute__((always_inline)) {
+    return (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) float*)q;
+  };
   // accumulators start at the per-column bias held in the LDS aux block
   auto init_bias = [&](f32x4(&acc)[MT][2], const float* bias_lds) __attribute__((always_inline)) {
+    f32x4 b[2];
+    asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %2 offset:64\n\ts_waitcnt lgkmcnt(0)"
+                 : "=&v"(b[0]), "=&v"(b[1])
+                 : "v"(lds_off(bias_lds + wid * 32 + g * 4))
+                 : "memory");
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      const float4 b = *reinterpret_cast<const float4*>(bias_lds + wid * 32 + j * 16 + g * 4);
+    for (int j = 0; j < 2; ++j)
 #pragma unroll
-      for (int mt = 0; mt < MT; ++mt) acc[mt][j] = f32x4{b.x, b.y, b.z, b.w};
-    }
+      for (int mt = 0; mt < MT; ++mt) acc[mt][j] = b[j];
+  };
+  // same for the swapped (D = C) orientation: one bias value per lane column n = j*16 + l15
+  auto init_bias_t = [&](f32x4(&acc)[MT][2], const float* bias_lds) __attribute__((always_inline)) {
+    float b[2];
+    asm volatile("ds_read_b32 %0, %2\n\tds_read_b32 %1, %2 offset:64\n\ts_waitcnt lgkmcnt(0)"
+                 : "=&v"(b[0]), "=&v"(b[1])
+                 : "v"(lds_off(bias_lds + wid * 32 + l15))
+                 : "memory");
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) acc[mt][j] = f32x4{b[j], b[j], b[j], b[j]};
   };
   // column of sub-tile (tile t, half j) for this lane
   auto col_of = [&](int t, int j) __attribute__((always_inline)) { return t * 128 + wid * 32 + j * 16 + g * 4; };
@@ -297,29 +321,42 @@ __global__ __launch_bounds__(256, 1) void chain_kernel(const ChainP p) {
   chain_bar();  // ... and for every other wave
 
   // ---- epilogue helpers ---------------------------------------------------------------------------------------
-  // FiLM affine + residual (transformer_modules.py:122-124,193): x += (scale + 1) * (acc + bias) + shift
+  // FiLM affine + residual (transformer_modules.py:122-124,193): x += (scale + 1) * (acc + bias) + shift.
+  // All operands of a tile are fetched in one batch BEFORE the arithmetic, and `film != NULL` is tested once per tile:
+  // a per-element "if (film) load" made hipcc branch around every load and wait for each one separately
+  // (24 dependent L2 round trips per tile, cdna_hip_programming.md §5 "three .s-level traps" (c)).
   auto film_res = [&](f32x4(&acc)[MT][2], int t, const float* bias, const float* film) __attribute__((always_inline)) {
+    f32x4 b[2];
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      const int n = col_of(t, j);
-      const float4 b = *reinterpret_cast<const float4*>(bias + n);
+    for (int j = 0; j < 2; ++j) b[j] = *reinterpret_cast<const f32x4*>(bias + col_of(t, j));
+    if (film) {
+      f32x4 sc[2][MT], sh[2][MT];
 #pragma unroll
-      for (int mt = 0; mt < MT; ++mt) {
-        f32x4 v = acc[mt][j];
-        v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
-        f32x4& xr = xrow[mt][t * 2 + j];
-        if (film) {
-          const float* fp = film + (int64_t)row_seq[mt] * p.film_seq_stride + n;
-          const float4 sc = *reinterpret_cast<const float4*>(fp);
-          const float4 sh = *reinterpret_cast<const float4*>(fp + p.film_shift_off);
-          xr[0] += (sc.x + 1.0f) * v[0] + sh.x;
-          xr[1] += (sc.y + 1.0f) * v[1] + sh.y;
-          xr[2] += (sc.z + 1.0f) * v[2] + sh.z;
-          xr[3] += (sc.w + 1.0f) * v[3] + sh.w;
-        } else {
-          xr[0] += v[0]; xr[1] += v[1]; xr[2] += v[2]; xr[3] += v[3];
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+          const float* fp = film + (int64_t)row_seq[mt] * p.film_seq_stride + col_of(t, j);
+          sc[j][mt] = *reinterpret_cast<const f32x4*>(fp);
+          sh[j][mt] = *reinterpret_cast<const f32x4*>(fp + p.film_shift_off);
         }
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        asm volatile("" : "+v"(b[j]));
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) asm volatile("" : "+v"(sc[j][mt]), "+v"(sh[j][mt]));
       }
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+          f32x4& xr = xrow[mt][t * 2 + j];
+          xr += (sc[j][mt] + 1.0f) * (acc[mt][j] + b[j]) + sh[j][mt];
+        }
+    } else {
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) xrow[mt][t * 2 + j] += acc[mt][j] + b[j];
     }
   };
   // LayerNorm statistics of the register rows (eps 1e-5, biased variance, two-pass like ln_rope_kernel)
@@ -359,24 +396,47 @@ __global__ __launch_bounds__(256, 1) void chain_kernel(const ChainP p) {
       ln_rstd[mt] = 1.0f / sqrtf(var + 1e-5f);
     }
   };
-  // normalised (optionally rotated, rotary_embedding_torch.py:46-66) rows -> bf16 A panel
-  auto ln_write = [&](const float* gamma, const float* beta, bool rope) __attribute__((always_inline)) {
+  // normalised (optionally rotated, rotary_embedding_torch.py:46-66) rows -> bf16 A panel.
+  // All global operands (gamma, beta, the rows' cos/sin entries) are fetched in ONE batch and pinned before the arithmetic:
+  // left alone, hipcc sinks each load next to its use and waits for it there -- 24+ dependent L2 round trips per call.
+  auto ln_write = [&](const float* gamma, const float* beta, auto rope_c) __attribute__((always_inline)) {
+    constexpr bool ROPE = decltype(rope_c)::value;
+    f32x4 ga[NSUB], be[NSUB];
+    f32x4 cs[ROPE ? MT : 1][ROPE ? NSUB : 1];
 #pragma unroll
     for (int ns = 0; ns < NSUB; ++ns) {
       const int n = col_of(ns >> 1, ns & 1);
-      const float4 ga = *reinterpret_cast<const float4*>(gamma + n);
-      const float4 be = *reinterpret_cast<const float4*>(beta + n);
+      ga[ns] = *reinterpret_cast<const f32x4*>(gamma + n);
+      be[ns] = *reinterpret_cast<const f32x4*>(beta + n);
+      if constexpr (ROPE) {
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+          const int pos = row_m[mt] - row_seq[mt] * p.rows_per_seq;
+          cs[mt][ns] = *reinterpret_cast<const f32x4*>(p.cs + (int64_t)pos * (D / 2) + (n >> 1));  // (cos,sin) x 2
+        }
+      }
+    }
+#pragma unroll
+    for (int ns = 0; ns < NSUB; ++ns) {
+      asm volatile("" : "+v"(ga[ns]), "+v"(be[ns]));
+      if constexpr (ROPE) {
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) asm volatile("" : "+v"(cs[mt][ns]));
+      }
+    }
+#pragma unroll
+    for (int ns = 0; ns < NSUB; ++ns) {
+      const int n = col_of(ns >> 1, ns & 1);
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt) {
-        float v0 = (xrow[mt][ns][0] - ln_mean[mt]) * ln_rstd[mt] * ga.x + be.x;
-        float v1 = (xrow[mt][ns][1] - ln_mean[mt]) * ln_rstd[mt] * ga.y + be.y;
-        float v2 = (xrow[mt][ns][2] - ln_mean[mt]) * ln_rstd[mt] * ga.z + be.z;
-        float v3 = (xrow[mt][ns][3] - ln_mean[mt]) * ln_rstd[mt] * ga.w + be.w;
-        if (rope) {
-          const int pos = row_m[mt] - row_seq[mt] * p.rows_per_seq;
-          const float4 t = *reinterpret_cast<const float4*>(p.cs + (int64_t)pos * (D / 2) + (n >> 1));  // (cos,sin) x 2
-          const float r0 = v0 * t.x - v1 * t.y, r1 = v1 * t.x + v0 * t.y;
-          const float r2 = v2 * t.z - v3 * t.w, r3 = v3 * t.z + v2 * t.w;
+        float v0 = (xrow[mt][ns][0] - ln_mean[mt]) * ln_rstd[mt] * ga[ns][0] + be[ns][0];
+        float v1 = (xrow[mt][ns][1] - ln_mean[mt]) * ln_rstd[mt] * ga[ns][1] + be[ns][1];
+        float v2 = (xrow[mt][ns][2] - ln_mean[mt]) * ln_rstd[mt] * ga[ns][2] + be[ns][2];
+        float v3 = (xrow[mt][ns][3] - ln_mean[mt]) * ln_rstd[mt] * ga[ns][3] + be[ns][3];
+        if constexpr (ROPE) {
+          const f32x4 t = cs[mt][ns];
+          const float r0 = v0 * t[0] - v1 * t[1], r1 = v1 * t[0] + v0 * t[1];
+          const float r2 = v2 * t[2] - v3 * t[3], r3 = v3 * t[2] + v2 * t[3];
           v0 = r0; v1 = r1; v2 = r2; v3 = r3;
         }
         const bf16x4 o = {(bf16_t)v0, (bf16_t)v1, (bf16_t)v2, (bf16_t)v3};
@@ -400,16 +460,8 @@ __global__ __launch_bounds__(256, 1) void chain_kernel(const ChainP p) {
   auto gemm_store = [&](int ntiles, const float* bias_lds, bf16_t* out, int64_t ldo, bool transposed) __attribute__((always_inline)) {
     for (int t = 0; t < ntiles; ++t) {
       f32x4 acc[MT][2];
-      if (!transposed) {
-        init_bias(acc, bias_lds + t * 128);
-      } else {
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-          const float b = bias_lds[t * 128 + wid * 32 + j * 16 + l15];
-#pragma unroll
-          for (int mt = 0; mt < MT; ++mt) acc[mt][j] = f32x4{b, b, b, b};
-        }
-      }
+      if (!transposed) init_bias(acc, bias_lds + t * 128);
+      else init_bias_t(acc, bias_lds + t * 128);
       gemm_tile(acc, panelA, D, KS, transposed);
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
@@ -437,10 +489,10 @@ __global__ __launch_bounds__(256, 1) void chain_kernel(const ChainP p) {
   // norm1 -> rotary -> [Q|K] ; norm1 -> V^T          (aux: bias_qk at aq, bias_v right after)
   auto pre_work = [&](const float* aq) __attribute__((always_inline)) {
     ln_stats();
-    ln_write(p.lnB_g, p.lnB_b, true);
+    ln_write(p.lnB_g, p.lnB_b, std::true_type{});
     gemm_store(2 * NT, aq, p.qk_out, p.ld_qk, false);
     chain_bar();  // every wave is done reading the rotated panel
-    ln_write(p.lnB_g, p.lnB_b, false);
+    ln_write(p.lnB_g, p.lnB_b, std::false_type{});
     gemm_store(NT, aq + 2 * D, p.vt_out, p.ld_vt, true);
   };
 
@@ -462,10 +514,10 @@ __global__ __launch_bounds__(256, 1) void chain_kernel(const ChainP p) {
     ln_stats();
     if constexpr (MODE == CHAIN_MID) {
       store_x();
-      ln_write(p.lnA_g, p.lnA_b, true);
+      ln_write(p.lnA_g, p.lnA_b, std::true_type{});
       gemm_store(NT, aux, p.q_out, p.ld_q, false);
     } else {
-      ln_write(p.lnA_g, p.lnA_b, false);
+      ln_write(p.lnA_g, p.lnA_b, std::false_type{});
       // feed forward, split-K over the 8 hidden chunks: linear1 chunk -> GELU -> LDS -> linear2 partial
       f32x4 facc[NT][MT][2];
 #pragma unroll

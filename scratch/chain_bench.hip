@@ -1,6 +1,7 @@
 // Ablation bench of the chain kernels on synthetic buffers (scratch; not product).
 // hipcc --offload-arch=gfx950 -O3 -std=c++17 scratch/chain_bench.hip -o scratch/chain_bench
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -19,14 +20,31 @@ float time_it(F f, int iters = 10) {
   float ms; CK(hipEventElapsedTime(&ms, e0, e1));
   return ms / iters * 1e3f;
 }
+static int g_thrash = 0;  // 1: read a 512 MiB buffer between launches (evicts L2 and the 256 MiB MALL like the K/V caches do)
+static uint4* g_tbuf = nullptr;
+static uint4* g_tout = nullptr;
+__global__ void thrash_kernel(const uint4* __restrict__ p, size_t n_per_block, uint4* out) {
+  uint4 acc = make_uint4(0, 0, 0, 0);
+  const uint4* q = p + (size_t)blockIdx.x * n_per_block;
+  for (size_t i = threadIdx.x; i < n_per_block; i += blockDim.x) { uint4 v = q[i]; acc.x ^= v.x; acc.y ^= v.y; }
+  if (acc.x == 0x12345678) out[0] = acc;
+}
 static int g_cycle = 1;  // number of distinct weight streams cycled through (1 = always L2-hot)
 template <int MT, int MODE, int ABL>
 void run(const char* name, ChainP p, int stages) {
   const int grid = (p.M + 16 * MT - 1) / (16 * MT);
-  int it = 0;
   const bf16_t* base = p.stream;
-  float us = time_it([&] { p.stream = base + (size_t)(it++ % g_cycle) * (256 + 8) * 8192; chain_kernel<512, MT, MODE, ABL><<<grid, 256>>>(p); });
-  CK(hipDeviceSynchronize());
+  hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+  double tot = 0; const int iters = 8;
+  for (int it = 0; it < iters + 2; ++it) {
+    p.stream = base + (size_t)(it % g_cycle) * (256 + 8) * 8192;
+    if (g_thrash) thrash_kernel<<<2048, 256>>>(g_tbuf, ((size_t)512 << 20) / 16 / 2048, g_tout);
+    hipExtLaunchKernelGGL((chain_kernel<512, MT, MODE, ABL>), dim3(grid), dim3(256), 0, 0, e0, e1, 0, p);
+    CK(hipEventSynchronize(e1));
+    float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+    if (it >= 2) tot += ms;
+  }
+  const float us = tot / iters * 1e3;
   printf("  MT=%d mode=%d abl=%2d %-28s %8.1f us  (%d blocks, %.3f us/stage)\n", MT, MODE, ABL, name, us, grid, us / stages / ((grid + 255) / 256));
 }
 template <int MT>
@@ -60,10 +78,11 @@ int main(int argc, char** argv) {
     p.bias_o = vec; p.film_o = film; p.film_seq_stride = 4 * D; p.film_shift_off = D; p.lnA_g = vec + 512; p.lnA_b = vec + 1024;
     p.q_out = qk; p.ld_q = D; p.bias_2 = vec + 1536; p.film_f = film + 2 * D; p.lnB_g = vec + 2048; p.lnB_b = vec + 2560;
     p.qk_out = qk; p.ld_qk = 2 * D; p.vt_out = vt; p.vt_seq_stride = (int64_t)D * 640; p.ld_vt = 640; p.cs = cs;
-    for (int cyc : {1, 16}) {
-      g_cycle = cyc;
-      printf("M=%d weight streams cycled=%d\n", M, cyc);
-      all<2>(p); all<3>(p); all<4>(p);
+    CK(hipMalloc(&g_tbuf, (size_t)512 << 20)); CK(hipMalloc(&g_tout, 64)); CK(hipMemset(g_tbuf, 1, (size_t)512 << 20));
+    for (int th : {0, 1}) {
+      g_cycle = 16; g_thrash = th;
+      printf("M=%d weight streams cycled=16, MALL/L2 thrash between launches=%d\n", M, th);
+      all<3>(p);
     }
   }
   return 0;
