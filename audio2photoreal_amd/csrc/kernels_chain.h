@@ -105,16 +105,21 @@ __device__ __forceinline__ void chain_glds16(const void* gsrc, void* lds_wave_ba
 #else
 #define CHAIN_NT 0
 #endif
+#ifdef CHAIN_NT_STORES   // experiment: only the output stores non-temporal (write-through: no dirty-line flush at kernel end)
+#define CHAIN_NT_ST 1
+#else
+#define CHAIN_NT_ST CHAIN_NT
+#endif
 __device__ __forceinline__ f32x4 chain_ld4(const float* p) {
   if constexpr (CHAIN_NT) return __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(p));
   else return *reinterpret_cast<const f32x4*>(p);
 }
 __device__ __forceinline__ void chain_st4(float* p, f32x4 v) {
-  if constexpr (CHAIN_NT) __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(p));
+  if constexpr (CHAIN_NT_ST) __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(p));
   else *reinterpret_cast<f32x4*>(p) = v;
 }
 __device__ __forceinline__ void chain_st_bf4(bf16_t* p, bf16x4 v) {
-  if constexpr (CHAIN_NT) __builtin_nontemporal_store(v, reinterpret_cast<bf16x4*>(p));
+  if constexpr (CHAIN_NT_ST) __builtin_nontemporal_store(v, reinterpret_cast<bf16x4*>(p));
   else *reinterpret_cast<bf16x4*>(p) = v;
 }
 
