@@ -154,7 +154,9 @@ struct a2p_ctx {
   std::vector<hipEvent_t> ev_pool;
   // side stream: the per-step time path (t -> FiLM scale/shift, time-token K/V) overlaps the first projections / self attention
   hipStream_t side = nullptr;
-  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+  hipEvent_t ev_fork_pool[8] = {}, ev_join_pool[8] = {};  // rotating pairs: an event is never re-recorded while a wait on it may be pending
+  unsigned ev_turn = 0;
+  hipEvent_t ev_fork = nullptr, ev_join = nullptr;      // the pair of the current forward
 
   void* offT(const Buf& b, int64_t elems) const { return reinterpret_cast<char*>(b.p) + elems * (int64_t)esz; }
   void* offT(void* p, int64_t elems) const { return reinterpret_cast<char*>(p) + elems * (int64_t)esz; }
@@ -419,12 +421,12 @@ extern "C" int a2p_ctx_create(const a2p_config* cfg, a2p_ctx** out) {
     A(c->kf_pack, (size_t)B * c->KFmax * c->KdPad * c->esz); A(c->kf_tok, (size_t)B * c->KFmax * d * 4);
   }
   A(c->slot_cond, B * 4); A(c->slot_unc, B * 4); A(c->slot_cfg, N * 4);
-  if (rc == 0 && (hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking) != hipSuccess ||
-                  hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) != hipSuccess ||
-                  hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming) != hipSuccess)) {
-    set_err("side stream / event creation failed");
-    rc = A2P_ERR_HIP;
-  }
+  if (rc == 0 && hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking) != hipSuccess) rc = A2P_ERR_HIP;
+  for (int i = 0; i < 8 && rc == 0; ++i)
+    if (hipEventCreateWithFlags(&c->ev_fork_pool[i], hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&c->ev_join_pool[i], hipEventDisableTiming) != hipSuccess)
+      rc = A2P_ERR_HIP;
+  if (rc == A2P_ERR_HIP) set_err("side stream / event creation failed");
   if (rc != 0) {
     a2p_ctx_destroy(c);
     return rc;
@@ -449,8 +451,10 @@ extern "C" int a2p_ctx_destroy(a2p_ctx* c) {
   for (auto& b : c->ch_stream) buf_free(b);
   for (auto& b : c->ch_aux) buf_free(b);
   for (void* slab : c->arena.slabs) (void)hipFree(slab);
-  if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
-  if (c->ev_join) (void)hipEventDestroy(c->ev_join);
+  for (int i = 0; i < 8; ++i) {
+    if (c->ev_fork_pool[i]) (void)hipEventDestroy(c->ev_fork_pool[i]);
+    if (c->ev_join_pool[i]) (void)hipEventDestroy(c->ev_join_pool[i]);
+  }
   if (c->side) (void)hipStreamDestroy(c->side);
   for (auto& e : c->evs) {
     hipEventDestroy(e.first);

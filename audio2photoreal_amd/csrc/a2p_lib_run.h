@@ -457,18 +457,26 @@ static int run_forward(a2p_ctx* c, const float* x_in, const int64_t* t_orig, int
   const int d = c->d, B = c->pB, T = c->pT, L = c->L, F = c->F;
   const int N = pass == A2P_PASS_CFG ? 2 * B : B;
   const int* slots = (const int*)(pass == A2P_PASS_CFG ? c->slot_cfg.p : (pass == A2P_PASS_COND ? c->slot_cond.p : c->slot_unc.p));
-  // chain mode: nothing before the first out_proj epilogue needs the time path, so it runs on the side stream next to
-  // input projection / norm1+QKV / self attention of layer 0 (7 latency-bound launches, ~70 us at B=8)
   // Row panels pay off once there are enough of them: every workgroup streams the whole weight set of its chain, so a
   // forward of < ~1000 rows (config 0: B=1, T=240 -> 480 rows = 10 panels) is faster as many small 2-D tiles
   // (measured: 0.99 vs 1.10 ms per step at 480 rows, equal at 1200, chain ahead from 2400 rows on).
   const bool use_chain = chain_supported(c) && ((int64_t)N * T >= 960 || getenv("A2P_CHAIN_MT"));
-  const bool overlap_tpath = use_chain && !getenv("A2P_NO_SIDE_STREAM");
+  // The time path (7 latency-bound launches, ~70 us at B=8) is not needed before the first out_proj epilogue and could run
+  // on the side stream next to input projection / norm1+QKV / self attention of layer 0 (-2 % step time).  OFF by default:
+  // with the two queues active, 1-30 % of forwards on SOME MI355X boxes came out different for one whole sample
+  // (scratch/stress2.py; never with the side stream off or joined immediately; rotating the events and replacing the
+  // hipMemcpyAsync did not help; every buffer either stream writes is private to it until the join).  Until that is
+  // understood the overlap is opt-in: A2P_SIDE_STREAM=1.
+  const bool overlap_tpath = use_chain && getenv("A2P_SIDE_STREAM") && !getenv("A2P_NO_SIDE_STREAM");
   if (overlap_tpath) {
+    c->ev_fork = c->ev_fork_pool[c->ev_turn & 7];
+    c->ev_join = c->ev_join_pool[c->ev_turn & 7];
+    ++c->ev_turn;
     HIPCHK(hipEventRecord(c->ev_fork, s));  // orders the side stream behind t_orig AND behind the previous step's readers
     HIPCHK(hipStreamWaitEvent(c->side, c->ev_fork, 0));
     CHK(time_path(c, t_orig, N, slots, c->side));
     HIPCHK(hipEventRecord(c->ev_join, c->side));
+    if (getenv("A2P_SIDE_EARLY_JOIN")) HIPCHK(hipStreamWaitEvent(s, c->ev_join, 0));  // diagnostic: side stream without overlap
   } else {
     CHK(time_path(c, t_orig, N, slots, s));
   }
@@ -481,8 +489,11 @@ static int run_forward(a2p_ctx* c, const float* x_in, const int64_t* t_orig, int
                         B * T, d, c->Cpad);
     p.out_f32 = 1;
     CHK(launch_gemm(c, p, s));
-    if (N == 2 * B)
-      HIPCHK(hipMemcpyAsync(c->x.f() + (size_t)B * T * d, c->x.p, (size_t)B * T * d * 4, hipMemcpyDeviceToDevice, s));
+    if (N == 2 * B) {
+      const int64_t n4 = (int64_t)B * T * d / 4;
+      dup_rows_kernel<<<(int)((n4 + 255) / 256), 256, 0, s>>>(reinterpret_cast<const float4*>(c->x.p),
+                                                             reinterpret_cast<float4*>(c->x.f() + (size_t)B * T * d), n4);
+    }
   }
   CrossKV kv, kv2;
   for (int l = 0; l < L; ++l) {

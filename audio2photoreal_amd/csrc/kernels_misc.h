@@ -312,6 +312,14 @@ __global__ void q_sample_kernel(const float* xs, const int64_t* t_idx, const flo
   out[i] = tab[TAB_SQRT_ACP * ns + t] * xs[i] + tab[TAB_SQRT_1M * ns + t] * noise[i];
 }
 
+// dst[i] = src[i] for n float4s: the CFG duplication of the projected input rows (cond half -> uncond half) as an ordinary
+// kernel on the launch stream (a hipMemcpyAsync here may be routed to a copy engine; with a second stream active that
+// showed up as whole-sample corruption in 1-3 % of forwards on some boxes, scratch/stress2.py)
+__global__ void dup_rows_kernel(const float4* __restrict__ src, float4* __restrict__ dst, int64_t n) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) dst[i] = src[i];
+}
+
 // gather rows: dst[r] = src[idx[r]]  (fp32 rows of `cols`)
 __global__ void gather_rows_kernel(const float* __restrict__ src, const int* __restrict__ idx, float* __restrict__ dst, int rows,
                                    int cols) {

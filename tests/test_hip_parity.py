@@ -372,3 +372,26 @@ def test_weight_updates_are_picked_up(dev):
     model.final_layer.bias.data.copy_(sd["final_layer.bias"].to(dev))     # bypasses the version counter ...
     model.invalidate_weights()                                             # ... so the caller says so
     assert torch.allclose(model(x, t, y), base, atol=1e-5)
+
+
+def test_chain_path_is_bitwise_reproducible_under_repetition(dev):
+    """Race screen for the LDS-DMA weight rings / panel hand-offs of the chain kernels: 24 repeated guided forwards at
+    the full bench size (B=8, T=600, bf16) must be bit-identical (a late DMA landing or an early fragment read shows up
+    as run-to-run differences), and a second context with the same weights must agree too."""
+    spec = face_spec()
+    sd = synthetic_state_dict(spec, SEED)
+    outs = []
+    for rep in range(2):
+        model, _ = create_model_and_diffusion(default_args("face", timestep_respacing=""), "test", precision="bf16", max_batch=8)
+        load_model(model, sd)
+        cfg = ClassifierFreeSampleModel(model.to(dev).eval())
+        inp = synthetic_inputs(spec, 8, 600, SEED)
+        y = y_for(spec, inp, dev, 10.0)
+        x = inp["x_T"].to(dev)
+        t = torch.tensor([999, 750, 500, 250, 100, 10, 1, 0], device=dev)
+        first = cfg(x, t, y).clone()
+        for i in range(11):
+            again = cfg(x, t, y)
+            assert torch.equal(again, first), f"context {rep}, repeat {i}: max |diff| = {float((again - first).abs().max()):.3e}"
+        outs.append(first)
+    assert torch.equal(outs[0], outs[1]), f"two contexts disagree: max |diff| = {float((outs[0] - outs[1]).abs().max()):.3e}"
