@@ -29,7 +29,7 @@ EXPORTS = (
     "a2p_ctx_create", "a2p_ctx_destroy", "a2p_last_error", "a2p_version", "a2p_set_weight", "a2p_finalize_weights",
     "a2p_prepare_cond", "a2p_denoise_forward", "a2p_sample_step", "a2p_p_mean_variance", "a2p_ddim_update",
     "a2p_p_sample_update", "a2p_q_sample", "a2p_decoder_layer_forward", "a2p_gemm", "a2p_attention",
-    "a2p_kernel_timing", "a2p_kernel_time_ms",
+    "a2p_kernel_timing", "a2p_kernel_time_ms", "a2p_debug_read",
 )
 
 
@@ -79,6 +79,7 @@ def load() -> C.CDLL:
         "a2p_attention": [vp, vp, vp, vp, vp, i32, i32, i32, vp],
         "a2p_kernel_timing": [vp, i32, i32],
         "a2p_kernel_time_ms": [vp, C.POINTER(C.c_double), C.POINTER(i64)],
+        "a2p_debug_read": [vp, C.c_char_p, vp, i64],
     }
     for name, args in sig.items():
         fn = getattr(lib, name)

@@ -280,13 +280,17 @@ static int decoder_layer_chain(a2p_ctx* c, int l, int N, int T, const CrossKV& k
   const int d = c->d;
   const std::string pf = "seqTransDecoder.stack." + std::to_string(l) + ".";
   ChainP p;
+  const char* jp = getenv("A2P_SIDE_JOIN");  // diagnostic: where the main stream joins the side stream (1 PRE, 2 self attention, default MID)
+  const int join_at = jp ? atoi(jp) : 3;
+  if (film_ready && join_at <= 1) HIPCHK(hipStreamWaitEvent(s, film_ready, 0));
   if (first) {
     chain_base(c, p, N, T, ch_index(l, CH_PRE), 3 * d);
     chain_set_pre(c, p, l, T);
     CHK(launch_chain(c, CHAIN_PRE, p, s));
   }
+  if (film_ready && join_at == 2) HIPCHK(hipStreamWaitEvent(s, film_ready, 0));
   CHK(launch_self_attention(c, N, T, s));
-  if (film_ready) HIPCHK(hipStreamWaitEvent(s, film_ready, 0));  // FiLM / time-token K,V of this step (side stream)
+  if (film_ready && join_at >= 3) HIPCHK(hipStreamWaitEvent(s, film_ready, 0));  // FiLM / time-token K,V of this step (side stream)
   auto mid = [&](int kind, const std::string& attn_done, int film_idx, const std::string& norm) -> int {
     chain_base(c, p, N, T, ch_index(l, kind), d);
     chain_set_out_proj(c, p, pf + attn_done, fr, film_idx);
@@ -407,7 +411,8 @@ static int time_path(a2p_ctx* c, const int64_t* t_orig, int N, const int* slots,
   tp.tct = c->tct.f(); tp.hidden = c->hidden.f(); tp.slot = slots; tp.tvec = c->tvec.f(); tp.mt = c->mt.f();
   tp.gamma = W32(c, "norm_cond.weight"); tp.beta = W32(c, "norm_cond.bias"); tp.cs = (const float2*)c->rope_cs.p;
   tp.tok_n = c->tokn.f(); tp.tok_r = c->tokr.f(); tp.B = B; tp.nseq = N; tp.d = d; tp.pos0 = c->pS0;
-  tpath_post_kernel<<<N + B, 256, 0, s>>>(tp);
+  if (d == 512) tpath_post_kernel<8><<<N + B, 256, 0, s>>>(tp);
+  else tpath_post_kernel<4><<<N + B, 256, 0, s>>>(tp);
   CHK(launch_skinny(c->mt.f(), d, c->film_w.f(), d, c->film_b.f(), c->film.f(), (int64_t)L * F * 2 * d, N, L * F * 2 * d, d, ACT_NONE, s));
   CHK(launch_skinny(c->tokr.f(), d, c->cak_w32.f(), d, c->cak_b.f(), c->ktail.f(), (int64_t)L * d, 2 * B, L * d, d, ACT_NONE, s));
   CHK(launch_skinny(c->tokn.f(), d, c->cav_w32.f(), d, c->cav_b.f(), c->vtail.f(), (int64_t)L * d, 2 * B, L * d, d, ACT_NONE, s));
@@ -764,6 +769,21 @@ extern "C" int a2p_decoder_layer_forward(a2p_ctx* c, int32_t layer, float* x, co
   hipStreamSynchronize(s);
   buf_free(kb); buf_free(vb); buf_free(k2b); buf_free(v2b); buf_free(mtb); buf_free(flm);
   return rc;
+}
+
+// ------------------------------------------------------------------------------------------------
+// debugging aid (scratch/stress*.py): copy an internal buffer to the host after a device synchronise
+// ------------------------------------------------------------------------------------------------
+extern "C" int a2p_debug_read(a2p_ctx* c, const char* name, void* host, int64_t bytes) {
+  ARG(c && name && host && bytes > 0, "bad arguments");
+  const std::string n(name);
+  const Buf* b = n == "film" ? &c->film : n == "ktail" ? &c->ktail : n == "vtail" ? &c->vtail : n == "tvec" ? &c->tvec
+               : n == "tokr" ? &c->tokr : n == "tokn" ? &c->tokn : n == "tct" ? &c->tct
+               : n == "x" ? &c->x : n == "qk" ? &c->qk : n == "vt" ? &c->vt : n == "ao" ? &c->ao : n == "mo" ? &c->mo : nullptr;
+  ARG(b && (size_t)bytes <= b->bytes, "unknown buffer '%s' or too many bytes", name);
+  HIPCHK(hipDeviceSynchronize());
+  HIPCHK(hipMemcpy(host, b->p, (size_t)bytes, hipMemcpyDeviceToHost));
+  return 0;
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -152,6 +152,7 @@ struct TPathP {
   int B, nseq, d, pos0; // pos0 = number of audio tokens (time tokens sit at pos0, pos0+1)
 };
 
+template <int NPL>  // d / 64: 8 (face) or 4 (pose) contiguous features per lane in the token part
 __global__ __launch_bounds__(256) void tpath_post_kernel(TPathP p) {
   const int d = p.d;
   const int wid = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -169,31 +170,46 @@ __global__ __launch_bounds__(256) void tpath_post_kernel(TPathP p) {
   const int b = blk - p.nseq;
   if (wid >= 2) return;
   const float* src = p.tct + (int64_t)b * 3 * d + d + wid * d;
-  const int npl = d / 64;
-  float v[8];
-  float s = 0.f;
-  for (int i = 0; i < npl; ++i) {
-    v[i] = src[lane * npl + i];
-    s += v[i];
+  const int row = b * 2 + wid, pos = p.pos0 + wid;
+  // The rotary (cos, sin) pairs are fetched first and pinned in registers: they are not consumed until after both
+  // LayerNorm reductions, so the loads have long landed by then.  (With the fetch next to its first use, the first VALU
+  // after the s_waitcnt -- a packed f32 op selecting the high dword of the returning dwordx2 -- was observed to read 0
+  // in lanes 48-63 when another stream's kernel loaded the memory system; see DESIGN.md section 6, "Reproducibility".)
+  float2 t[NPL / 2];
+#pragma unroll
+  for (int i = 0; i < NPL / 2; ++i) t[i] = p.cs[(int64_t)pos * (d / 2) + lane * (NPL / 2) + i];
+#pragma unroll
+  for (int i = 0; i < NPL / 2; ++i) asm volatile("" : "+v"(t[i].x), "+v"(t[i].y));
+  float v[NPL], g[NPL], be[NPL];
+#pragma unroll
+  for (int i = 0; i < NPL; ++i) {
+    v[i] = src[lane * NPL + i];
+    g[i] = p.gamma[lane * NPL + i];
+    be[i] = p.beta[lane * NPL + i];
   }
+#pragma unroll
+  for (int i = 0; i < NPL; ++i) asm volatile("" : "+v"(v[i]), "+v"(g[i]), "+v"(be[i]));
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < NPL; ++i) s += v[i];
   const float mean = wave_sum(s) / d;
   float q = 0.f;
-  for (int i = 0; i < npl; ++i) {
+#pragma unroll
+  for (int i = 0; i < NPL; ++i) {
     v[i] -= mean;
     q += v[i] * v[i];
   }
   const float rstd = 1.0f / sqrtf(wave_sum(q) / d + 1e-5f);
-  const int row = b * 2 + wid, pos = p.pos0 + wid;
-  for (int i = 0; i < npl; ++i) {
-    const int c = lane * npl + i;
-    v[i] = v[i] * rstd * p.gamma[c] + p.beta[c];
-    p.tok_n[(int64_t)row * d + c] = v[i];
+#pragma unroll
+  for (int i = 0; i < NPL; ++i) {
+    v[i] = v[i] * rstd * g[i] + be[i];
+    p.tok_n[(int64_t)row * d + lane * NPL + i] = v[i];
   }
-  for (int i = 0; i < npl; i += 2) {
-    const int c = lane * npl + i;
-    const float2 t = p.cs[(int64_t)pos * (d / 2) + c / 2];
-    p.tok_r[(int64_t)row * d + c] = v[i] * t.x - v[i + 1] * t.y;
-    p.tok_r[(int64_t)row * d + c + 1] = v[i + 1] * t.x + v[i] * t.y;
+#pragma unroll
+  for (int i = 0; i < NPL / 2; ++i) {
+    const int c = lane * NPL + 2 * i;
+    p.tok_r[(int64_t)row * d + c] = v[2 * i] * t[i].x - v[2 * i + 1] * t[i].y;
+    p.tok_r[(int64_t)row * d + c + 1] = v[2 * i + 1] * t[i].x + v[2 * i] * t[i].y;
   }
 }
 
