@@ -22,13 +22,14 @@ KERNEL_GEMM, KERNEL_ATTN_SELF, KERNEL_ATTN_CROSS, KERNEL_LNROPE, KERNEL_CHAIN = 
 TABLE_NAMES = (
     "posterior_mean_coef1", "posterior_mean_coef2", "posterior_variance", "posterior_log_variance_clipped",
     "sqrt_recip_alphas_cumprod", "sqrt_recipm1_alphas_cumprod", "alphas_cumprod", "alphas_cumprod_prev",
-    "sqrt_alphas_cumprod", "sqrt_one_minus_alphas_cumprod",
+    "sqrt_alphas_cumprod", "sqrt_one_minus_alphas_cumprod", "alphas_cumprod_next",
 )
+PLMS_PREDICT, PLMS_AB1, PLMS_AB2, PLMS_AB3, PLMS_AB4, PLMS_EULER = range(6)
 
 EXPORTS = (
     "a2p_ctx_create", "a2p_ctx_destroy", "a2p_last_error", "a2p_version", "a2p_set_weight", "a2p_finalize_weights",
     "a2p_prepare_cond", "a2p_denoise_forward", "a2p_sample_step", "a2p_p_mean_variance", "a2p_ddim_update",
-    "a2p_p_sample_update", "a2p_q_sample", "a2p_decoder_layer_forward", "a2p_gemm", "a2p_attention",
+    "a2p_p_sample_update", "a2p_q_sample", "a2p_eps_from_xstart", "a2p_plms_update", "a2p_ddim_reverse_update", "a2p_decoder_layer_forward", "a2p_gemm", "a2p_attention",
     "a2p_kernel_timing", "a2p_kernel_time_ms", "a2p_debug_read",
 )
 
@@ -74,6 +75,9 @@ def load() -> C.CDLL:
         "a2p_ddim_update": [vp, vp, vp, vp, i32, vp, f32, i32, i64, vp, vp],
         "a2p_p_sample_update": [vp, vp, vp, i32, vp, i32, i64, vp, vp],
         "a2p_q_sample": [vp, vp, vp, i32, vp, i32, i64, vp, vp],
+        "a2p_eps_from_xstart": [vp, vp, vp, vp, i32, i32, i64, vp, vp],
+        "a2p_plms_update": [vp, vp, vp, vp, i32, vp, vp, vp, vp, i32, i32, i64, vp, vp],
+        "a2p_ddim_reverse_update": [vp, vp, vp, vp, i32, i32, i64, vp, vp],
         "a2p_decoder_layer_forward": [vp, i32, vp, vp, vp, vp, i32, i32, i32, i32, vp],
         "a2p_gemm": [vp, vp, vp, vp, vp, i32, i32, i32, vp],
         "a2p_attention": [vp, vp, vp, vp, vp, i32, i32, i32, vp],

@@ -625,6 +625,40 @@ extern "C" int a2p_p_sample_update(const float* mean, const int64_t* t_idx, cons
   return 0;
 }
 
+extern "C" int a2p_eps_from_xstart(const float* x, const float* pred_xstart, const int64_t* t_idx, const float* tables,
+                                  int32_t n_steps, int32_t batch, int64_t per_sample, float* eps, void* stream) {
+  ARG(x && pred_xstart && t_idx && tables && eps, "null argument");
+  const int64_t total = batch * per_sample;
+  eps_from_xstart_kernel<<<(int)((total + 255) / 256), 256, 0, (hipStream_t)stream>>>(x, pred_xstart, t_idx, tables, n_steps,
+                                                                                     per_sample, total, eps);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+extern "C" int a2p_plms_update(const float* x, const float* pred_xstart, const int64_t* t_idx, const float* tables, int32_t n_steps,
+                               const float* eps0, const float* eps1, const float* eps2, const float* eps3, int32_t mode,
+                               int32_t batch, int64_t per_sample, float* sample, void* stream) {
+  ARG(x && pred_xstart && t_idx && tables && eps0 && sample, "null argument");
+  ARG(mode >= A2P_PLMS_PREDICT && mode <= A2P_PLMS_EULER, "bad PLMS mode %d", mode);
+  const int need = mode == A2P_PLMS_EULER ? 2 : mode;  // eps buffers the mode reads beyond eps0
+  ARG((need < 2 || eps1) && (need < 3 || eps2) && (need < 4 || eps3), "PLMS mode %d needs %d eps buffers", mode, need);
+  const int64_t total = batch * per_sample;
+  plms_update_kernel<<<(int)((total + 255) / 256), 256, 0, (hipStream_t)stream>>>(x, pred_xstart, t_idx, tables, n_steps, eps0, eps1,
+                                                                                 eps2, eps3, mode, per_sample, total, sample);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+extern "C" int a2p_ddim_reverse_update(const float* pred_xstart, const float* x, const int64_t* t_idx, const float* tables,
+                                       int32_t n_steps, int32_t batch, int64_t per_sample, float* sample, void* stream) {
+  ARG(pred_xstart && x && t_idx && tables && sample, "null argument");
+  const int64_t total = batch * per_sample;
+  ddim_reverse_kernel<<<(int)((total + 255) / 256), 256, 0, (hipStream_t)stream>>>(x, pred_xstart, t_idx, tables, n_steps, per_sample,
+                                                                                  total, sample);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
 extern "C" int a2p_q_sample(const float* x_start, const int64_t* t_idx, const float* tables, int32_t n_steps, const float* noise,
                             int32_t batch, int64_t per_sample, float* out, void* stream) {
   ARG(x_start && t_idx && tables && noise && out, "null argument");

@@ -223,7 +223,7 @@ __global__ void mish_kernel(const float* __restrict__ a, float* __restrict__ o, 
 // fp32 in the reference's operation order (gaussian_diffusion.py:235-257, 305-316, 347-351,
 // 470-476, 699-717).
 // ---------------------------------------------------------------------------------------------
-enum { TAB_C1 = 0, TAB_C2, TAB_VAR, TAB_LOGVAR, TAB_SRA, TAB_SRM1, TAB_ACP, TAB_ACPP, TAB_SQRT_ACP, TAB_SQRT_1M };
+enum { TAB_C1 = 0, TAB_C2, TAB_VAR, TAB_LOGVAR, TAB_SRA, TAB_SRM1, TAB_ACP, TAB_ACPP, TAB_SQRT_ACP, TAB_SQRT_1M, TAB_ACPN };
 
 __device__ __forceinline__ float ddim_update(float x0, float x, float noise, const float* tab, int ns, int t, float eta) {
   const float eps = (tab[TAB_SRA * ns + t] * x - x0) / tab[TAB_SRM1 * ns + t];
@@ -318,6 +318,52 @@ __global__ void p_sample_update_kernel(const float* mean, const int64_t* t_idx, 
   const int t = (int)t_idx[i / per];
   const float nz = t != 0 ? 1.f : 0.f;
   out[i] = mean[i] + nz * expf(0.5f * tab[TAB_LOGVAR * ns + t]) * noise[i];
+}
+
+// eps = (sqrt(1/abar_t) x_t - x0) / sqrt(1/abar_t - 1)   (gaussian_diffusion.py:347-351)
+__global__ void eps_from_xstart_kernel(const float* x, const float* x0, const int64_t* t_idx, const float* tab, int ns, int64_t per,
+                                       int64_t total, float* eps) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const int t = (int)t_idx[i / per];
+  eps[i] = (tab[TAB_SRA * ns + t] * x[i] - x0[i]) / tab[TAB_SRM1 * ns + t];
+}
+
+// Pseudo linear multistep update (gaussian_diffusion.py:990-1041).  e0 is the newest eps, e1..e3 older ones.
+//   mode 0     : Euler predictor  x0 sqrt(abar_prev) + sqrt(1 - abar_prev) e0       (fed to the model at t-1, no t==0 mask)
+//   mode 1..4  : Adams-Bashforth of that order over e0..e{mode-1}
+//   mode 5     : improved Euler corrector, eps' = (e1 + e0) / 2   (e1 = eps at t, e0 = eps at the predictor)
+__global__ void plms_update_kernel(const float* x, const float* x0, const int64_t* t_idx, const float* tab, int ns, const float* e0,
+                                   const float* e1, const float* e2, const float* e3, int mode, int64_t per, int64_t total,
+                                   float* out) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const int t = (int)t_idx[i / per];
+  const float abp = tab[TAB_ACPP * ns + t];
+  if (mode == 0) {
+    out[i] = x0[i] * sqrtf(abp) + sqrtf(1.f - abp) * e0[i];
+    return;
+  }
+  float ep;
+  if (mode == 1) ep = e0[i];
+  else if (mode == 2) ep = (3.f * e0[i] - e1[i]) / 2.f;
+  else if (mode == 3) ep = (23.f * e0[i] - 16.f * e1[i] + 5.f * e2[i]) / 12.f;
+  else if (mode == 4) ep = (55.f * e0[i] - 59.f * e1[i] + 37.f * e2[i] - 9.f * e3[i]) / 24.f;
+  else ep = (e1[i] + e0[i]) / 2.f;
+  const float pred = tab[TAB_SRA * ns + t] * x[i] - tab[TAB_SRM1 * ns + t] * ep;
+  const float mean_pred = pred * sqrtf(abp) + sqrtf(1.f - abp) * ep;
+  out[i] = t != 0 ? mean_pred : x0[i];
+}
+
+// ddim_reverse_sample, eta = 0 (gaussian_diffusion.py:760-795): x0 sqrt(abar_next) + sqrt(1 - abar_next) eps
+__global__ void ddim_reverse_kernel(const float* x, const float* x0, const int64_t* t_idx, const float* tab, int ns, int64_t per,
+                                    int64_t total, float* out) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const int t = (int)t_idx[i / per];
+  const float eps = (tab[TAB_SRA * ns + t] * x[i] - x0[i]) / tab[TAB_SRM1 * ns + t];
+  const float abn = tab[TAB_ACPN * ns + t];
+  out[i] = x0[i] * sqrtf(abn) + sqrtf(1.f - abn) * eps;
 }
 
 __global__ void q_sample_kernel(const float* xs, const int64_t* t_idx, const float* tab, int ns, const float* noise,

@@ -73,7 +73,7 @@ class LossType(enum.Enum):
 
 def _out_of_scope(name):
     def fn(self, *a, **k):
-        raise NotImplementedError(f"GaussianDiffusion.{name} is outside the accelerated sampling path (SURVEY.md §8f4)")
+        raise NotImplementedError(f"GaussianDiffusion.{name} is outside the accelerated sampling path (training / gradient guidance, SURVEY.md §2)")
     fn.__name__ = name
     return fn
 
@@ -352,13 +352,91 @@ class GaussianDiffusion:
             final = sample
         return final["pred_xstart"]
 
+    # ------------------------------------------------------------------ DDIM reverse ODE, PLMS
+    def _elementwise(self, fn_name, x, *args):
+        """Launch one of the [B, per_sample] sampler kernels on x's stream; returns the fp32 output tensor."""
+        out = th.empty_like(x)
+        _lib.check(getattr(_lib.load(), fn_name)(*args, x.shape[0], x.numel() // x.shape[0], _lib.ptr(out),
+                                                 _lib.current_stream()), fn_name)
+        return out
+
+    def ddim_reverse_sample(self, model, x, t, clip_denoised=True, denoised_fn=None, model_kwargs=None, eta=0.0):
+        """x_{t+1} along the deterministic DDIM ODE (reference :781-813)."""
+        assert eta == 0.0, "Reverse ODE only for deterministic path"
+        out = self.p_mean_variance(model, x, t, clip_denoised=clip_denoised, denoised_fn=denoised_fn, model_kwargs=model_kwargs)
+        x, t64 = self._prep(x), t.to(th.int64).contiguous()
+        sample = self._elementwise("a2p_ddim_reverse_update", x, _lib.ptr(out["pred_xstart"]), _lib.ptr(x), _lib.ptr(t64),
+                                   _lib.ptr(self._tables(x.device)), self.num_timesteps)
+        return {"sample": sample, "pred_xstart": out["pred_xstart"]}
+
+    def plms_sample(self, model, x, t, clip_denoised=True, denoised_fn=None, cond_fn=None, model_kwargs=None,
+                    cond_fn_with_grad=False, order=2, old_out=None):
+        """Pseudo linear multistep step (reference :938-1041).  `old_out` is the previous step's return value; its
+        "old_eps" list is extended in place and trimmed to `order - 1` entries, as the reference does."""
+        if not int(order) or not 1 <= order <= 4:
+            raise ValueError("order is invalid (should be int from 1-4).")
+        if cond_fn is not None or cond_fn_with_grad:
+            raise NotImplementedError("cond_fn guidance is out of scope")
+        x = self._prep(x)
+        t64 = t.to(th.int64).contiguous()
+        tab = self._tables(x.device)
+
+        def eps_of(x_in, t_in):
+            out = self.p_mean_variance(model, x_in, t_in, clip_denoised=clip_denoised, denoised_fn=denoised_fn,
+                                       model_kwargs=model_kwargs)
+            eps = self._elementwise("a2p_eps_from_xstart", x_in, _lib.ptr(x_in), _lib.ptr(out["pred_xstart"]), _lib.ptr(t_in),
+                                    _lib.ptr(tab), self.num_timesteps)
+            return eps, out
+
+        def update(mode, e):
+            e = list(e) + [None] * (4 - len(e))
+            return self._elementwise("a2p_plms_update", x, _lib.ptr(x), _lib.ptr(out["pred_xstart"]), _lib.ptr(t64), _lib.ptr(tab),
+                                     self.num_timesteps, *(_lib.ptr(v) for v in e), mode)
+
+        eps, out = eps_of(x, t64)
+        if order > 1 and old_out is None:
+            # pseudo improved Euler: predictor to t-1, second model call there, averaged eps
+            old_eps = [eps]
+            predictor = update(_lib.PLMS_PREDICT, [eps])
+            eps_2, _ = eps_of(predictor, (t64 - 1).contiguous())
+            sample = update(_lib.PLMS_EULER, [eps_2, eps])
+        else:
+            old_eps = old_out["old_eps"] if old_out is not None else []
+            old_eps.append(eps)
+            cur_order = min(order, len(old_eps))
+            sample = update(_lib.PLMS_AB1 + cur_order - 1, old_eps[::-1][:cur_order])
+        if len(old_eps) >= order:
+            old_eps.pop(0)
+        return {"sample": sample, "pred_xstart": out["pred_xstart"], "old_eps": old_eps}
+
+    def plms_sample_loop_progressive(self, model, shape, noise=None, clip_denoised=True, denoised_fn=None, cond_fn=None,
+                                     model_kwargs=None, device=None, progress=False, skip_timesteps=0, init_image=None,
+                                     randomize_class=False, cond_fn_with_grad=False, order=2):
+        state = {"old_out": None}
+
+        def step(model, img, t, model_kwargs=None, noise=None, **kw):
+            state["old_out"] = self.plms_sample(model, img, t, model_kwargs=model_kwargs, old_out=state["old_out"], **kw)
+            return state["old_out"]
+
+        yield from self._loop(step, model, shape, noise, model_kwargs, device, progress, skip_timesteps, init_image,
+                              randomize_class, None, clip_denoised=clip_denoised, denoised_fn=denoised_fn, cond_fn=cond_fn,
+                              cond_fn_with_grad=cond_fn_with_grad, order=order)
+
+    def plms_sample_loop(self, model, shape, noise=None, clip_denoised=True, denoised_fn=None, cond_fn=None, model_kwargs=None,
+                         device=None, progress=False, skip_timesteps=0, init_image=None, randomize_class=False,
+                         cond_fn_with_grad=False, order=2):
+        """reference :1043-1081: returns the last "sample"."""
+        final = None
+        for sample in self.plms_sample_loop_progressive(
+                model, shape, noise=noise, clip_denoised=clip_denoised, denoised_fn=denoised_fn, cond_fn=cond_fn,
+                model_kwargs=model_kwargs, device=device, progress=progress, skip_timesteps=skip_timesteps,
+                init_image=init_image, randomize_class=randomize_class, cond_fn_with_grad=cond_fn_with_grad, order=order):
+            final = sample
+        return final["sample"]
+
     # ------------------------------------------------------------------ out of scope (SURVEY.md §2 row 1)
     condition_mean = _out_of_scope("condition_mean")
     condition_score = _out_of_scope("condition_score")
     p_sample_with_grad = _out_of_scope("p_sample_with_grad")
     ddim_sample_with_grad = _out_of_scope("ddim_sample_with_grad")
-    ddim_reverse_sample = _out_of_scope("ddim_reverse_sample")
-    plms_sample = _out_of_scope("plms_sample")
-    plms_sample_loop = _out_of_scope("plms_sample_loop")
-    plms_sample_loop_progressive = _out_of_scope("plms_sample_loop_progressive")
     training_losses = _out_of_scope("training_losses")

@@ -122,6 +122,7 @@ enum a2p_table_id {
   A2P_TAB_ACP_PREV,
   A2P_TAB_SQRT_ACP,
   A2P_TAB_SQRT_1M_ACP,
+  A2P_TAB_ACP_NEXT,
   A2P_NTAB
 };
 int a2p_sample_step(a2p_ctx* ctx, int32_t sampler, const float* x, const int64_t* t_idx,
@@ -142,6 +143,19 @@ int a2p_ddim_update(const float* pred_xstart, const float* x, const int64_t* t_i
 /* p_sample update (gaussian_diffusion.py:470-476): mean + [t!=0] exp(.5 logvar) noise. */
 int a2p_p_sample_update(const float* mean, const int64_t* t_idx, const float* tables, int32_t n_steps,
                         const float* noise, int32_t batch, int64_t per_sample, float* sample, void* stream);
+/* _predict_eps_from_xstart (gaussian_diffusion.py:347-351). */
+int a2p_eps_from_xstart(const float* x, const float* pred_xstart, const int64_t* t_idx, const float* tables,
+                        int32_t n_steps, int32_t batch, int64_t per_sample, float* eps, void* stream);
+/* plms_sample arithmetic (gaussian_diffusion.py:990-1041).  eps0 is the newest eps, eps1..3 older ones (NULL when the mode
+ * does not read them).  PREDICT writes the Euler predictor x0 sqrt(abar_prev) + sqrt(1-abar_prev) eps0 that the
+ * reference feeds to the model at t-1; AB1..AB4 / EULER write the step's "sample" (pred_xstart where t == 0). */
+enum a2p_plms_mode { A2P_PLMS_PREDICT = 0, A2P_PLMS_AB1, A2P_PLMS_AB2, A2P_PLMS_AB3, A2P_PLMS_AB4, A2P_PLMS_EULER };
+int a2p_plms_update(const float* x, const float* pred_xstart, const int64_t* t_idx, const float* tables, int32_t n_steps,
+                    const float* eps0, const float* eps1, const float* eps2, const float* eps3, int32_t mode,
+                    int32_t batch, int64_t per_sample, float* sample, void* stream);
+/* ddim_reverse_sample update, eta = 0 (gaussian_diffusion.py:781-813). */
+int a2p_ddim_reverse_update(const float* pred_xstart, const float* x, const int64_t* t_idx, const float* tables,
+                            int32_t n_steps, int32_t batch, int64_t per_sample, float* sample, void* stream);
 /* q_sample (gaussian_diffusion.py:215-233). */
 int a2p_q_sample(const float* x_start, const int64_t* t_idx, const float* tables, int32_t n_steps,
                  const float* noise, int32_t batch, int64_t per_sample, float* out, void* stream);

@@ -398,3 +398,58 @@ class OracleSampler:
             final = self.p_sample(model_fn, img, t, step_noise[n])
             img = final["sample"]
         return final["sample"], final["pred_xstart"]
+
+    # ---- pseudo linear multistep (gaussian_diffusion.py:938-1158) and the reverse DDIM ODE (:781-813) ----------
+    def _eps(self, x, t, pred_xstart):
+        tb = self.tab                                                # _predict_eps_from_xstart (:347-351)
+        return (_extract(tb["sqrt_recip_alphas_cumprod"], t, x) * x - pred_xstart) \
+            / _extract(tb["sqrt_recipm1_alphas_cumprod"], t, x)
+
+    def plms_sample(self, model_fn, x, t, order=2, old_eps: Optional[list] = None, clip_denoised=False):
+        """One PLMS step; `old_eps` is None on the first step (reference: old_out is None)."""
+        tb = self.tab
+        abp = _extract(tb["alphas_cumprod_prev"], t, x)
+        out = self.p_mean_variance(model_fn, x, t, clip_denoised)
+        eps = self._eps(x, t, out["pred_xstart"])
+
+        def to_prev(eps_prime):                                      # :1013-1017 / :1036-1040
+            pred = _extract(tb["sqrt_recip_alphas_cumprod"], t, x) * x \
+                - _extract(tb["sqrt_recipm1_alphas_cumprod"], t, x) * eps_prime
+            return pred * torch.sqrt(abp) + torch.sqrt(1 - abp) * eps_prime
+
+        if order > 1 and old_eps is None:                            # pseudo improved Euler (:1001-1017)
+            old_eps = [eps]
+            predictor = out["pred_xstart"] * torch.sqrt(abp) + torch.sqrt(1 - abp) * eps
+            out2 = self.p_mean_variance(model_fn, predictor, t - 1, clip_denoised)
+            eps_2 = self._eps(predictor, t - 1, out2["pred_xstart"])
+            mean_pred = to_prev((eps + eps_2) / 2)
+        else:                                                        # Adams-Bashforth (:1018-1040)
+            old_eps = [] if old_eps is None else old_eps
+            old_eps.append(eps)
+            k = min(order, len(old_eps))
+            e = old_eps
+            eps_prime = {1: lambda: e[-1],
+                         2: lambda: (3 * e[-1] - e[-2]) / 2,
+                         3: lambda: (23 * e[-1] - 16 * e[-2] + 5 * e[-3]) / 12,
+                         4: lambda: (55 * e[-1] - 59 * e[-2] + 37 * e[-3] - 9 * e[-4]) / 24}[k]()
+            mean_pred = to_prev(eps_prime)
+        if len(old_eps) >= order:
+            old_eps.pop(0)
+        nz = (t != 0).to(x.dtype).view(-1, 1, 1, 1)
+        return {"sample": mean_pred * nz + out["pred_xstart"] * (1 - nz), "pred_xstart": out["pred_xstart"],
+                "old_eps": old_eps}
+
+    def plms_sample_loop(self, model_fn, x_T: Tensor, order=2, max_steps: Optional[int] = None):
+        img, final, B, old = x_T, None, x_T.shape[0], None
+        idx = list(range(self.num_timesteps))[::-1]
+        for i in (idx[: max_steps] if max_steps else idx):
+            final = self.plms_sample(model_fn, img, torch.tensor([i] * B), order, old)
+            old, img = final["old_eps"], final["sample"]
+        return final["sample"], final["pred_xstart"]
+
+    def ddim_reverse_sample(self, model_fn, x, t, clip_denoised=False):
+        out = self.p_mean_variance(model_fn, x, t, clip_denoised)
+        eps = self._eps(x, t, out["pred_xstart"])
+        abn = _extract(np.append(self.tab["alphas_cumprod"][1:], 0.0), t, x)   # alphas_cumprod_next (:160)
+        return {"sample": out["pred_xstart"] * torch.sqrt(abn) + torch.sqrt(1 - abn) * eps, "pred_xstart": out["pred_xstart"]}
+

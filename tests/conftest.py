@@ -24,6 +24,12 @@ def golden():
     return np.load(os.path.join(ROOT, "tests", "golden", "golden_v1.npz"))
 
 
+@pytest.fixture(scope="session")
+def golden_plms():
+    import numpy as np
+    return np.load(os.path.join(ROOT, "tests", "golden", "golden_plms_v1.npz"))
+
+
 def rel_l2(a, b):
     import torch
     a, b = torch.as_tensor(a).double(), torch.as_tensor(b).double()

@@ -178,6 +178,44 @@ def test_ddpm_restored_noise_fp32_vs_reference_golden(dev, golden, fmt):
     assert rel_l2(last["sample"].cpu(), golden[f"{fmt}/ddpm1000_first3"]) < 1e-3
 
 
+@pytest.mark.parametrize("fmt,order", [("face", 2), ("face", 4), ("pose", 3)])
+def test_plms_fp32_vs_reference_golden(dev, golden_plms, fmt, order):
+    """plms_sample_loop (Euler start + Adams-Bashforth orders 1..4) against the reference's own output."""
+    spec, model = get_model(fmt, "fp32", dev)
+    B, frames = (1, 240) if fmt == "face" else (2, 240)
+    inp = synthetic_inputs(spec, B, frames, SEED)
+    y = y_for(spec, inp, dev, 10.0 if fmt == "face" else 2.0)
+    res = make_diffusion(fmt, "ddim10").plms_sample_loop(ClassifierFreeSampleModel(model), (B, spec.nfeats, 1, frames),
+                                                         clip_denoised=False, model_kwargs={"y": y}, noise=inp["x_T"].to(dev),
+                                                         order=order)
+    want = golden_plms[f"{fmt}/plms10_order{order}"]
+    e2, em = rel_l2(res.cpu(), want), rel_max(res.cpu(), want)
+    print(f"plms10 {fmt} order {order} fp32: rel L2 {e2:.3e} max-norm {em:.3e}")
+    assert e2 < 1e-3 and em < 1e-3
+
+
+@pytest.mark.parametrize("fmt", ["face", "pose"])
+def test_plms_steps_and_ddim_reverse_fp32_vs_reference_golden(dev, golden_plms, fmt):
+    spec, model = get_model(fmt, "fp32", dev)
+    cfg = ClassifierFreeSampleModel(model)
+    B, frames = (1, 240) if fmt == "face" else (2, 240)
+    inp = synthetic_inputs(spec, B, frames, SEED)
+    y = y_for(spec, inp, dev, 10.0 if fmt == "face" else 2.0)
+    d = make_diffusion(fmt, "ddim10")
+    gen = d.plms_sample_loop_progressive(cfg, (B, spec.nfeats, 1, frames), clip_denoised=False, model_kwargs={"y": y},
+                                         noise=inp["x_T"].to(dev), order=2)
+    for i, out in zip(range(2), gen):
+        assert set(out) == {"sample", "pred_xstart", "old_eps"} and len(out["old_eps"]) == 1
+        for k in ("sample", "pred_xstart"):
+            assert rel_l2(out[k].cpu(), golden_plms[f"{fmt}/plms_step{i}/{k}"]) < 1e-3, (i, k)
+    r = d.ddim_reverse_sample(cfg, inp["x_T"].to(dev), torch.tensor([5] * B, device=dev), clip_denoised=False, model_kwargs={"y": y})
+    assert rel_l2(r["sample"].cpu(), golden_plms[f"{fmt}/ddim_reverse_t5"]) < 1e-3
+    with pytest.raises(ValueError):
+        d.plms_sample(cfg, inp["x_T"].to(dev), torch.tensor([5] * B, device=dev), model_kwargs={"y": y}, order=5)
+    with pytest.raises(AssertionError):
+        d.ddim_reverse_sample(cfg, inp["x_T"].to(dev), torch.tensor([5] * B, device=dev), model_kwargs={"y": y}, eta=0.5)
+
+
 def test_generic_path_matches_fused(dev):
     """p_mean_variance through the model protocol (`model(x, ts, **kw)`, any callable) == fused step."""
     spec, model = get_model("face", "fp32", dev)

@@ -93,3 +93,31 @@ def test_ddim10_face_config0(golden):
     x0, _ = O.OracleSampler("ddim10").ddim_sample_loop(fn, inp["x_T"])
     assert rel_l2(x0, golden["face/ddim10"]) < 1e-4
     assert rel_max(x0, golden["face/ddim10"]) < 1e-4
+
+
+@pytest.mark.parametrize("fmt,order", [("face", 2), ("face", 4), ("pose", 3)])
+def test_plms_loop_vs_reference(golden_plms, fmt, order):
+    """the oracle's PLMS restatement against the reference's plms_sample_loop output."""
+    spec, den = _den(fmt)
+    B, frames = (1, 240) if fmt == "face" else (2, 240)
+    inp = synthetic_inputs(spec, B, frames, SEED)
+    scale = torch.full((B,), 10.0 if fmt == "face" else 2.0)
+    fn = lambda x, ts: den.forward_cfg(x, ts, inp["cond_embed"], scale, inp.get("keyframes"), inp.get("mask"))  # noqa: E731
+    sample, _ = O.OracleSampler("ddim10").plms_sample_loop(fn, inp["x_T"], order=order)
+    assert rel_l2(sample, golden_plms[f"{fmt}/plms10_order{order}"]) < 5 * TOL
+
+
+def test_plms_first_steps_and_ddim_reverse_vs_reference(golden_plms):
+    spec, den = _den("face")
+    inp = synthetic_inputs(spec, 1, 240, SEED)
+    scale = torch.full((1,), 10.0)
+    fn = lambda x, ts: den.forward_cfg(x, ts, inp["cond_embed"], scale)  # noqa: E731
+    s = O.OracleSampler("ddim10")
+    o0 = s.plms_sample(fn, inp["x_T"], torch.tensor([9]), 2, None)
+    o1 = s.plms_sample(fn, o0["sample"], torch.tensor([8]), 2, o0["old_eps"])
+    for i, o in enumerate((o0, o1)):
+        for k in ("sample", "pred_xstart"):
+            assert rel_l2(o[k], golden_plms[f"face/plms_step{i}/{k}"]) < 5 * TOL, (i, k)
+    r = s.ddim_reverse_sample(fn, inp["x_T"], torch.tensor([5]))
+    assert rel_l2(r["sample"], golden_plms["face/ddim_reverse_t5"]) < 5 * TOL
+
