@@ -141,6 +141,7 @@ struct a2p_ctx {
   Buf ca2k_wt, ca2v_wt, ca2k_b, ca2v_b;
   Buf conv_wt[7];
   std::vector<Buf> ch_stream, ch_aux;  // packed weight streams / bias blocks of the chain kernels, [layer*4 + kind]
+  int ch_nw = 4;                       // waves per chain workgroup the streams were packed for (slice = 128/ch_nw out-cols)
   Buf hidden, kc, vtc, k2c, vt2c, slot_cond, slot_unc, slot_cfg;
   std::vector<int> h_slots;
   int pB = 0, pS0 = 0, pT = 0, pK = 0;

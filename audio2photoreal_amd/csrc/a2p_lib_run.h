@@ -113,12 +113,12 @@ static void pk_gemm(std::vector<ChainPackDesc>& v, const void* W, int ldw, int n
 static int chain_pack(a2p_ctx* c, int idx, const std::vector<ChainPackDesc>& descs, const std::vector<std::pair<const float*, int>>& aux,
                       hipStream_t s) {
   Buf& st = c->ch_stream[idx];
-  const size_t pad = 8;  // the prefetch runs up to NS-1 (<= 5) stages past the end
+  const size_t pad = CHAIN_STREAM_PAD;  // the DMA runs up to NS-1 (<= 5) stages past the end
   CHK(buf_alloc(st, (descs.size() + pad) * CHAIN_STAGE_ELEMS * 2));
   Buf dd;
   CHK(buf_alloc_tmp(dd, descs.size() * sizeof(ChainPackDesc)));
   HIPCHK(hipMemcpyAsync(dd.p, descs.data(), descs.size() * sizeof(ChainPackDesc), hipMemcpyHostToDevice, s));
-  chain_pack_kernel<<<(int)descs.size(), 256, 0, s>>>(reinterpret_cast<const ChainPackDesc*>(dd.p), reinterpret_cast<bf16_t*>(st.p));
+  chain_pack_kernel<<<(int)descs.size(), 256, 0, s>>>(reinterpret_cast<const ChainPackDesc*>(dd.p), reinterpret_cast<bf16_t*>(st.p), c->ch_nw);
   HIPCHK(hipGetLastError());
   Buf& ax = c->ch_aux[idx];
   CHK(buf_alloc(ax, 2560 * 4 + 1024));
@@ -135,6 +135,10 @@ static int chain_pack(a2p_ctx* c, int idx, const std::vector<ChainPackDesc>& des
 // pre-pack every chain's weight stream in consumption order (called from a2p_finalize_weights)
 static int chain_build_streams(a2p_ctx* c, hipStream_t s) {
   const int d = c->d, ff = c->ff, L = c->L;
+  // waves per chain workgroup: 4 (one 512-register wave per SIMD, default) or 8 (two per SIMD; faster only while the stream
+  // is L2-warm, which the attention kernels between two chain launches prevent -- DESIGN.md section 4)
+  const char* nwe = getenv("A2P_CHAIN_NW");
+  c->ch_nw = nwe && atoi(nwe) == 8 ? 8 : 4;
   if (c->ch_stream.size() != (size_t)L * 4) {  // first build; later builds (weight updates) refill the same buffers
     c->ch_stream.assign((size_t)L * 4, Buf());
     c->ch_aux.assign((size_t)L * 4, Buf());
@@ -211,8 +215,10 @@ static int launch_chain(a2p_ctx* c, int mode, const ChainP& p, hipStream_t s) {
   int mt = env_mt ? atoi(env_mt) : 0;
   // panel heights instantiated per width (LDS: the [16*MT][d] bf16 panel + hidden chunk + >= 3 ring slots must fit 160 KiB)
   static const int kMt512[] = {4, 3, 2}, kMt256[] = {6, 5, 4, 3, 2};
-  const int* cands = c->d == 512 ? kMt512 : kMt256;
-  const int ncand = c->d == 512 ? 3 : 5;
+  static const int kMt512w8[] = {3, 2}, kMt256w8[] = {4, 3, 2};  // 8 waves: 256 registers per wave bound the panel height
+  const bool w8 = c->ch_nw == 8;
+  const int* cands = c->d == 512 ? (w8 ? kMt512w8 : kMt512) : (w8 ? kMt256w8 : kMt256);
+  const int ncand = c->d == 512 ? (w8 ? 2 : 3) : (w8 ? 3 : 5);
   bool ok = false;
   for (int i = 0; i < ncand; ++i) ok = ok || cands[i] == mt;
   if (!ok) {  // fewest rounds over the 256 CUs, then the cheaper (shorter) panel: every panel streams all weights once
@@ -225,13 +231,23 @@ static int launch_chain(a2p_ctx* c, int mode, const ChainP& p, hipStream_t s) {
   }
   const int grid = (p.M + 16 * mt - 1) / (16 * mt);
   KernelTimer kt(c, A2P_KERNEL_CHAIN);
-#define A2P_CHAIN(D, MT)                                                                                   \
-  do {                                                                                                     \
-    if (mode == CHAIN_PRE) A2P_LAUNCH(kt, (chain_kernel<D, MT, CHAIN_PRE, 0>), grid, 256, s, p);           \
-    else if (mode == CHAIN_MID) A2P_LAUNCH(kt, (chain_kernel<D, MT, CHAIN_MID, 0>), grid, 256, s, p);      \
-    else A2P_LAUNCH(kt, (chain_kernel<D, MT, CHAIN_POST, 0>), grid, 256, s, p);                            \
+#define A2P_CHAIN_W(D, MT, NW)                                                                                  \
+  do {                                                                                                          \
+    if (mode == CHAIN_PRE) A2P_LAUNCH(kt, (chain_kernel<D, MT, CHAIN_PRE, 0, NW>), grid, 64 * NW, s, p);        \
+    else if (mode == CHAIN_MID) A2P_LAUNCH(kt, (chain_kernel<D, MT, CHAIN_MID, 0, NW>), grid, 64 * NW, s, p);   \
+    else A2P_LAUNCH(kt, (chain_kernel<D, MT, CHAIN_POST, 0, NW>), grid, 64 * NW, s, p);                         \
   } while (0)
-  if (c->d == 512) {
+#define A2P_CHAIN(D, MT) A2P_CHAIN_W(D, MT, 4)
+  if (w8) {
+    if (c->d == 512) {
+      if (mt == 2) A2P_CHAIN_W(512, 2, 8);
+      else A2P_CHAIN_W(512, 3, 8);
+    } else {
+      if (mt == 2) A2P_CHAIN_W(256, 2, 8);
+      else if (mt == 3) A2P_CHAIN_W(256, 3, 8);
+      else A2P_CHAIN_W(256, 4, 8);
+    }
+  } else if (c->d == 512) {
     if (mt == 2) A2P_CHAIN(512, 2);
     else if (mt == 3) A2P_CHAIN(512, 3);
     else A2P_CHAIN(512, 4);
@@ -243,6 +259,7 @@ static int launch_chain(a2p_ctx* c, int mode, const ChainP& p, hipStream_t s) {
     else A2P_CHAIN(256, 6);
   }
 #undef A2P_CHAIN
+#undef A2P_CHAIN_W
   HIPCHK(hipGetLastError());
   return 0;
 }

@@ -35,6 +35,10 @@
 #include "a2p_common.h"
 
 enum { CHAIN_PRE = 0, CHAIN_MID = 1, CHAIN_POST = 2 };
+// An in-kernel L2 look-ahead of the stream (one 4-byte-per-lane LDS-DMA per wave per stage touching the slice 8-16 stages
+// ahead of the DMA head) was measured and rejected: +30 % kernel time warm AND cold -- the L2 request count per line, not
+// the bytes, is what the extra instruction doubles (scratch/chain_bench).
+#define CHAIN_STREAM_PAD 8  // stages the host appends to a stream: the DMA runs up to NS-1 (<= 5) stages past the end
 #define CHAIN_STAGE_ELEMS 8192  // 128 out-cols x 64 k bf16 = 16 KiB; 2048 elements (4 KiB) per wave
 
 struct ChainP {
@@ -80,12 +84,13 @@ struct ChainPackDesc {
   int ldw, row0, k0, nrows;  // rows >= nrows are zero-filled
 };
 
-__global__ __launch_bounds__(256) void chain_pack_kernel(const ChainPackDesc* __restrict__ descs, bf16_t* __restrict__ dst) {
+__global__ __launch_bounds__(256) void chain_pack_kernel(const ChainPackDesc* __restrict__ descs, bf16_t* __restrict__ dst, int nw) {
   const ChainPackDesc d = descs[blockIdx.x];
   uint4* out = reinterpret_cast<uint4*>(dst + (int64_t)blockIdx.x * CHAIN_STAGE_ELEMS);
+  const int cw = 128 / nw;  // out-cols (weight rows) per wave: 32 (4 waves) or 16 (8 waves)
   for (int q = threadIdx.x; q < 1024; q += 256) {  // 16-byte chunk q = (wave, row-in-slice, chunk position)
-    const int w = q >> 8, r = (q & 255) >> 3, pos = q & 7;
-    const int row = d.row0 + w * 32 + r, chunk = pos ^ ((r >> 1) & 7);
+    const int w = q / (cw * 8), r = (q % (cw * 8)) >> 3, pos = q & 7;
+    const int row = d.row0 + w * cw + r, chunk = pos ^ ((r >> 1) & 7);
     uint4 v = make_uint4(0, 0, 0, 0);
     if (row < d.nrows) v = *reinterpret_cast<const uint4*>(d.W + (int64_t)row * d.ldw + d.k0 + chunk * 8);
     out[q] = v;
@@ -127,31 +132,46 @@ __device__ __forceinline__ void chain_st_bf4(bf16_t* p, bf16x4 v) {
 __device__ __forceinline__ void chain_bar() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
 // ABL: ablation switches for scratch/chain_bench.hip only (the library instantiates ABL = 0):
-//   1 = no global stores, 2 = no MFMA, 4 = no weight DMA / waits, 8 = no workgroup barriers in the FFN
-template <int D, int MT, int MODE, int ABL = 0>
-__global__ __launch_bounds__(256, 1) void chain_kernel(const ChainP p) {
+//   1 = no global stores, 2 = no MFMA, 4 = no weight DMA / waits, 8 = no workgroup barriers in the FFN,
+//   16 = no fragment reads from LDS, 64 = phase time stamps (100 MHz s_memrealtime) of blocks 0 / 101 into p.fin_out
+// NW: waves per workgroup.  4 = one 512-register wave per SIMD; 8 = two 256-register waves per SIMD, each owning 16 of a
+// tile's 128 columns (half the accumulators, half the weight slice, its own DMA ring): a wave's LDS-DMA pieces and
+// fragment reads cost it 40-60 issue cycles each that its own MFMAs do not hide (measured additive),
+// so the second wave on the SIMD is what overlaps them.
+template <int D, int MT, int MODE, int ABL = 0, int NW = 4>
+__global__ __launch_bounds__(64 * NW, 1) void chain_kernel(const ChainP p) {
+  constexpr int CW = 128 / NW;   // columns of a 128-column tile owned by one wave
+  constexpr int NJ = CW / 16;    // 16-column sub-tiles per wave per tile
+  constexpr int PCS = CW / 8;    // 1 KiB LDS-DMA pieces per wave per stage
   constexpr int BM = 16 * MT;
   constexpr int CPR = D / 8;     // 16-byte chunks per panel row
   constexpr int NT = D / 128;    // 128-column tiles of a D-wide output
   constexpr int KS = D / 64;     // k-steps of a D-deep contraction
-  constexpr int NSUB = 2 * NT;   // 16-column sub-tiles a wave owns of a D-wide output
+  constexpr int NSUB = NJ * NT;  // 16-column sub-tiles a wave owns of a D-wide output
   constexpr int FT = 8;          // ff_size / 128
   constexpr int HLD = 128;       // hidden chunk row stride
   constexpr int AUX_F = 2560;    // floats of per-tile biases (10 KiB)
-  constexpr int FIXED = BM * D + BM * HLD + 16 * BM + 2 * AUX_F;  // bf16 elements before the ring
+  constexpr int FIXED = BM * D + BM * HLD + 4 * NW * BM + 2 * AUX_F;  // bf16 elements before the ring
   constexpr int NS = (160 * 1024 / 2 - FIXED) / CHAIN_STAGE_ELEMS > 6 ? 6 : (160 * 1024 / 2 - FIXED) / CHAIN_STAGE_ELEMS;
   static_assert(NS >= 3, "panel too tall for a 3-deep weight ring");
-  constexpr int WSLICE = CHAIN_STAGE_ELEMS / 4;  // elements per wave per stage
+  constexpr int WSLICE = CHAIN_STAGE_ELEMS / NW;  // elements per wave per stage
   __shared__ __attribute__((aligned(16))) bf16_t smem[FIXED + NS * CHAIN_STAGE_ELEMS];
   bf16_t* const panelA = smem;
   bf16_t* const panelH = panelA + BM * D;
-  float* const red = reinterpret_cast<float*>(panelH + BM * HLD);  // [2][4][BM]
-  float* const aux = red + 8 * BM;                                  // [AUX_F]
+  float* const red = reinterpret_cast<float*>(panelH + BM * HLD);  // [2][NW][BM]
+  float* const aux = red + 2 * NW * BM;                                  // [AUX_F]
   bf16_t* const ring = reinterpret_cast<bf16_t*>(aux + AUX_F);      // [wave][NS][32][64]
 
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int l15 = lane & 15, g = lane >> 4;
   const int m0 = blockIdx.x * BM;
+  auto stamp = [&](int i) __attribute__((always_inline)) {
+    if constexpr (ABL & 64) {
+      if (tid == 0 && (blockIdx.x == 0 || blockIdx.x == 101))
+        reinterpret_cast<unsigned long long*>(p.fin_out)[(blockIdx.x ? 32 : 0) + i] = wall_clock64();
+    }
+  };
+  stamp(0);
   bf16_t* const myring = ring + wid * NS * WSLICE;
 
   // ---- weight stream ---------------------------------------------------------------------------------------
@@ -164,17 +184,19 @@ __global__ __launch_bounds__(256, 1) void chain_kernel(const ChainP p) {
       const auto lp = (__attribute__((address_space(3))) void*)buf;
       __builtin_amdgcn_global_load_lds(gp, lp, 16, 0, 0);
       __builtin_amdgcn_global_load_lds(gp, lp, 16, 1024, 0);
-      __builtin_amdgcn_global_load_lds(gp, lp, 16, 2048, 0);
-      __builtin_amdgcn_global_load_lds(gp, lp, 16, 3072, 0);
+      if constexpr (PCS == 4) {
+        __builtin_amdgcn_global_load_lds(gp, lp, 16, 2048, 0);
+        __builtin_amdgcn_global_load_lds(gp, lp, 16, 3072, 0);
+      }
     }
-    wsrc += CHAIN_STAGE_ELEMS;  // past the end of the stream: the host pads NS stages
+    wsrc += CHAIN_STAGE_ELEMS;  // past the end of the stream: the host pads CHAIN_STREAM_PAD stages
     ++issued;
   };
   int consumed = 0;
   // wait for this wave's oldest slice (NS-2 newer ones stay in flight), hand the just-freed slot to the DMA
   auto stage_begin = [&]() __attribute__((always_inline)) -> const bf16_t* {
     // lgkmcnt(0): the fragment reads of the slot that is about to be refilled have returned
-    if constexpr (!(ABL & 4)) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(4 * (NS - 2)) : "memory");
+    if constexpr (!(ABL & 4)) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(PCS * (NS - 2)) : "memory");
     // pin the step boundary: hipcc otherwise hoists the NEXT step's MFMAs above this wait, right behind their fragment
     // reads, which un-pipelines the loop (cdna_hip_programming.md §5.4 rule 18)
     __builtin_amdgcn_sched_barrier(0);
@@ -186,30 +208,32 @@ __global__ __launch_bounds__(256, 1) void chain_kernel(const ChainP p) {
   // one k-step (64) of a [BM x 128] tile = this wave's fragments of 2 MFMA k-chunks.  Reads and MFMAs are split so the
   // reads of step s+1 are in flight while the MFMAs of step s issue (one wave per SIMD: nobody else hides LDS latency).
   struct Frags {
-    bf16x8 a[2][MT], w[2][2];
+    bf16x8 a[2][MT], w[2][NJ];
   };
   auto load_frags = [&](Frags& f, const bf16_t* P, int pld, int kchunk0, const bf16_t* wb) __attribute__((always_inline)) {
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk) {
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt)
-        f.a[kk][mt] = *reinterpret_cast<const bf16x8*>(P + (mt * 16 + l15) * pld + (((kchunk0 + kk * 4 + g) ^ l15) << 3));
+        if constexpr (ABL & 16) asm volatile("" : "=v"(f.a[kk][mt]));
+        else f.a[kk][mt] = *reinterpret_cast<const bf16x8*>(P + (mt * 16 + l15) * pld + (((kchunk0 + kk * 4 + g) ^ l15) << 3));
 #pragma unroll
-      for (int j = 0; j < 2; ++j) {
+      for (int j = 0; j < NJ; ++j) {
         const int wrow = j * 16 + l15;
-        f.w[kk][j] = *reinterpret_cast<const bf16x8*>(wb + wrow * 64 + (((kk * 4 + g) ^ ((wrow >> 1) & 7)) << 3));
+        if constexpr (ABL & 16) asm volatile("" : "=v"(f.w[kk][j]));
+        else f.w[kk][j] = *reinterpret_cast<const bf16x8*>(wb + wrow * 64 + (((kk * 4 + g) ^ ((wrow >> 1) & 7)) << 3));
       }
     }
   };
   // swap = false: D = C^T, lane holds 4 consecutive columns n of row m = l15 (row-major consumers);
   // swap = true : D = C,   lane holds 4 consecutive rows m = g*4 + r of column n = l15 (the transposed V^T store)
-  auto mma_frags = [&](f32x4(&acc)[MT][2], const Frags& f, bool swap) __attribute__((always_inline)) {
+  auto mma_frags = [&](f32x4(&acc)[MT][NJ], const Frags& f, bool swap) __attribute__((always_inline)) {
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk)
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
+        for (int j = 0; j < NJ; ++j) {
           if constexpr (!(ABL & 2)) {
             if (swap) acc[mt][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f.a[kk][mt], f.w[kk][j], acc[mt][j], 0, 0, 0);
             else acc[mt][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f.w[kk][j], f.a[kk][mt], acc[mt][j], 0, 0, 0);
@@ -219,18 +243,18 @@ __global__ __launch_bounds__(256, 1) void chain_kernel(const ChainP p) {
         }
   };
   // acc += P[:, 0:64*nks] * (the next nks stream stages)^T, nks even
-  auto gemm_tile = [&](f32x4(&acc)[MT][2], const bf16_t* P, int pld, int nks, bool swap = false) __attribute__((always_inline)) {
+  auto gemm_tile = [&](f32x4(&acc)[MT][NJ], const bf16_t* P, int pld, int nks, bool swap = false) __attribute__((always_inline)) {
     // Issue order inside one step (one wave per SIMD, in-order issue): each MFMA occupies the matrix pipe for 16 cycles
     // but its issue slot for 4, so the DMA pieces and fragment reads of the NEXT step are slotted between the MFMAs
     // of the current one instead of in front of them.
     auto interleave = [&]() __attribute__((always_inline)) {
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
+      for (int i = 0; i < PCS; ++i) {
         __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);  // VMEM read (LDS-DMA piece)
         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // MFMA
       }
 #pragma unroll
-      for (int i = 0; i < 2 * MT + 4; ++i) {
+      for (int i = 0; i < 2 * MT + 2 * NJ; ++i) {
         __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);  // DS read
         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // MFMA
       }
@@ -250,11 +274,11 @@ __global__ __launch_bounds__(256, 1) void chain_kernel(const ChainP p) {
       }
     }
   };
-  auto zero = [&](f32x4(&acc)[MT][2]) __attribute__((always_inline)) {
+  auto zero = [&](f32x4(&acc)[MT][NJ]) __attribute__((always_inline)) {
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-      for (int j = 0; j < 2; ++j) acc[mt][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+      for (int j = 0; j < NJ; ++j) acc[mt][j] = f32x4{0.f, 0.f, 0.f, 0.f};
   };
   // Per-tile bias reads from the LDS aux block go through inline asm: a compiler-visible ds_read at a runtime offset makes
   // hipcc emit s_waitcnt vmcnt(0) first (it cannot prove the read does not alias a pending LDS-DMA slice), which drained
@@ -264,33 +288,39 @@ __global__ __launch_bounds__(256, 1) void chain_kernel(const ChainP p) {
     return (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) float*)q;
   };
   // accumulators start at the per-column bias held in the LDS aux block
-  auto init_bias = [&](f32x4(&acc)[MT][2], const float* bias_lds) __attribute__((always_inline)) {
+  auto init_bias = [&](f32x4(&acc)[MT][NJ], const float* bias_lds) __attribute__((always_inline)) {
     f32x4 b[2];
-    asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %2 offset:64\n\ts_waitcnt lgkmcnt(0)"
-                 : "=&v"(b[0]), "=&v"(b[1])
-                 : "v"(lds_off(bias_lds + wid * 32 + g * 4))
-                 : "memory");
+    if constexpr (NJ == 2)
+      asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %2 offset:64\n\ts_waitcnt lgkmcnt(0)"
+                   : "=&v"(b[0]), "=&v"(b[1])
+                   : "v"(lds_off(bias_lds + wid * CW + g * 4))
+                   : "memory");
+    else
+      asm volatile("ds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=&v"(b[0]) : "v"(lds_off(bias_lds + wid * CW + g * 4)) : "memory");
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+    for (int j = 0; j < NJ; ++j)
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt) acc[mt][j] = b[j];
   };
   // same for the swapped (D = C) orientation: one bias value per lane column n = j*16 + l15
-  auto init_bias_t = [&](f32x4(&acc)[MT][2], const float* bias_lds) __attribute__((always_inline)) {
+  auto init_bias_t = [&](f32x4(&acc)[MT][NJ], const float* bias_lds) __attribute__((always_inline)) {
     float b[2];
-    asm volatile("ds_read_b32 %0, %2\n\tds_read_b32 %1, %2 offset:64\n\ts_waitcnt lgkmcnt(0)"
-                 : "=&v"(b[0]), "=&v"(b[1])
-                 : "v"(lds_off(bias_lds + wid * 32 + l15))
-                 : "memory");
+    if constexpr (NJ == 2)
+      asm volatile("ds_read_b32 %0, %2\n\tds_read_b32 %1, %2 offset:64\n\ts_waitcnt lgkmcnt(0)"
+                   : "=&v"(b[0]), "=&v"(b[1])
+                   : "v"(lds_off(bias_lds + wid * CW + l15))
+                   : "memory");
+    else
+      asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=&v"(b[0]) : "v"(lds_off(bias_lds + wid * CW + l15)) : "memory");
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+    for (int j = 0; j < NJ; ++j)
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt) acc[mt][j] = f32x4{b[j], b[j], b[j], b[j]};
   };
   // column of sub-tile (tile t, half j) for this lane
-  auto col_of = [&](int t, int j) __attribute__((always_inline)) { return t * 128 + wid * 32 + j * 16 + g * 4; };
+  auto col_of = [&](int t, int j) __attribute__((always_inline)) { return t * 128 + wid * CW + j * 16 + g * 4; };
 
   // ---- kernel start: panel + aux DMA, residual rows, stream prefetch ----------------------------------------
   f32x4 xrow[MT][NSUB];
@@ -304,7 +334,7 @@ __global__ __launch_bounds__(256, 1) void chain_kernel(const ChainP p) {
   }
   if constexpr (MODE != CHAIN_PRE) {  // attention output panel: one global_load_lds per 64 chunks
     constexpr int RPI = 64 / CPR;     // rows per wave instruction (1 for d = 512, 2 for d = 256)
-    for (int r0 = wid * RPI; r0 < BM; r0 += 4 * RPI) {
+    for (int r0 = wid * RPI; r0 < BM; r0 += NW * RPI) {
       const int row = r0 + lane / CPR, pos = lane % CPR;
       int m = m0 + row;
       m = m < p.M ? m : p.M - 1;
@@ -312,32 +342,33 @@ __global__ __launch_bounds__(256, 1) void chain_kernel(const ChainP p) {
                                        (__attribute__((address_space(3))) void*)(panelA + r0 * D), 16, 0, CHAIN_NT ? 2 : 0);
     }
   }
-  for (int kb = wid; kb < p.aux_kb; kb += 4) chain_glds16(p.aux + kb * 256 + lane * 4, aux + kb * 256);
+  for (int kb = wid; kb < p.aux_kb; kb += NW) chain_glds16(p.aux + kb * 256 + lane * 4, aux + kb * 256);
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
     for (int ns = 0; ns < NSUB; ++ns) {
-      xrow[mt][ns] = chain_ld4(p.x + (int64_t)row_m[mt] * D + col_of(ns >> 1, ns & 1));
+      xrow[mt][ns] = chain_ld4(p.x + (int64_t)row_m[mt] * D + col_of(ns / NJ, ns % NJ));
     }
 #pragma unroll
   for (int i = 0; i < NS - 1; ++i) issue_stage();
   // everything older than the NS-1 weight slices (panel, aux, residual rows) has landed for this wave ...
-  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * (NS - 1)) : "memory");
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PCS * (NS - 1)) : "memory");
   chain_bar();  // ... and for every other wave
+  stamp(1);
 
   // ---- epilogue helpers ---------------------------------------------------------------------------------------
   // FiLM affine + residual (transformer_modules.py:122-124,193): x += (scale + 1) * (acc + bias) + shift.
   // All operands of a tile are fetched in one batch BEFORE the arithmetic, and `film != NULL` is tested once per tile:
   // a per-element "if (film) load" made hipcc branch around every load and wait for each one separately
   // (24 dependent L2 round trips per tile, cdna_hip_programming.md §5 "three .s-level traps" (c)).
-  auto film_res = [&](f32x4(&acc)[MT][2], int t, const float* bias, const float* film) __attribute__((always_inline)) {
-    f32x4 b[2];
+  auto film_res = [&](f32x4(&acc)[MT][NJ], int t, const float* bias, const float* film) __attribute__((always_inline)) {
+    f32x4 b[NJ];
 #pragma unroll
-    for (int j = 0; j < 2; ++j) b[j] = *reinterpret_cast<const f32x4*>(bias + col_of(t, j));
+    for (int j = 0; j < NJ; ++j) b[j] = *reinterpret_cast<const f32x4*>(bias + col_of(t, j));
     if (film) {
-      f32x4 sc[2][MT], sh[2][MT];
+      f32x4 sc[NJ][MT], sh[NJ][MT];
 #pragma unroll
-      for (int j = 0; j < 2; ++j)
+      for (int j = 0; j < NJ; ++j)
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
           const float* fp = film + (int64_t)row_seq[mt] * p.film_seq_stride + col_of(t, j);
@@ -345,27 +376,32 @@ __global__ __launch_bounds__(256, 1) void chain_kernel(const ChainP p) {
           sh[j][mt] = *reinterpret_cast<const f32x4*>(fp + p.film_shift_off);
         }
 #pragma unroll
-      for (int j = 0; j < 2; ++j) {
+      for (int j = 0; j < NJ; ++j) {
         asm volatile("" : "+v"(b[j]));
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) asm volatile("" : "+v"(sc[j][mt]), "+v"(sh[j][mt]));
       }
 #pragma unroll
-      for (int j = 0; j < 2; ++j)
+      for (int j = 0; j < NJ; ++j)
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
-          f32x4& xr = xrow[mt][t * 2 + j];
+          f32x4& xr = xrow[mt][t * NJ + j];
           xr += (sc[j][mt] + 1.0f) * (acc[mt][j] + b[j]) + sh[j][mt];
         }
     } else {
 #pragma unroll
-      for (int j = 0; j < 2; ++j)
+      for (int j = 0; j < NJ; ++j)
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt) xrow[mt][t * 2 + j] += acc[mt][j] + b[j];
+        for (int mt = 0; mt < MT; ++mt) xrow[mt][t * NJ + j] += acc[mt][j] + b[j];
     }
   };
   // LayerNorm statistics of the register rows (eps 1e-5, biased variance, two-pass like ln_rope_kernel)
   float ln_mean[MT], ln_rstd[MT];
+  auto wave_partials = [&](const float* q) __attribute__((always_inline)) {  // pairwise sum of the NW per-wave partials
+    float s4 = (q[0] + q[BM]) + (q[2 * BM] + q[3 * BM]);
+    if constexpr (NW == 8) s4 += (q[4 * BM] + q[5 * BM]) + (q[6 * BM] + q[7 * BM]);
+    return s4;
+  };
   auto ln_stats = [&]() __attribute__((always_inline)) {
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
@@ -380,7 +416,7 @@ __global__ __launch_bounds__(256, 1) void chain_kernel(const ChainP p) {
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
       const int r = mt * 16 + l15;
-      ln_mean[mt] = ((red[r] + red[BM + r]) + (red[2 * BM + r] + red[3 * BM + r])) * (1.0f / D);
+      ln_mean[mt] = wave_partials(red + r) * (1.0f / D);
       float q = 0.f;
 #pragma unroll
       for (int ns = 0; ns < NSUB; ++ns)
@@ -391,13 +427,13 @@ __global__ __launch_bounds__(256, 1) void chain_kernel(const ChainP p) {
         }
       q += __shfl_xor(q, 16, 64);
       q += __shfl_xor(q, 32, 64);
-      if (g == 0) red[4 * BM + wid * BM + r] = q;
+      if (g == 0) red[NW * BM + wid * BM + r] = q;
     }
     chain_bar();
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
       const int r = mt * 16 + l15;
-      const float var = ((red[4 * BM + r] + red[5 * BM + r]) + (red[6 * BM + r] + red[7 * BM + r])) * (1.0f / D);
+      const float var = wave_partials(red + NW * BM + r) * (1.0f / D);
       ln_rstd[mt] = 1.0f / sqrtf(var + 1e-5f);
     }
   };
@@ -410,7 +446,7 @@ __global__ __launch_bounds__(256, 1) void chain_kernel(const ChainP p) {
     f32x4 cs[ROPE ? MT : 1][ROPE ? NSUB : 1];
 #pragma unroll
     for (int ns = 0; ns < NSUB; ++ns) {
-      const int n = col_of(ns >> 1, ns & 1);
+      const int n = col_of(ns / NJ, ns % NJ);
       ga[ns] = *reinterpret_cast<const f32x4*>(gamma + n);
       be[ns] = *reinterpret_cast<const f32x4*>(beta + n);
       if constexpr (ROPE) {
@@ -431,7 +467,7 @@ __global__ __launch_bounds__(256, 1) void chain_kernel(const ChainP p) {
     }
 #pragma unroll
     for (int ns = 0; ns < NSUB; ++ns) {
-      const int n = col_of(ns >> 1, ns & 1);
+      const int n = col_of(ns / NJ, ns % NJ);
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt) {
         float v0 = (xrow[mt][ns][0] - ln_mean[mt]) * ln_rstd[mt] * ga[ns][0] + be[ns][0];
@@ -457,19 +493,19 @@ __global__ __launch_bounds__(256, 1) void chain_kernel(const ChainP p) {
       if (m0 + mt * 16 + l15 >= p.M) continue;
 #pragma unroll
       for (int ns = 0; ns < NSUB; ++ns)
-        chain_st4(p.x + (int64_t)row_m[mt] * D + col_of(ns >> 1, ns & 1), xrow[mt][ns]);
+        chain_st4(p.x + (int64_t)row_m[mt] * D + col_of(ns / NJ, ns % NJ), xrow[mt][ns]);
     }
   };
   // D-deep GEMM over `ntiles` output tiles with a per-tile bf16 store: out[m][n] (row-major, 4 columns per lane) or the
   // transposed V^T layout out[seq][n][t] (operands swapped: 4 consecutive frames t per lane, one 8-byte store each)
   auto gemm_store = [&](int ntiles, const float* bias_lds, bf16_t* out, int64_t ldo, bool transposed) __attribute__((always_inline)) {
     for (int t = 0; t < ntiles; ++t) {
-      f32x4 acc[MT][2];
+      f32x4 acc[MT][NJ];
       if (!transposed) init_bias(acc, bias_lds + t * 128);
       else init_bias_t(acc, bias_lds + t * 128);
       gemm_tile(acc, panelA, D, KS, transposed);
 #pragma unroll
-      for (int j = 0; j < 2; ++j) {
+      for (int j = 0; j < NJ; ++j) {
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
           const f32x4 v = acc[mt][j];
@@ -484,7 +520,7 @@ __global__ __launch_bounds__(256, 1) void chain_kernel(const ChainP p) {
           } else {  // rows m .. m+3 (m % 4 == 0, rows_per_seq % 4 == 0: never straddle a sequence), column n
             const int m = m0 + mt * 16 + g * 4;
             if (m >= p.M) continue;
-            const int sq = m / p.rows_per_seq, n = t * 128 + wid * 32 + j * 16 + l15;
+            const int sq = m / p.rows_per_seq, n = t * 128 + wid * CW + j * 16 + l15;
             chain_st_bf4(out + (int64_t)sq * p.vt_seq_stride + (int64_t)n * ldo + (m - sq * p.rows_per_seq), o);
           }
         }
@@ -495,10 +531,13 @@ __global__ __launch_bounds__(256, 1) void chain_kernel(const ChainP p) {
   auto pre_work = [&](const float* aq) __attribute__((always_inline)) {
     ln_stats();
     ln_write(p.lnB_g, p.lnB_b, std::true_type{});
+    stamp(9);
     gemm_store(2 * NT, aq, p.qk_out, p.ld_qk, false);
     chain_bar();  // every wave is done reading the rotated panel
+    stamp(10);
     ln_write(p.lnB_g, p.lnB_b, std::false_type{});
     gemm_store(NT, aq + 2 * D, p.vt_out, p.ld_vt, true);
+    stamp(11);
   };
 
   // ================================================================================================
@@ -507,34 +546,38 @@ __global__ __launch_bounds__(256, 1) void chain_kernel(const ChainP p) {
   } else {
     // out_proj of the attention that produced `ain`; FiLM + residual into the register rows once all tiles are done
     {
-      f32x4 oacc[NT][MT][2];
+      f32x4 oacc[NT][MT][NJ];
 #pragma unroll
       for (int t = 0; t < NT; ++t) {
         zero(oacc[t]);
         gemm_tile(oacc[t], panelA, D, KS);
       }
+      stamp(2);
 #pragma unroll
       for (int t = 0; t < NT; ++t) film_res(oacc[t], t, p.bias_o, p.film_o);
     }
+    stamp(3);
     ln_stats();
+    stamp(4);
     if constexpr (MODE == CHAIN_MID) {
       store_x();
       ln_write(p.lnA_g, p.lnA_b, std::true_type{});
       gemm_store(NT, aux, p.q_out, p.ld_q, false);
     } else {
       ln_write(p.lnA_g, p.lnA_b, std::false_type{});
+      stamp(5);
       // feed forward, split-K over the 8 hidden chunks: linear1 chunk -> GELU -> LDS -> linear2 partial
-      f32x4 facc[NT][MT][2];
+      f32x4 facc[NT][MT][NJ];
 #pragma unroll
       for (int t = 0; t < NT; ++t) zero(facc[t]);
       for (int h = 0; h < FT; ++h) {
-        f32x4 acc[MT][2];
+        f32x4 acc[MT][NJ];
         init_bias(acc, aux + h * 128);
         gemm_tile(acc, panelA, D, KS);
         if (h > 0 && !(ABL & 8)) chain_bar();  // every wave finished the linear2 partial of the previous chunk
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-          const int c = wid * 32 + j * 16 + g * 4;  // column inside the hidden chunk
+        for (int j = 0; j < NJ; ++j) {
+          const int c = wid * CW + j * 16 + g * 4;  // column inside the hidden chunk
 #pragma unroll
           for (int mt = 0; mt < MT; ++mt) {
             const f32x4 v = acc[mt][j];
@@ -547,13 +590,15 @@ __global__ __launch_bounds__(256, 1) void chain_kernel(const ChainP p) {
 #pragma unroll
         for (int t = 0; t < NT; ++t) gemm_tile(facc[t], panelH, HLD, 2);
       }
+      stamp(6);
 #pragma unroll
       for (int t = 0; t < NT; ++t) film_res(facc[t], t, p.bias_2, p.film_f);
+      stamp(7);
       if (p.has_next == 2) {
         // final_layer on the finished rows: plain bf16 cast into the A panel, [BM x fin_n] GEMM, fp32 store
 #pragma unroll
         for (int ns = 0; ns < NSUB; ++ns) {
-          const int n = col_of(ns >> 1, ns & 1);
+          const int n = col_of(ns / NJ, ns % NJ);
 #pragma unroll
           for (int mt = 0; mt < MT; ++mt) {
             const bf16x4 o = {(bf16_t)xrow[mt][ns][0], (bf16_t)xrow[mt][ns][1], (bf16_t)xrow[mt][ns][2], (bf16_t)xrow[mt][ns][3]};
@@ -562,11 +607,11 @@ __global__ __launch_bounds__(256, 1) void chain_kernel(const ChainP p) {
         }
         chain_bar();
         for (int t = 0; t < (p.fin_n + 127) / 128; ++t) {
-          f32x4 acc[MT][2];
+          f32x4 acc[MT][NJ];
           init_bias(acc, aux + FT * 128 + t * 128);
           gemm_tile(acc, panelA, D, KS);
 #pragma unroll
-          for (int j = 0; j < 2; ++j) {
+          for (int j = 0; j < NJ; ++j) {
             const int n = col_of(t, j);
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) {
@@ -578,9 +623,11 @@ __global__ __launch_bounds__(256, 1) void chain_kernel(const ChainP p) {
         }
       } else {
         store_x();
+        stamp(8);
         if (p.has_next) pre_work(aux + FT * 128);
       }
     }
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the run-ahead DMA slices must land before the LDS is released
+  stamp(12);
 }

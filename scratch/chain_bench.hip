@@ -30,7 +30,7 @@ __global__ void thrash_kernel(const uint4* __restrict__ p, size_t n_per_block, u
   if (acc.x == 0x12345678) out[0] = acc;
 }
 static int g_cycle = 1;  // number of distinct weight streams cycled through (1 = always L2-hot)
-template <int MT, int MODE, int ABL>
+template <int MT, int MODE, int ABL, int NW = 4>
 void run(const char* name, ChainP p, int stages) {
   const int grid = (p.M + 16 * MT - 1) / (16 * MT);
   const bf16_t* base = p.stream;
@@ -39,34 +39,46 @@ void run(const char* name, ChainP p, int stages) {
   for (int it = 0; it < iters + 2; ++it) {
     p.stream = base + (size_t)(it % g_cycle) * (256 + 8) * 8192;
     if (g_thrash) thrash_kernel<<<2048, 256>>>(g_tbuf, ((size_t)512 << 20) / 16 / 2048, g_tout);
-    hipExtLaunchKernelGGL((chain_kernel<512, MT, MODE, ABL>), dim3(grid), dim3(256), 0, 0, e0, e1, 0, p);
+    hipExtLaunchKernelGGL((chain_kernel<512, MT, MODE, ABL, NW>), dim3(grid), dim3(64 * NW), 0, 0, e0, e1, 0, p);
     CK(hipEventSynchronize(e1));
     float ms; CK(hipEventElapsedTime(&ms, e0, e1));
     if (it >= 2) tot += ms;
   }
   const float us = tot / iters * 1e3;
-  printf("  MT=%d mode=%d abl=%2d %-28s %8.1f us  (%d blocks, %.3f us/stage)\n", MT, MODE, ABL, name, us, grid, us / stages / ((grid + 255) / 256));
+  printf("  NW=%d MT=%d mode=%d abl=%2d %-28s %8.1f us  (%d blocks, %.3f us/stage)\n", NW, MT, MODE, ABL, name, us, grid, us / stages / ((grid + 255) / 256));
 }
-template <int MT>
+template <int MT, int NW>
 void all(ChainP p) {
   p.has_next = 1;
-  run<MT, CHAIN_PRE, 0>("full", p, 96);
-  run<MT, CHAIN_PRE, 1>("no stores", p, 96);
-  run<MT, CHAIN_MID, 0>("full", p, 64);
-  run<MT, CHAIN_MID, 1>("no stores", p, 64);
-  run<MT, CHAIN_POST, 0>("full", p, 256);
-  run<MT, CHAIN_POST, 1>("no stores", p, 256);
-  run<MT, CHAIN_POST, 3>("no stores, no mfma", p, 256);
-  run<MT, CHAIN_POST, 5>("no stores, no dma", p, 256);
+  run<MT, CHAIN_PRE, 0, NW>("full", p, 96);
+  run<MT, CHAIN_PRE, 1, NW>("no stores", p, 96);
+  run<MT, CHAIN_MID, 0, NW>("full", p, 64);
+  run<MT, CHAIN_MID, 1, NW>("no stores", p, 64);
+  run<MT, CHAIN_POST, 0, NW>("full", p, 256);
+  run<MT, CHAIN_POST, 1, NW>("no stores", p, 256);
+  run<MT, CHAIN_POST, 5, NW>("no stores, no dma", p, 256);
+  {
+    unsigned long long* st; CK(hipMalloc(&st, 64 * 8)); CK(hipMemset(st, 0, 64 * 8));
+    ChainP q = p; q.fin_out = reinterpret_cast<float*>(st);
+    run<MT, CHAIN_POST, 64, NW>("full + stamps", q, 256);
+    unsigned long long h[64]; CK(hipMemcpy(h, st, sizeof(h), hipMemcpyDeviceToHost));
+    static const char* names[] = {"prologue", "out_proj", "film_res", "ln_stats", "ln_write", "ffn", "film_res", "store_x", "ln+rope", "qk_gemm", "ln+v_gemm", "drain"};
+    for (int b = 0; b < 2; ++b) {
+      printf("    block %3d phases (us):", b ? 101 : 0);
+      for (int i = 1; i <= 12; ++i) printf(" %s=%.2f", names[i - 1], (double)(h[b * 32 + i] - h[b * 32 + i - 1]) * 0.01);
+      printf("  total=%.2f\n", (double)(h[b * 32 + 12] - h[b * 32]) * 0.01);
+    }
+    CK(hipFree(st));
+  }
 }
 int main(int argc, char** argv) {
   for (int M : {9600}) {
     const int D = 512;
     float *x, *aux, *vec, *film; bf16_t *ain, *stream, *qk, *vt; float2* cs;
-    CK(hipMalloc(&x, (size_t)M * D * 4)); CK(hipMalloc(&ain, (size_t)M * D * 2)); CK(hipMalloc(&stream, (size_t)16 * (256 + 8) * 16384));
+    CK(hipMalloc(&x, (size_t)M * D * 4)); CK(hipMalloc(&ain, (size_t)M * D * 2)); CK(hipMalloc(&stream, (size_t)(16 * (256 + 8) + 64) * 16384));
     CK(hipMalloc(&aux, 16384)); CK(hipMalloc(&vec, 8192 * 4)); CK(hipMalloc(&film, (size_t)64 * 4 * D * 4));
     CK(hipMalloc(&qk, (size_t)M * 2 * D * 2)); CK(hipMalloc(&vt, (size_t)M * D * 2 + (1 << 20))); CK(hipMalloc(&cs, (size_t)640 * 256 * 8));
-    std::vector<uint16_t> h((size_t)16 * (256 + 8) * 8192);
+    std::vector<uint16_t> h((size_t)(16 * (256 + 8) + 64) * 8192);
     for (auto& v : h) v = 0x3c00 + (rand() & 0x3ff) - ((rand() & 1) << 15);
     CK(hipMemcpy(stream, h.data(), h.size() * 2, hipMemcpyHostToDevice));
     h.resize((size_t)M * D);
@@ -79,10 +91,12 @@ int main(int argc, char** argv) {
     p.q_out = qk; p.ld_q = D; p.bias_2 = vec + 1536; p.film_f = film + 2 * D; p.lnB_g = vec + 2048; p.lnB_b = vec + 2560;
     p.qk_out = qk; p.ld_qk = 2 * D; p.vt_out = vt; p.vt_seq_stride = (int64_t)D * 640; p.ld_vt = 640; p.cs = cs;
     CK(hipMalloc(&g_tbuf, (size_t)512 << 20)); CK(hipMalloc(&g_tout, 64)); CK(hipMemset(g_tbuf, 1, (size_t)512 << 20));
-    for (int th : {0, 1}) {
+    for (int th : {1, 0}) {
       g_cycle = 16; g_thrash = th;
       printf("M=%d weight streams cycled=16, MALL/L2 thrash between launches=%d\n", M, th);
-      all<3>(p);
+      all<3, 4>(p);
+      all<3, 8>(p);
+
     }
   }
   return 0;
