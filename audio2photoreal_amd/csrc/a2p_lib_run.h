@@ -79,6 +79,7 @@ static int cross_attn_block(a2p_ctx* c, const std::string& p, const std::string&
   a.O = c->ao.p; a.o_seq_stride = (int64_t)T * d; a.ldo = d;
   a.ktail = kv.ktail; a.vtail = kv.vtail; a.tail_sample_stride = kv.tail_sample_stride; a.tail_row_stride = kv.tail_row_stride;
   a.kv_slot = kv.slots; a.tail_mod = kv.tail_mod; a.Tq = T; a.S_main = kv.S_main; a.S_tail = kv.S_tail;
+  a.kv_stream = kv.slots && !getenv("A2P_KV_CACHED") ? 1 : 0;  // A2P_KV_CACHED=1: default cache policy for A/B runs
   a.scale_log2e = 1.4426950408889634f / sqrtf((float)c->DH);
   CHK(launch_attn(c, a, N, A2P_KERNEL_ATTN_CROSS, s));
   return film_gemm(c, c->ao.p, d, p + ".out_proj.weight", W32(c, p + ".out_proj.bias"), d, fr, film_idx, M, T, s);
@@ -287,6 +288,7 @@ static int launch_cross_attention(a2p_ctx* c, int N, int T, const CrossKV& kv, h
   a.O = c->ao.p; a.o_seq_stride = (int64_t)T * d; a.ldo = d;
   a.ktail = kv.ktail; a.vtail = kv.vtail; a.tail_sample_stride = kv.tail_sample_stride; a.tail_row_stride = kv.tail_row_stride;
   a.kv_slot = kv.slots; a.tail_mod = kv.tail_mod; a.Tq = T; a.S_main = kv.S_main; a.S_tail = kv.S_tail;
+  a.kv_stream = kv.slots && !getenv("A2P_KV_CACHED") ? 1 : 0;  // A2P_KV_CACHED=1: default cache policy for A/B runs
   a.scale_log2e = 1.4426950408889634f / sqrtf((float)c->DH);
   return launch_attn(c, a, N, A2P_KERNEL_ATTN_CROSS, s);
 }

@@ -36,6 +36,8 @@ struct AttnP {
   int64_t tail_sample_stride, tail_row_stride;
   const int* kv_slot;  // per-sequence slot index, NULL -> slot = seq
   int tail_mod;        // sample = seq % tail_mod
+  int kv_stream;       // 1: K/V slots other than 0 are read once per step (cached audio K/V): DMA them non-temporal so that
+                       // they do not evict the chain kernels' weight streams from L2 / MALL
   int Tq, S_main, S_tail;
   float scale_log2e;   // log2(e) / sqrt(head_dim)
 };
@@ -74,9 +76,10 @@ struct AttnLds {
   }
 };
 
+template <int AUX>  // cache policy of the tile DMA: 0 default, 2 non-temporal
 __device__ __forceinline__ void attn_glds16(const bf16_t* gsrc, bf16_t* lds_wave_base) {
   __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
-                                   (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+                                   (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, AUX);
 }
 
 // ABL: ablation switches for scratch/attn_bench.hip only (the library instantiates ABL = 0):
@@ -96,6 +99,7 @@ __global__ __launch_bounds__(256, 3) void attn_kernel(AttnP p) {
   const int seq = blockIdx.z, head = blockIdx.y;
   const int q0 = blockIdx.x * BQ + wid * (QT * 16);
   const int slot = p.kv_slot ? p.kv_slot[seq] : seq;
+  const bool kv_nt = p.kv_stream && slot != 0;  // slot 0 (null conditioning) is shared by the whole unconditional half: keep it cached
   const int S_total = p.S_main + p.S_tail;
   const int ntiles = (S_total + KV - 1) / KV;
 
@@ -148,10 +152,17 @@ __global__ __launch_bounds__(256, 3) void attn_kernel(AttnP p) {
       bf16_t* Vs = Ks + L::KSZ;
       const bf16_t* Kt = reinterpret_cast<const bf16_t*>(Kb) + (int64_t)tile * KV * p.ldk;
       const bf16_t* Vt = reinterpret_cast<const bf16_t*>(Vb) + tile * KV;
+      if (kv_nt) {  // block-uniform
 #pragma unroll
-      for (int j = 0; j < KPW; ++j) attn_glds16(Kt + ksrc[j], Ks + (j * 4 + wid) * KRPI * DH);
+        for (int j = 0; j < KPW; ++j) attn_glds16<2>(Kt + ksrc[j], Ks + (j * 4 + wid) * KRPI * DH);
 #pragma unroll
-      for (int j = 0; j < VPW; ++j) attn_glds16(Vt + vsrc[j], Vs + (j * 4 + wid) * 8 * KV);
+        for (int j = 0; j < VPW; ++j) attn_glds16<2>(Vt + vsrc[j], Vs + (j * 4 + wid) * 8 * KV);
+      } else {
+#pragma unroll
+        for (int j = 0; j < KPW; ++j) attn_glds16<0>(Kt + ksrc[j], Ks + (j * 4 + wid) * KRPI * DH);
+#pragma unroll
+        for (int j = 0; j < VPW; ++j) attn_glds16<0>(Vt + vsrc[j], Vs + (j * 4 + wid) * 8 * KV);
+      }
     }
   };
   auto stage_regs = [&](int tile) {  // fp32: global -> registers -> padded LDS

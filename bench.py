@@ -202,7 +202,7 @@ def main():
         # of MI355X_MICROARCH.md + WRITE_SIZE; scratch/run_pmc.sh writes the file) -- null when not collected
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-        if os.path.exists(tpath) and B == 8 and T == 600 and a.precision == "bf16":
+        if os.path.exists(tpath) and a.model == "face" and B == 8 and T == 600 and a.precision == "bf16":   # the profiled workload
             traffic = json.load(open(tpath)).get(dom)
         roofline = {"kernel": dom, "bound": "mfma", "achieved": kernels[dom]["tflops"], "peak": peak, "unit": "TFLOP/s",
                     "frac": round(kernels[dom]["tflops"] / peak, 4), "traffic": traffic and traffic["total_bytes"],
