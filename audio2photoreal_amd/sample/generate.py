@@ -17,21 +17,66 @@ import torch
 from ..sample_parallel import sample_parallel
 
 
+def fixseed(seed: int) -> None:
+    """utils/misc.py:138-142."""
+    import random
+    random.seed(seed)
+    np.random.seed(seed)
+    torch.manual_seed(seed)
+
+
+def load_data_stats(path: str) -> Dict[str, np.ndarray]:
+    """A subject's `data_stats.pth` (numpy arrays `pose_mean/std[104]`, `code_mean/std[256]`, `audio_mean[2]`,
+    `audio_std_flat[1]`, ...; data_loaders/data.py:100-110)."""
+    return torch.load(path, map_location="cpu", weights_only=False)
+
+
 def make_inv_transform(stats: Dict[str, np.ndarray]) -> Callable:
-    """`Social.inv_transform` (data_loaders/data.py:71-98) from a data_stats.pth dict."""
+    """`Social.inv_transform` (data_loaders/data.py:71-91) over the statistics `Social._load_std` picks (:100-110): pose and
+    face use the per-channel mean / std, audio the per-channel mean and the FLAT std.  Like the reference, tensors are scaled
+    by `torch.tensor(std)` in the statistics' own dtype, so fp32 pose / face data comes back as float64."""
+    table = {"pose": (np.asarray(stats["pose_std"]).reshape(-1), np.asarray(stats["pose_mean"]).reshape(-1)),
+             "face": (np.asarray(stats["code_std"]), np.asarray(stats["code_mean"])),
+             "audio": (np.asarray(stats["audio_std_flat"]), np.asarray(stats["audio_mean"]))}
+
     def inv(data, data_type: str):
-        if data_type == "pose":
-            std, mean = stats["pose_std"], stats["pose_mean"]
-        elif data_type == "face":
-            std, mean = stats["code_std"], stats["code_mean"]
-        elif data_type == "audio":
-            std, mean = stats["audio_std"], stats["audio_mean"]
-        else:
-            raise ValueError(f"unknown data type {data_type}")
+        assert data_type in table, f"datatype not defined: {data_type}"
+        std, mean = table[data_type]
         if torch.is_tensor(data):
-            return data * torch.as_tensor(std, dtype=data.dtype, device=data.device) + torch.as_tensor(mean, dtype=data.dtype, device=data.device)
+            return data * torch.tensor(std, device=data.device, requires_grad=False) \
+                + torch.tensor(mean, device=data.device, requires_grad=False)
         return data * std + mean
     return inv
+
+
+def _setup_model(args, state_dict, **model_kwargs):
+    """Model + diffusion for sampling (reference sample/generate.py:165-198, with the checkpoint passed in instead of read
+    from args.model_path): build, load, wrap for classifier-free guidance, move to args.device, eval."""
+    from ..model.cfg_sampler import ClassifierFreeSampleModel
+    from ..model_util import create_model_and_diffusion, load_model
+    model, diffusion = create_model_and_diffusion(args, "test", **model_kwargs)
+    load_model(model, state_dict)
+    if not getattr(args, "unconstrained", False):
+        assert args.guidance_param != 1
+    if args.guidance_param != 1:
+        model = ClassifierFreeSampleModel(model)
+    model.to(args.device)
+    model.eval()
+    return model, diffusion
+
+
+def save_results(output_dir: str, data_block: Dict[str, np.ndarray]) -> str:
+    """`results.npy` exactly as the reference writes it (sample/generate.py:282-285): a pickled dict."""
+    import os
+    os.makedirs(output_dir, exist_ok=True)
+    npy_path = os.path.join(output_dir, "results.npy")
+    np.save(npy_path, data_block)
+    return npy_path
+
+
+def load_results(npy_path: str) -> Dict[str, np.ndarray]:
+    """reference sample/generate.py:288."""
+    return np.load(npy_path, allow_pickle=True).item()
 
 
 def _run_single_diffusion(args, model_kwargs, diffusion, model, inv_transform: Callable, gt: Optional[torch.Tensor],

@@ -249,3 +249,39 @@ def test_world_size_2_gloo_matches_single_process(tmp_path, total):
 def test_gather_is_identity_without_a_process_group():
     t = torch.randn(3, 2)
     assert gather_samples(t, 3) is t
+
+
+# ----------------------------------------------------------------------------- results format / un-normalisation
+def test_inv_transform_matches_the_reference_on_its_own_statistics(tmp_path):
+    """`make_inv_transform` against `Social.inv_transform` run by the reference on PXB184's data_stats.pth
+    (tests/golden/make_golden_stats.py): same values, same dtype promotion (fp32 pose/face data -> float64)."""
+    import os
+    from audio2photoreal_amd.sample import generate as G
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", "golden_stats_v1.npz"))
+    stats = {k.split("/", 1)[1]: z[k] for k in z.files if k.startswith("stats/")}
+    path = tmp_path / "data_stats.pth"
+    torch.save(stats, path)
+    inv = G.make_inv_transform(G.load_data_stats(str(path)))
+    for kind in ("pose", "face"):
+        got = inv(torch.from_numpy(z[f"in/{kind}"]), kind)
+        assert got.dtype == torch.float64 and np.array_equal(got.numpy(), z[f"out/{kind}"]), kind
+    got = inv(z["in/audio"], "audio")
+    assert got.dtype == np.float32 and np.array_equal(got, z["out/audio"])     # the FLAT audio std, per-channel mean
+    with pytest.raises(AssertionError):
+        inv(z["in/audio"], "lips")
+
+
+def test_results_file_round_trip_and_fixseed(tmp_path):
+    from audio2photoreal_amd.sample import generate as G
+    block = {"motions": np.arange(24, dtype=np.float32).reshape(2, 3, 1, 4), "audio": np.zeros((2, 8, 2), np.float32),
+             "gt": np.ones((2, 3, 1, 4), np.float32), "lengths": np.array([4, 3]), "keyframes": np.zeros((2, 1, 3), np.float32)}
+    path = G.save_results(str(tmp_path / "out"), block)
+    assert path.endswith("results.npy")
+    back = G.load_results(path)
+    assert set(back) == {"motions", "audio", "gt", "lengths", "keyframes"}      # reference sample/generate.py:146-152
+    assert all(np.array_equal(back[k], block[k]) for k in block)
+    G.fixseed(10)
+    a = (torch.rand(3), np.random.rand(3))
+    G.fixseed(10)
+    b = (torch.rand(3), np.random.rand(3))
+    assert torch.equal(a[0], b[0]) and np.array_equal(a[1], b[1])
