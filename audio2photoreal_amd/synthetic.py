@@ -17,7 +17,7 @@ from typing import Dict
 import numpy as np
 import torch
 
-from .spec import DenoiserSpec, param_shapes
+from .spec import DenoiserSpec, GuideSpec, TokenizerSpec, guide_param_shapes, param_shapes, tokenizer_param_shapes
 
 
 def _rng(seed: int, name: str) -> np.random.Generator:
@@ -54,6 +54,44 @@ def synthetic_state_dict(spec: DenoiserSpec, seed: int = 10) -> Dict[str, torch.
     d = spec.latent_dim
     sd["rotary.freqs"] = 1.0 / (10000 ** (torch.arange(0, d, 2)[: d // 2].float() / d))
     return sd
+
+
+def _init_like_reference(seed: int, name: str, shape, prefix: str = "") -> torch.Tensor:
+    """The rule synthetic_state_dict applies per parameter, shared with the guide / tokenizer dictionaries (`prefix` only
+    separates their random streams)."""
+    leaf, key = name.split(".")[-1], prefix + name
+    is_norm = ".norm" in name or name.startswith("norm_cond") or name.startswith("non_attn_cond_projection.0")
+    if name.startswith("null_") or name.endswith("_codebook.embed") or name.startswith("token_embedding"):
+        return synthetic_tensor(seed, key, shape, 1.0)
+    if is_norm and leaf == "weight":
+        return synthetic_tensor(seed, key, shape, 0.1, 1.0)
+    if is_norm and leaf == "bias":
+        return synthetic_tensor(seed, key, shape, 0.1)
+    if leaf in ("bias", "in_proj_bias"):
+        return synthetic_tensor(seed, key, shape, 0.02)
+    if len(shape) == 3:
+        fan_out, fan_in = shape[0] * shape[2], shape[1] * shape[2]
+    else:
+        fan_out, fan_in = shape[0], shape[1]
+    return synthetic_tensor(seed, key, shape, float(np.sqrt(2.0 / (fan_in + fan_out))))
+
+
+def synthetic_guide_state_dict(spec: GuideSpec, seed: int = 10) -> Dict[str, torch.Tensor]:
+    """GuideTransformer parameters (model/guide.py) + its rotary buffer; conv weights get a gain of 2 so that 13 stacked
+    LeakyReLU convolutions keep O(1) activations."""
+    sd = {}
+    for name, shape in guide_param_shapes(spec).items():
+        t = _init_like_reference(seed, name, shape, "guide.")
+        if name.startswith("pre_audio") and name.endswith("weight"):
+            t = t * 2.0
+        sd[name] = t
+    d = spec.dim
+    sd["rotary.freqs"] = 1.0 / (10000 ** (torch.arange(0, d, 2)[: d // 2].float() / d))
+    return sd
+
+
+def synthetic_tokenizer_state_dict(spec: TokenizerSpec, seed: int = 10) -> Dict[str, torch.Tensor]:
+    return {name: _init_like_reference(seed, name, shape, "vq.") for name, shape in tokenizer_param_shapes(spec).items()}
 
 
 def synthetic_inputs(spec: DenoiserSpec, batch: int, frames: int, seed: int = 10,
