@@ -31,6 +31,8 @@ EXPORTS = (
     "a2p_prepare_cond", "a2p_denoise_forward", "a2p_sample_step", "a2p_p_mean_variance", "a2p_ddim_update",
     "a2p_p_sample_update", "a2p_q_sample", "a2p_eps_from_xstart", "a2p_plms_update", "a2p_ddim_reverse_update", "a2p_decoder_layer_forward", "a2p_gemm", "a2p_attention",
     "a2p_kernel_timing", "a2p_kernel_time_ms", "a2p_debug_read",
+    "a2p_guide_create", "a2p_guide_destroy", "a2p_guide_set_weight", "a2p_guide_finalize", "a2p_guide_prepare",
+    "a2p_guide_forward", "a2p_guide_generate", "a2p_guide_debug_read", "a2p_vq_decode",
 )
 
 
@@ -38,6 +40,12 @@ class A2PConfig(C.Structure):
     _fields_ = [(n, C.c_int32) for n in (
         "data_format", "nfeats", "latent_dim", "ff_size", "num_layers", "num_heads", "cond_feature_dim",
         "max_frames", "emb_len", "keyframe_dim", "keyframe_step", "precision", "max_batch", "reserved")]
+
+
+class A2PGuideConfig(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in (
+        "tokens", "dim", "num_layers", "num_heads", "ff_size", "cond_feature_dim", "emb_len", "num_audio_layers",
+        "max_batch", "max_positions")] + [("reserved", C.c_int32 * 2)]
 
 
 class A2PError(RuntimeError):
@@ -84,6 +92,15 @@ def load() -> C.CDLL:
         "a2p_kernel_timing": [vp, i32, i32],
         "a2p_kernel_time_ms": [vp, C.POINTER(C.c_double), C.POINTER(i64)],
         "a2p_debug_read": [vp, C.c_char_p, vp, i64],
+        "a2p_guide_create": [C.POINTER(A2PGuideConfig), C.POINTER(vp)],
+        "a2p_guide_destroy": [vp],
+        "a2p_guide_set_weight": [vp, C.c_char_p, vp, i64, vp],
+        "a2p_guide_finalize": [vp, vp],
+        "a2p_guide_prepare": [vp, vp, i32, i32, i32, vp],
+        "a2p_guide_forward": [vp, vp, i32, i32, vp, vp],
+        "a2p_guide_generate": [vp, i32, i32, f32, vp, vp, vp, vp],
+        "a2p_guide_debug_read": [vp, C.c_char_p, vp, i64],
+        "a2p_vq_decode": [vp, i32, i32, i32, i32, i32, i32, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), vp, vp],
     }
     for name, args in sig.items():
         fn = getattr(lib, name)

@@ -644,3 +644,4 @@ extern "C" int a2p_finalize_weights(a2p_ctx* c, void* stream) {
 }
 
 #include "a2p_lib_run.h"
+#include "a2p_guide.h"

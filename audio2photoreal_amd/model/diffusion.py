@@ -191,7 +191,18 @@ class FiLMTransformer(nn.Module):
         return [p for p in self.parameters() if p.requires_grad]
 
     def _hot_state(self) -> Dict[str, torch.Tensor]:
-        return {k: v for k, v in self.state_dict().items() if not k.endswith("rotary.freqs")}
+        # the guide transformer / tokenizer sub-modules (setup_guide_predictor) own their native contexts
+        return {k: v for k, v in self.state_dict().items()
+                if not (k.endswith("rotary.freqs") or k.startswith("transformer.") or k.startswith("tokenizer."))}
+
+    def setup_guide_predictor(self, transformer: nn.Module, tokenizer: nn.Module, resume_trans: str = "<in-memory>") -> None:
+        """model/diffusion.py:244-271 with the modules passed in (the reference builds them from `args.json` + checkpoint files
+        next to `cp_path`): attaches the guide transformer and the VQ tokenizer that `_replace_keyframes` calls."""
+        assert self.data_format == "pose", "the guide transformer predicts body keyframes"
+        self.tokenizer, self.transformer, self.resume_trans = tokenizer, transformer, resume_trans
+        for p in list(transformer.parameters()) + list(tokenizer.parameters()):
+            p.requires_grad = False
+        self._param_list = None
 
     def _ensure_ctx(self, device: torch.device, batch: int):
         lib = _lib.load()
@@ -222,7 +233,9 @@ class FiLMTransformer(nn.Module):
         # small configurations host-bound).  In-place updates (load_state_dict, optimisers) bump `_version`;
         # storage re-seating goes through `_apply` above.
         if self._param_list is None:
-            self._param_list = list(self.parameters()) + list(self.buffers())
+            skip = {id(t) for n in ("transformer", "tokenizer") if isinstance(getattr(self, n, None), nn.Module)
+                    for t in list(getattr(self, n).parameters()) + list(getattr(self, n).buffers())}
+            self._param_list = [t for t in list(self.parameters()) + list(self.buffers()) if id(t) not in skip]
         return (len(self._param_list), sum(p._version for p in self._param_list))
 
     def _ensure_weights(self, lib, device):

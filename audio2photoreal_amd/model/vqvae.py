@@ -1,0 +1,67 @@
+"""TemporalVertexCodec: the decode side of the reference's residual-VQ tokenizer (model/vqvae.py:467-521) on the sampling
+path: `decode(tokens)` turns the guide transformer's tokens into the keyframe poses the body denoiser
+is conditioned on (sample/generate.py:51-71).  Parameter names are the reference's; encoder / EMA buffers are accepted by
+`load_state_dict(strict=False)` semantics of the caller and not needed here.  The arithmetic runs in liba2p_hip.so
+(`a2p_vq_decode`: codebook gather + sum, 4 causal dilated Conv1d + LeakyReLU, 1x1 conv; one workgroup per sequence)."""
+from __future__ import annotations
+
+import ctypes as C
+
+import torch
+import torch.nn as nn
+
+from .. import _lib
+
+
+class _Codebook(nn.Module):
+    def __init__(self, categories: int, dim: int):
+        super().__init__()
+        self.register_buffer("embed", torch.randn(categories, dim))     # EuclideanCodebook.embed (model/vqvae.py:86-110)
+
+
+class _VQ(nn.Module):
+    def __init__(self, categories: int, dim: int):
+        super().__init__()
+        self._codebook = _Codebook(categories, dim)
+
+
+class _RVQ(nn.Module):
+    def __init__(self, categories: int, dim: int, depth: int):
+        super().__init__()
+        self.layers = nn.ModuleList([_VQ(categories, dim) for _ in range(depth)])
+
+
+class _Decoder(nn.Module):
+    def __init__(self, n_vertices: int, latent_dim: int):
+        super().__init__()
+        lr = lambda: nn.LeakyReLU(0.2)                                   # noqa: E731
+        self.dec = nn.Sequential(                                       # model/vqvae.py:440-450
+            nn.Conv1d(latent_dim, latent_dim, 2, dilation=1), lr(), nn.Conv1d(latent_dim, latent_dim, 2, dilation=2), lr(),
+            nn.Conv1d(latent_dim, latent_dim, 2, dilation=3), lr(), nn.Conv1d(latent_dim, latent_dim, 2, dilation=1), lr(),
+            nn.Conv1d(latent_dim, n_vertices, 1))
+
+
+class TemporalVertexCodec(nn.Module):
+    def __init__(self, n_vertices: int = 338, latent_dim: int = 128, categories: int = 128, residual_depth: int = 4):
+        super().__init__()
+        self.latent_dim, self.categories, self.residual_depth = latent_dim, categories, residual_depth
+        self.n_clusters, self.n_vertices = categories, n_vertices
+        self.decoder = _Decoder(n_vertices, latent_dim)
+        self.quantizer = _RVQ(categories, latent_dim, residual_depth)
+
+    def decode(self, q: torch.Tensor) -> torch.Tensor:
+        """q int64 [B, T, residual_depth] -> [B, T, n_vertices] (reference :508-521)."""
+        _lib.require_gpu_tensor(q, "tokens")
+        assert q.dim() == 3 and q.shape[-1] == self.residual_depth
+        B, T, _ = q.shape
+        q = q.to(torch.int64).contiguous()
+        f32 = lambda t: t.detach().to(device=q.device, dtype=torch.float32).contiguous()   # noqa: E731
+        books = [f32(l._codebook.embed) for l in self.quantizer.layers]
+        convs = [self.decoder.dec[i] for i in (0, 2, 4, 6, 8)]
+        ws, bs = [f32(c.weight) for c in convs], [f32(c.bias) for c in convs]
+        arr = lambda ts: (C.c_void_p * len(ts))(*[t.data_ptr() for t in ts])               # noqa: E731
+        out = torch.empty(B, T, self.n_vertices, device=q.device, dtype=torch.float32)
+        _lib.check(_lib.load().a2p_vq_decode(_lib.ptr(q), B, T, self.residual_depth, self.categories, self.latent_dim, self.n_vertices,
+                                             arr(books), arr(ws), arr(bs), _lib.ptr(out), _lib.current_stream()), "a2p_vq_decode")
+        torch.cuda.current_stream().synchronize()   # the staged fp32 copies above must outlive the kernel
+        return out

@@ -79,9 +79,28 @@ def load_results(npy_path: str) -> Dict[str, np.ndarray]:
     return np.load(npy_path, allow_pickle=True).item()
 
 
+def _replace_keyframes(model_kwargs, model, uniforms: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """Keyframes predicted by the guide transformer instead of ground truth (reference sample/generate.py:51-71):
+    `model.transformer.generate` -> `[B, T, residual_depth]` tokens -> `model.tokenizer.decode`.  The condition is
+    `y["cond_embed"]` (audio features) when present, else `y["audio"]` through the transformer's `audio_frontend`."""
+    y = model_kwargs["y"]
+    B, T = y["keyframes"].shape[0], y["keyframes"].shape[1]
+    cond = y["cond_embed"] if "cond_embed" in y else y["audio"]
+    with torch.no_grad():
+        tokens = model.transformer.generate(cond, T, layers=model.tokenizer.residual_depth, n_sequences=B, max_key_len=T,
+                                            max_seq_len=30 * T, uniforms=uniforms)
+    tokens = tokens.reshape((B, -1, model.tokenizer.residual_depth))
+    pred = model.tokenizer.decode(tokens).detach().cpu()
+    assert y["keyframes"].shape == pred.shape, f"{y['keyframes'].shape} vs {pred.shape}"
+    return pred
+
+
 def _run_single_diffusion(args, model_kwargs, diffusion, model, inv_transform: Callable, gt: Optional[torch.Tensor],
                           noise: Optional[torch.Tensor] = None):
     """One ddim_sample_loop over the (possibly rank-sharded) batch + un-normalisation (reference :74-107)."""
+    if args.data_format == "pose" and getattr(args, "resume_trans", None) is not None:   # reference :82-83
+        y = model_kwargs["y"]
+        y["keyframes"] = _replace_keyframes(model_kwargs, model).to(y["keyframes"].device)
     shape = (args.batch_size, model.nfeats, 1, args.curr_seq_length)
     with torch.no_grad():
         sample = sample_parallel(diffusion.ddim_sample_loop, model, shape, model_kwargs, noise=noise,

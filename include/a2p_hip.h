@@ -189,6 +189,49 @@ int a2p_kernel_time_ms(a2p_ctx* ctx, double* total_ms, int64_t* launches);
  * memory after a device synchronise (race hunts, scratch/stress*.py); not part of the reference's interface. */
 int a2p_debug_read(a2p_ctx* ctx, const char* name, void* host, int64_t bytes);
 
+/* ---- guide transformer + residual-VQ decode --------------------------------------
+ * GuideTransformer (model/guide.py:26-83) predicts the body model's keyframe tokens from the audio features;
+ * TemporalVertexCodec.decode (model/vqvae.py:508-521) turns them into the `keyframes` the pose denoiser consumes
+ * (sample/generate.py:51-71 `_replace_keyframes`).  fp32 throughout.  Parameter names are the reference's state_dict keys
+ * (`audio_model.*` and `*.rotary.freqs` are accepted and ignored). */
+typedef struct a2p_guide_ctx a2p_guide_ctx;
+typedef struct a2p_guide_config {
+  int32_t tokens;           /* codebook size; id `tokens` is the sequence-start token (model/guide.py:42-45) */
+  int32_t dim, num_layers, num_heads, ff_size;
+  int32_t cond_feature_dim; /* audio feature width (1024) */
+  int32_t emb_len;          /* rows of null_cond_embed (1998) = upper bound of the audio tokens left after the conv stack */
+  int32_t num_audio_layers; /* blocks of 6 dilated convs in `pre_audio` (model/guide.py:84-109) */
+  int32_t max_batch;
+  int32_t max_positions;    /* longest token prefix incl. the start token (self-attention cache depth) */
+  int32_t reserved[2];
+} a2p_guide_config;
+int a2p_guide_create(const a2p_guide_config* cfg, a2p_guide_ctx** out);
+int a2p_guide_destroy(a2p_guide_ctx* ctx);
+int a2p_guide_set_weight(a2p_guide_ctx* ctx, const char* name, const float* dev_ptr, int64_t numel, void* stream);
+int a2p_guide_finalize(a2p_guide_ctx* ctx, void* stream);
+/* Token-independent part of GuideTransformer.forward (model/guide.py:150-169), hoisted out of the 80-step loop of
+ * `generate`: pre_audio conv stack, cond projection, pooled FiLM vector, norm_cond, per-layer cross-attention K/V.
+ * cond_embed [batch, n_tokens, cond_feature_dim] fp32 = what encode_audio returns (:111-119); cond_drop 0|1 selects the
+ * null embeddings (:156-165). */
+int a2p_guide_prepare(a2p_guide_ctx* ctx, const float* cond_embed, int32_t batch, int32_t n_tokens, int32_t cond_drop,
+                      void* stream);
+/* GuideTransformer.forward on the prepared condition: tokens int64 [batch, len] (causal) -> logits fp32 [batch, len, tokens]. */
+int a2p_guide_forward(a2p_guide_ctx* ctx, const int64_t* tokens, int32_t batch, int32_t len, float* logits, void* stream);
+/* GuideTransformer.generate (model/guide.py:175-222) as one persistent launch: n_steps tokens per sequence by nucleus
+ * sampling (top_p); the categorical draw of step i, sequence b is the inverse CDF at uniforms[i * batch + b] in [0, 1).
+ * tokens_out int64 [batch, n_steps]; sorted_probs_out (nullable) fp32 [n_steps, batch, tokens] = the renormalised sorted
+ * nucleus probabilities the reference hands to Categorical (:212-214). */
+int a2p_guide_generate(a2p_guide_ctx* ctx, int32_t batch, int32_t n_steps, float top_p, const float* uniforms,
+                       int64_t* tokens_out, float* sorted_probs_out, void* stream);
+/* test / diagnostics: copy a prepared buffer ("pre_audio", "ct", "mem", "memr", "hidden", "film", "kc", "vc") to the host */
+int a2p_guide_debug_read(a2p_guide_ctx* ctx, const char* name, void* host, int64_t bytes);
+/* TemporalVertexCodec.decode: q int64 [batch, T, depth] -> out fp32 [batch, T, vertices].  codebooks: `depth` device
+ * pointers [categories, latent] (quantizer.layers.i._codebook.embed); conv_w / conv_b: the 5 Conv1d of decoder.dec
+ * (indices 0,2,4,6: [latent, latent, 2], dilation 1,2,3,1; index 8: [vertices, latent, 1]).  The pointer arrays are host memory. */
+int a2p_vq_decode(const int64_t* q, int32_t batch, int32_t T, int32_t depth, int32_t categories, int32_t latent,
+                  int32_t vertices, const float* const* codebooks, const float* const* conv_w, const float* const* conv_b,
+                  float* out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -374,7 +374,7 @@ def test_sample_parallel_world_size_1_and_generate_surface(dev):
     d = make_diffusion("face", "ddim10")
     inp = synthetic_inputs(spec, 2, 64, SEED)
     stats = {"code_mean": np.full(256, 0.5), "code_std": np.full(256, 2.0), "pose_mean": np.zeros(104), "pose_std": np.ones(104),
-             "audio_mean": np.zeros(2, np.float32), "audio_std": np.ones(2, np.float32)}
+             "audio_mean": np.zeros(2, np.float32), "audio_std": np.ones(2, np.float32), "audio_std_flat": np.ones(1, np.float32)}
     args = argparse.Namespace(batch_size=2, curr_seq_length=64, data_format="face", num_repetitions=2, guidance_param=10.0, device=dev)
     torch.manual_seed(0)
     res = _generate_sequences(args, {"y": {"cond_embed": inp["cond_embed"].to(dev), "lengths": torch.tensor([64, 64])}}, d, cfg,
