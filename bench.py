@@ -49,6 +49,69 @@ def algorithmic_flops(spec, T, S, nseq):
             "attn_cross": nseq * L * (ca_attn + ca_attn2)}
 
 
+def run_pipeline(a, dev):
+    """One subject of BASELINE configs[4] on one GPU: everything after the (out-of-scope) wav2vec front end."""
+    from audio2photoreal_amd.model.cfg_sampler import ClassifierFreeSampleModel
+    from audio2photoreal_amd.model.guide import GuideTransformer
+    from audio2photoreal_amd.model.vqvae import TemporalVertexCodec
+    from audio2photoreal_amd.model_util import create_model_and_diffusion, default_args, load_model
+    from audio2photoreal_amd.sample.generate import _replace_keyframes
+    from audio2photoreal_amd.spec import GuideSpec, TokenizerSpec, face_spec, pose_spec
+    from audio2photoreal_amd.synthetic import (cond_tokens_for_frames, synthetic_guide_state_dict, synthetic_state_dict, synthetic_tensor,
+                                               synthetic_tokenizer_state_dict)
+    B, T = a.batch, a.frames
+    S0, gs, ts = cond_tokens_for_frames(T), GuideSpec(), TokenizerSpec()
+    guide = GuideTransformer(tokens=gs.tokens, num_layers=gs.num_layers, dim=gs.dim, emb_len=gs.emb_len,
+                             num_audio_layers=gs.num_audio_layers, max_batch=B, max_positions=96)
+    guide.load_state_dict(synthetic_guide_state_dict(gs, 10), strict=False)
+    tok = TemporalVertexCodec(ts.n_vertices, ts.latent_dim, ts.categories, ts.residual_depth)
+    tok.load_state_dict(synthetic_tokenizer_state_dict(ts, 10), strict=False)
+    models = {}
+    for fmt, spec in (("pose", pose_spec()), ("face", face_spec())):
+        m, d = create_model_and_diffusion(default_args(fmt, timestep_respacing="ddim100"), "test", precision=a.precision, max_batch=B)
+        load_model(m, synthetic_state_dict(spec, 10))
+        if fmt == "pose":
+            m.setup_guide_predictor(guide.to(dev).eval(), tok.to(dev))
+        models[fmt] = (spec, ClassifierFreeSampleModel(m.to(dev).eval()), d)
+    nk = len(range(T)[::30])
+    feats = synthetic_tensor(10, "pipeline_audio_feats", (B, S0, 1024)).to(dev)
+    lip = synthetic_tensor(10, "pipeline_lip_feats", (B, S0, 1014)).to(dev)
+
+    def once():
+        guide._prepared_for = None                     # every run pays the hoisted conditioning of all three models
+        for _, cfg_m, _ in models.values():
+            cfg_m.model._cond_key = None
+        torch.cuda.synchronize()
+        st, t0 = {}, time.perf_counter()
+
+        def mark(name):
+            nonlocal t0
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            st[name], t0 = (t1 - t0) * 1e3, t1
+        spec, cfg, diff = models["pose"]
+        y = {"cond_embed": feats, "keyframes": torch.zeros(B, nk, 104, device=dev), "mask": torch.ones(B, 1, 1, T, dtype=torch.bool, device=dev),
+             "scale": torch.full((B,), 2.0, device=dev)}
+        y["keyframes"] = _replace_keyframes({"y": y}, cfg).to(dev)
+        mark("guide_tokens_and_vq_decode_ms")
+        body = diff.ddim_sample_loop(cfg, (B, spec.nfeats, 1, T), clip_denoised=False, model_kwargs={"y": y})
+        mark("body_ddim100_ms")
+        spec, cfg, diff = models["face"]
+        yf = {"cond_embed": torch.cat([feats, lip], -1), "scale": torch.full((B,), 10.0, device=dev)}
+        face = diff.ddim_sample_loop(cfg, (B, spec.nfeats, 1, T), clip_denoised=False, model_kwargs={"y": yf})
+        mark("face_ddim100_ms")
+        assert bool(torch.isfinite(body).all()) and bool(torch.isfinite(face).all())
+        return st
+    once()                                    # contexts, weight upload, allocator warm-up
+    st = once()
+    total = sum(st.values()) / 1e3
+    print(json.dumps({"metric": "end-to-end sec/sample: guide transformer -> body ddim100 -> face ddim100, 600 frames, from audio features "
+                                "(BASELINE configs[4] shape, one subject, one GPU; the wav2vec front end is out of scope)",
+                      "value": round(total / B, 5), "unit": "s/sample", "higher_is_better": False, "n_gpus": 1, "batch": B,
+                      "dtype": a.precision, "data": "synthetic", "total_s": round(total, 4),
+                      "stages_ms": {k: round(v, 2) for k, v in st.items()}}))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -59,6 +122,9 @@ def main():
     ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--model", default="face", choices=["face", "pose"],
                     help="face = BASELINE configs[1] (the metric's config, default); pose = configs[2] shape (body model, keyframes, scale 2)")
+    ap.add_argument("--pipeline", action="store_true",
+                    help="instead of the step benchmark: BASELINE configs[4] shape on this GPU for one subject -- audio features -> "
+                         "guide transformer tokens -> VQ keyframes -> body ddim100 -> face ddim100 (demo/demo.py:156-216), sec/sample")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
     a = ap.parse_args()
@@ -96,6 +162,8 @@ def main():
     from audio2photoreal_amd.spec import face_spec, pose_spec
     from audio2photoreal_amd.synthetic import cond_tokens_for_frames, synthetic_state_dict, synthetic_tensor
 
+    if a.pipeline:
+        return run_pipeline(a, dev)
     spec = face_spec() if a.model == "face" else pose_spec()
     B, T = a.batch, a.frames
     S0 = cond_tokens_for_frames(T)
