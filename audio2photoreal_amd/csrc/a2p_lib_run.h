@@ -358,7 +358,7 @@ extern "C" int a2p_prepare_cond(a2p_ctx* c, const float* cond_embed, int32_t B, 
   }
   ARG(B >= 1 && B <= c->Bmax, "batch %d exceeds max_batch %d", B, c->Bmax);
   ARG(S0 >= 1 && S0 <= c->S0max, "n_tok %d exceeds emb_len %d", S0, c->S0max);
-  ARG(T >= 1 && T <= c->Tmax && T % 4 == 0, "frames %d must be a multiple of 4 and <= %d", T, c->Tmax);
+  ARG(T >= 1 && T <= c->Tmax, "frames %d outside [1, %d]", T, c->Tmax);
   if (c->pose) ARG(keyframes && n_key >= 1 && n_key <= c->KFmax, "pose model needs keyframes (1..%d)", c->KFmax);
   hipStream_t s = (hipStream_t)stream;
   const int d = c->d, M = B * S0;
@@ -771,7 +771,7 @@ extern "C" int a2p_decoder_layer_forward(a2p_ctx* c, int32_t layer, float* x, co
     set_err("a2p_decoder_layer_forward before a2p_finalize_weights");
     return A2P_ERR_STATE;
   }
-  ARG(layer >= 0 && layer < c->L && N >= 1 && N <= c->Nmax && T >= 1 && T <= c->Tmax && T % 4 == 0, "bad layer/shape");
+  ARG(layer >= 0 && layer < c->L && N >= 1 && N <= c->Nmax && T >= 1 && T <= c->Tmax, "bad layer/shape");
   ARG(S >= 1 && S <= c->S0max + 2 && (int64_t)N * S <= c->rows_cap, "bad memory length");
   ARG(!memory2 || (c->pose && S2 >= 1 && S2 <= 64), "bad memory2");
   hipStream_t s = (hipStream_t)stream;

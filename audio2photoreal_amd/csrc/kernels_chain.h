@@ -517,11 +517,22 @@ __global__ __launch_bounds__(64 * NW, 1) void chain_kernel(const ChainP p) {
           if (!transposed) {
             if (m0 + mt * 16 + l15 >= p.M) continue;
             chain_st_bf4(out + (int64_t)row_m[mt] * ldo + col_of(t, j), o);
-          } else {  // rows m .. m+3 (m % 4 == 0, rows_per_seq % 4 == 0: never straddle a sequence), column n
+          } else {  // rows m .. m+3 (m % 4 == 0) of column n: one 8-byte store when the frame count is a multiple of 4 (the
+                    // four rows then share a sequence and the address is aligned), else row by row (T = 30 k frames, k odd)
             const int m = m0 + mt * 16 + g * 4;
             if (m >= p.M) continue;
             const int sq = m / p.rows_per_seq, n = t * 128 + wid * CW + j * 16 + l15;
-            chain_st_bf4(out + (int64_t)sq * p.vt_seq_stride + (int64_t)n * ldo + (m - sq * p.rows_per_seq), o);
+            if ((p.rows_per_seq & 3) == 0) {
+              chain_st_bf4(out + (int64_t)sq * p.vt_seq_stride + (int64_t)n * ldo + (m - sq * p.rows_per_seq), o);
+            } else {
+#pragma unroll
+              for (int r = 0; r < 4; ++r) {
+                const int mm = m + r;
+                if (mm >= p.M) break;
+                const int s2 = mm / p.rows_per_seq;
+                out[(int64_t)s2 * p.vt_seq_stride + (int64_t)n * ldo + (mm - s2 * p.rows_per_seq)] = o[r];
+              }
+            }
           }
         }
       }

@@ -295,8 +295,33 @@ def test_chain_kernels_match_the_per_op_kernels_bf16(dev, golden, fmt, mt, monke
     assert e_pair < 3e-2 and e_gold < 0.25 and e_gold < 2.0 * e_old + 1e-3
 
 
+@pytest.mark.parametrize("fmt,B,frames", [("face", 4, 150), ("pose", 5, 210)])
+def test_chain_kernels_with_frame_counts_that_are_not_a_multiple_of_4(dev, fmt, B, frames, monkeypatch):
+    """The reference derives the frame count from the audio length (demo/demo.py: int(len/sr) * 30), so T = 150, 210, ... occur:
+    4-row groups of the transposed V^T store then straddle sequences.  Chain path == per-op path, and both close to the oracle."""
+    from oracle import a2p_oracle as O
+    spec, model = get_model(fmt, "bf16", dev)
+    inp = synthetic_inputs(spec, B, frames, SEED)
+    scale = 10.0 if fmt == "face" else 2.0
+    y = y_for(spec, inp, dev, scale)
+    times = torch.tensor([999, 500, 250, 3, 77][:B], device=dev)
+    x = inp["x_T"].to(dev)
+    cfg = ClassifierFreeSampleModel(model)
+    monkeypatch.delenv("A2P_NO_CHAIN", raising=False)
+    chained = cfg(x, times, y).cpu()
+    monkeypatch.setenv("A2P_NO_CHAIN", "1")
+    per_op = cfg(x, times, y).cpu()
+    monkeypatch.delenv("A2P_NO_CHAIN")
+    den = O.OracleDenoiser(synthetic_state_dict(spec, SEED), fmt, spec.num_layers, spec.num_heads, torch.float32)
+    ref = den.forward_cfg(inp["x_T"][:2], times[:2].cpu(), inp["cond_embed"][:2], torch.full((2,), scale),
+                          inp.get("keyframes", [None])[:2] if spec.is_pose else None, inp["mask"][:2] if spec.is_pose else None)
+    e_pair, e_ref = rel_l2(chained, per_op), rel_l2(chained[:2], ref)
+    print(f"T={frames} {fmt}: chain vs per-op {e_pair:.3e}, chain vs oracle {e_ref:.3e}, per-op vs oracle {rel_l2(per_op[:2], ref):.3e}")
+    assert e_pair < 3e-2 and e_ref < 0.25
+
+
 # ----------------------------------------------------------------------------- edge shapes / sampler API surface
-@pytest.mark.parametrize("fmt,B,frames", [("face", 1, 100), ("pose", 3, 64), ("face", 2, 4)])
+@pytest.mark.parametrize("fmt,B,frames", [("face", 1, 100), ("pose", 3, 64), ("face", 2, 4), ("face", 2, 30), ("pose", 2, 90)])
 def test_edge_shapes_fp32_vs_oracle(dev, fmt, B, frames):
     """Ragged sizes the reference accepts: frames not a multiple of the 64/128 tile sizes, token counts not a multiple of
     64, odd batch, partially masked keyframes, the minimum frame count.  fp32 mode vs the pinned oracle, <= 1e-3."""
