@@ -12,6 +12,7 @@
 //   time-token K / V tail    fp32 [B*2][L*d]
 #include <hip/hip_runtime.h>
 #include <hip/hip_ext.h>
+#include <tuple>
 #include <math.h>
 #include <stdarg.h>
 #include <stdio.h>
@@ -140,8 +141,13 @@ struct a2p_ctx {
   Buf cak_w32, cak_b, cav_w32, cav_b, cak_wt, cav_wt;
   Buf ca2k_wt, ca2v_wt, ca2k_b, ca2v_b;
   Buf conv_wt[7];
-  std::vector<Buf> ch_stream, ch_aux;  // packed weight streams / bias blocks of the chain kernels, [layer*4 + kind]
-  int ch_nw = 4;                       // waves per chain workgroup the streams were packed for (slice = 128/ch_nw out-cols)
+  std::vector<Buf> ch_stream, ch_aux;  // packed weight streams [(nw == 8) * L*4 + layer*4 + kind] / bias blocks [layer*4 + kind]
+  int ch_nw = 4;                       // waves per chain workgroup of the forward being enqueued (4 or 8; chain_pick_nw)
+  struct ChainTune {                   // per forward size (rows): which workgroup shape is faster ON THIS BOX, measured in situ
+    int choice = 0, calls = 0;
+    std::vector<std::tuple<int, hipEvent_t, hipEvent_t>> samples;
+  };
+  std::map<int64_t, ChainTune> ch_tune;
   Buf hidden, kc, vtc, k2c, vt2c, slot_cond, slot_unc, slot_cfg;
   std::vector<int> h_slots;
   int pB = 0, pS0 = 0, pT = 0, pK = 0;
@@ -450,6 +456,8 @@ extern "C" int a2p_ctx_destroy(a2p_ctx* c) {
   for (Buf* b : all) buf_free(*b);
   for (int i = 0; i < 7; ++i) buf_free(c->conv_wt[i]);
   for (auto& b : c->ch_stream) buf_free(b);
+  for (auto& kv : c->ch_tune)
+    for (auto& sm : kv.second.samples) { (void)hipEventDestroy(std::get<1>(sm)); (void)hipEventDestroy(std::get<2>(sm)); }
   for (auto& b : c->ch_aux) buf_free(b);
   for (void* slab : c->arena.slabs) (void)hipFree(slab);
   for (int i = 0; i < 8; ++i) {

@@ -113,13 +113,15 @@ static void pk_gemm(std::vector<ChainPackDesc>& v, const void* W, int ldw, int n
 
 static int chain_pack(a2p_ctx* c, int idx, const std::vector<ChainPackDesc>& descs, const std::vector<std::pair<const float*, int>>& aux,
                       hipStream_t s) {
-  Buf& st = c->ch_stream[idx];
   const size_t pad = CHAIN_STREAM_PAD;  // the DMA runs up to NS-1 (<= 5) stages past the end
-  CHK(buf_alloc(st, (descs.size() + pad) * CHAIN_STAGE_ELEMS * 2));
   Buf dd;
   CHK(buf_alloc_tmp(dd, descs.size() * sizeof(ChainPackDesc)));
   HIPCHK(hipMemcpyAsync(dd.p, descs.data(), descs.size() * sizeof(ChainPackDesc), hipMemcpyHostToDevice, s));
-  chain_pack_kernel<<<(int)descs.size(), 256, 0, s>>>(reinterpret_cast<const ChainPackDesc*>(dd.p), reinterpret_cast<bf16_t*>(st.p), c->ch_nw);
+  for (int w8 = 0; w8 < 2; ++w8) {  // both slice layouts: 4 waves x 32 out-cols and 8 waves x 16 (chain_pick_nw chooses per box)
+    Buf& st = c->ch_stream[(size_t)w8 * c->L * 4 + idx];
+    CHK(buf_alloc(st, (descs.size() + pad) * CHAIN_STAGE_ELEMS * 2));
+    chain_pack_kernel<<<(int)descs.size(), 256, 0, s>>>(reinterpret_cast<const ChainPackDesc*>(dd.p), reinterpret_cast<bf16_t*>(st.p), w8 ? 8 : 4);
+  }
   HIPCHK(hipGetLastError());
   Buf& ax = c->ch_aux[idx];
   CHK(buf_alloc(ax, 2560 * 4 + 1024));
@@ -136,12 +138,8 @@ static int chain_pack(a2p_ctx* c, int idx, const std::vector<ChainPackDesc>& des
 // pre-pack every chain's weight stream in consumption order (called from a2p_finalize_weights)
 static int chain_build_streams(a2p_ctx* c, hipStream_t s) {
   const int d = c->d, ff = c->ff, L = c->L;
-  // waves per chain workgroup: 4 (one 512-register wave per SIMD, default) or 8 (two per SIMD; faster only while the stream
-  // is L2-warm, which the attention kernels between two chain launches prevent -- DESIGN.md section 4)
-  const char* nwe = getenv("A2P_CHAIN_NW");
-  c->ch_nw = nwe && atoi(nwe) == 8 ? 8 : 4;
-  if (c->ch_stream.size() != (size_t)L * 4) {  // first build; later builds (weight updates) refill the same buffers
-    c->ch_stream.assign((size_t)L * 4, Buf());
+  if (c->ch_stream.size() != (size_t)L * 8) {  // first build; later builds (weight updates) refill the same buffers
+    c->ch_stream.assign((size_t)L * 8, Buf());
     c->ch_aux.assign((size_t)L * 4, Buf());
   }
   auto pf = [&](int l) { return "seqTransDecoder.stack." + std::to_string(l) + "."; };
@@ -188,7 +186,7 @@ static void chain_base(a2p_ctx* c, ChainP& p, int N, int T, int idx, int aux_flo
   memset(&p, 0, sizeof(p));
   p.M = N * T; p.rows_per_seq = T; p.x = c->x.f(); p.cs = reinterpret_cast<const float2*>(c->rope_cs.p);
   p.ain = reinterpret_cast<const bf16_t*>(c->ao.p); p.ld_ain = c->d;
-  p.stream = reinterpret_cast<const bf16_t*>(c->ch_stream[idx].p);
+  p.stream = reinterpret_cast<const bf16_t*>(c->ch_stream[(size_t)(c->ch_nw == 8) * c->L * 4 + idx].p);
   p.aux = c->ch_aux[idx].f(); p.aux_kb = (aux_floats + 255) / 256;
 }
 
@@ -209,6 +207,48 @@ static void chain_set_out_proj(a2p_ctx* c, ChainP& p, const std::string& attn, c
   if (fr.base) {
     p.film_o = fr.base + (int64_t)film_idx * 2 * d; p.film_seq_stride = fr.seq_stride; p.film_shift_off = d;
   }
+}
+
+// Workgroup shape of the chain kernels for a forward of `rows` rows: 4 waves (one 512-register wave per SIMD) or 8 (two
+// 256-register waves per SIMD, panels of at most 48 / 64 rows).  Both give bit-identical results (kernels_chain.h ln_stats).
+// Which one is faster depends on the BOX, not on the code: on most MI355X boxes NW=4 leads by 3-5 % at B=8, on a sizeable
+// minority the 512-register kernels run 35 % slower inside the step (not in isolation) and NW=8 leads by 19 % (DESIGN.md
+// section 6).  So it is measured in situ: forwards 1..4 of a given size alternate the two shapes with an event pair around
+// the decoder stack (forward 0 is warm-up), forward 5 picks the faster average and the choice sticks.  A2P_CHAIN_NW=4|8 forces.
+static const int kTuneForwards = 5;
+static int chain_pick_nw(a2p_ctx* c, int64_t rows, hipEvent_t* e0, hipEvent_t* e1) {
+  *e0 = *e1 = nullptr;
+  if (const char* f = getenv("A2P_CHAIN_NW")) return atoi(f) == 8 ? 8 : 4;
+  if (const char* m = getenv("A2P_CHAIN_MT")) {  // a forced panel height the 8-wave kernels do not have
+    const int mt = atoi(m);
+    if (mt > (c->d == 512 ? 3 : 4)) return 4;
+  }
+  auto& t = c->ch_tune[rows];
+  if (t.choice) return t.choice;
+  const int call = t.calls++;
+  if (call < kTuneForwards) {
+    const int nw = (call & 1) ? 8 : 4;
+    if (call >= 1 && hipEventCreate(e0) == hipSuccess && hipEventCreate(e1) == hipSuccess) t.samples.emplace_back(nw, *e0, *e1);
+    else *e0 = *e1 = nullptr;
+    return nw;
+  }
+  double sum[2] = {0, 0};
+  int cnt[2] = {0, 0};
+  for (auto& sm : t.samples) {
+    float ms = 0.f;
+    if (hipEventSynchronize(std::get<2>(sm)) == hipSuccess && hipEventElapsedTime(&ms, std::get<1>(sm), std::get<2>(sm)) == hipSuccess) {
+      sum[std::get<0>(sm) == 8] += ms;
+      ++cnt[std::get<0>(sm) == 8];
+    }
+    (void)hipEventDestroy(std::get<1>(sm));
+    (void)hipEventDestroy(std::get<2>(sm));
+  }
+  t.samples.clear();
+  t.choice = (cnt[0] && cnt[1] && sum[1] / cnt[1] < sum[0] / cnt[0]) ? 8 : 4;
+  if (getenv("A2P_TUNE_VERBOSE"))
+    fprintf(stderr, "[a2p] chain workgroup shape for %lld rows: NW=4 %.3f ms, NW=8 %.3f ms -> %d\n", (long long)rows,
+            cnt[0] ? sum[0] / cnt[0] : -1.0, cnt[1] ? sum[1] / cnt[1] : -1.0, t.choice);
+  return t.choice;
 }
 
 static int launch_chain(a2p_ctx* c, int mode, const ChainP& p, hipStream_t s) {
@@ -519,6 +559,11 @@ static int run_forward(a2p_ctx* c, const float* x_in, const int64_t* t_orig, int
                                                              reinterpret_cast<float4*>(c->x.f() + (size_t)B * T * d), n4);
     }
   }
+  hipEvent_t tune0 = nullptr, tune1 = nullptr;
+  if (use_chain) {
+    c->ch_nw = chain_pick_nw(c, (int64_t)N * T, &tune0, &tune1);
+    if (tune0) HIPCHK(hipEventRecord(tune0, s));
+  }
   CrossKV kv, kv2;
   for (int l = 0; l < L; ++l) {
     kv.K = c->offT(c->kc, (int64_t)l * d); kv.k_slot_stride = (int64_t)c->Sld * L * d; kv.ldk = (int64_t)L * d;
@@ -539,6 +584,7 @@ static int run_forward(a2p_ctx* c, const float* x_in, const int64_t* t_orig, int
                               /*fuse_final=*/!c->pose));
     else CHK(decoder_layer(c, l, N, T, kv, c->pose ? &kv2 : nullptr, fr, s));
   }
+  if (tune1) HIPCHK(hipEventRecord(tune1, s));
   // final_layer (model/diffusion.py:397): cast the stream, GEMM   (face + chain mode: already done by the last POST kernel)
   if (use_chain && !c->pose) {
     *mo_seq_rows = T;

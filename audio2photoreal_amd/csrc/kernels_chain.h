@@ -151,15 +151,15 @@ __global__ __launch_bounds__(64 * NW, 1) void chain_kernel(const ChainP p) {
   constexpr int FT = 8;          // ff_size / 128
   constexpr int HLD = 128;       // hidden chunk row stride
   constexpr int AUX_F = 2560;    // floats of per-tile biases (10 KiB)
-  constexpr int FIXED = BM * D + BM * HLD + 4 * NW * BM + 2 * AUX_F;  // bf16 elements before the ring
+  constexpr int FIXED = BM * D + BM * HLD + 32 * BM + 2 * AUX_F;  // bf16 elements before the ring
   constexpr int NS = (160 * 1024 / 2 - FIXED) / CHAIN_STAGE_ELEMS > 6 ? 6 : (160 * 1024 / 2 - FIXED) / CHAIN_STAGE_ELEMS;
   static_assert(NS >= 3, "panel too tall for a 3-deep weight ring");
   constexpr int WSLICE = CHAIN_STAGE_ELEMS / NW;  // elements per wave per stage
   __shared__ __attribute__((aligned(16))) bf16_t smem[FIXED + NS * CHAIN_STAGE_ELEMS];
   bf16_t* const panelA = smem;
   bf16_t* const panelH = panelA + BM * D;
-  float* const red = reinterpret_cast<float*>(panelH + BM * HLD);  // [2][NW][BM]
-  float* const aux = red + 2 * NW * BM;                                  // [AUX_F]
+  float* const red = reinterpret_cast<float*>(panelH + BM * HLD);  // [2][8][BM]: LayerNorm partial sums per 16-column group
+  float* const aux = red + 16 * BM;                                  // [AUX_F]
   bf16_t* const ring = reinterpret_cast<bf16_t*>(aux + AUX_F);      // [wave][NS][32][64]
 
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
@@ -397,43 +397,56 @@ __global__ __launch_bounds__(64 * NW, 1) void chain_kernel(const ChainP p) {
   };
   // LayerNorm statistics of the register rows (eps 1e-5, biased variance, two-pass like ln_rope_kernel)
   float ln_mean[MT], ln_rstd[MT];
-  auto wave_partials = [&](const float* q) __attribute__((always_inline)) {  // pairwise sum of the NW per-wave partials
-    float s4 = (q[0] + q[BM]) + (q[2 * BM] + q[3 * BM]);
-    if constexpr (NW == 8) s4 += (q[4 * BM] + q[5 * BM]) + (q[6 * BM] + q[7 * BM]);
-    return s4;
+  // The row statistics are reduced over EIGHT partials per row -- one per 16-column group of a 128-column tile, i.e. per wave
+  // with NW = 8 and per (wave, half) with NW = 4 -- in one fixed tree, so both workgroup shapes produce bit-identical rows
+  // (the run-time choice between them, a2p_lib_run.h `chain_pick_nw`, is then invisible in the results).
+  auto group_partials = [&](const float* q) __attribute__((always_inline)) {
+    return ((q[0] + q[BM]) + (q[2 * BM] + q[3 * BM])) + ((q[4 * BM] + q[5 * BM]) + (q[6 * BM] + q[7 * BM]));
   };
   auto ln_stats = [&]() __attribute__((always_inline)) {
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
-      float s = 0.f;
+      float s[NJ];
 #pragma unroll
-      for (int ns = 0; ns < NSUB; ++ns) s += (xrow[mt][ns][0] + xrow[mt][ns][1]) + (xrow[mt][ns][2] + xrow[mt][ns][3]);
-      s += __shfl_xor(s, 16, 64);
-      s += __shfl_xor(s, 32, 64);
-      if (g == 0) red[wid * BM + mt * 16 + l15] = s;
+      for (int j = 0; j < NJ; ++j) s[j] = 0.f;
+#pragma unroll
+      for (int ns = 0; ns < NSUB; ++ns) s[ns % NJ] += (xrow[mt][ns][0] + xrow[mt][ns][1]) + (xrow[mt][ns][2] + xrow[mt][ns][3]);
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) {
+        float v = s[j];
+        v += __shfl_xor(v, 16, 64);
+        v += __shfl_xor(v, 32, 64);
+        if (g == 0) red[(wid * NJ + j) * BM + mt * 16 + l15] = v;
+      }
     }
     chain_bar();
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
       const int r = mt * 16 + l15;
-      ln_mean[mt] = wave_partials(red + r) * (1.0f / D);
-      float q = 0.f;
+      ln_mean[mt] = group_partials(red + r) * (1.0f / D);
+      float q[NJ];
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) q[j] = 0.f;
 #pragma unroll
       for (int ns = 0; ns < NSUB; ++ns)
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           const float dlt = xrow[mt][ns][e] - ln_mean[mt];
-          q += dlt * dlt;
+          q[ns % NJ] += dlt * dlt;
         }
-      q += __shfl_xor(q, 16, 64);
-      q += __shfl_xor(q, 32, 64);
-      if (g == 0) red[NW * BM + wid * BM + r] = q;
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) {
+        float v = q[j];
+        v += __shfl_xor(v, 16, 64);
+        v += __shfl_xor(v, 32, 64);
+        if (g == 0) red[8 * BM + (wid * NJ + j) * BM + r] = v;
+      }
     }
     chain_bar();
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
       const int r = mt * 16 + l15;
-      const float var = wave_partials(red + NW * BM + r) * (1.0f / D);
+      const float var = group_partials(red + 8 * BM + r) * (1.0f / D);
       ln_rstd[mt] = 1.0f / sqrtf(var + 1e-5f);
     }
   };

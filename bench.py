@@ -211,6 +211,11 @@ def main():
         torch.cuda.synchronize()
 
     with torch.no_grad():
+        # one-off setup like the weight upload above: the library measures which chain-kernel workgroup shape is faster on THIS
+        # box during the first 6 forwards of a given size (csrc/a2p_lib_run.h chain_pick_nw; both shapes give identical bits)
+        for _ in range(6):
+            cfg(x, steps_idx[0], y)
+        torch.cuda.synchronize()
         run_steps(a.warmup)
         barrier()
         t0 = time.perf_counter()
