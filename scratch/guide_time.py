@@ -6,7 +6,7 @@ from audio2photoreal_amd.spec import GuideSpec
 from audio2photoreal_amd.synthetic import synthetic_guide_state_dict, synthetic_tensor
 dev = torch.device("cuda:0")
 gs = GuideSpec()
-for B in (1, 8, 32):
+for B in (tuple(int(v) for v in os.environ.get("GUIDE_B", "1,8,32").split(","))):
     g = GuideTransformer(tokens=gs.tokens, num_layers=gs.num_layers, dim=gs.dim, emb_len=gs.emb_len, num_audio_layers=gs.num_audio_layers,
                          max_batch=B, max_positions=96)
     g.load_state_dict(synthetic_guide_state_dict(gs, 10), strict=False)
