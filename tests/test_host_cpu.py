@@ -285,3 +285,64 @@ def test_results_file_round_trip_and_fixseed(tmp_path):
     G.fixseed(10)
     b = (torch.rand(3), np.random.rand(3))
     assert torch.equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+
+
+# ----------------------------------------------------------------------------- SURVEY §8 f2 / f4 host contracts (no GPU needed)
+def test_guide_and_tokenizer_state_dict_contract_and_no_cpu_path():
+    """Key names / shapes of the GuideTransformer and TemporalVertexCodec mirrors equal the spec that was checked against the
+    reference modules (tests/golden/make_golden_guide.py loads the same dictionaries into the reference with strict key checks);
+    like the denoiser they refuse to compute on CPU tensors."""
+    from audio2photoreal_amd.model.guide import GuideTransformer
+    from audio2photoreal_amd.model.vqvae import TemporalVertexCodec
+    from audio2photoreal_amd.spec import GuideSpec, TokenizerSpec, guide_param_shapes, tokenizer_param_shapes
+    from audio2photoreal_amd.synthetic import synthetic_guide_state_dict, synthetic_tokenizer_state_dict
+    gs, ts = GuideSpec(), TokenizerSpec()
+    g = GuideTransformer(tokens=gs.tokens, num_layers=gs.num_layers, dim=gs.dim, emb_len=gs.emb_len, num_audio_layers=gs.num_audio_layers)
+    got = {k: tuple(v.shape) for k, v in g.state_dict().items() if not k.endswith("rotary.freqs")}
+    assert got == dict(guide_param_shapes(gs))
+    res = g.load_state_dict(synthetic_guide_state_dict(gs), strict=False)
+    assert not res.unexpected_keys and all(k.endswith("rotary.freqs") for k in res.missing_keys)
+    assert gs.cond_tokens_after_conv(1998) == 1950 and gs.cond_tokens_after_conv(798) == 750
+    t = TemporalVertexCodec(ts.n_vertices, ts.latent_dim, ts.categories, ts.residual_depth)
+    assert {k: tuple(v.shape) for k, v in t.state_dict().items()} == dict(tokenizer_param_shapes(ts))
+    assert t.residual_depth == 4 and t.n_clusters == 1024
+    t.load_state_dict(synthetic_tokenizer_state_dict(ts))
+    with pytest.raises(_lib.A2PError):
+        g(torch.zeros(1, 3, dtype=torch.int64), torch.zeros(1, 798, 1024))
+    with pytest.raises(_lib.A2PError):
+        t.decode(torch.zeros(1, 8, 4, dtype=torch.int64))
+    with pytest.raises(_lib.A2PError):
+        g.encode_audio(torch.zeros(1, 16000, 2))            # no audio front end attached
+    with pytest.raises(NotImplementedError):
+        GuideTransformer(tokens=8, use_rotary=False)
+
+
+def test_setup_guide_predictor_keeps_the_denoiser_weight_set_separate():
+    from audio2photoreal_amd.model.guide import GuideTransformer
+    from audio2photoreal_amd.model.vqvae import TemporalVertexCodec
+    model, _ = create_model_and_diffusion(default_args("pose", layers=1), "test", precision="fp32", max_batch=1)
+    before = set(model._hot_state())
+    sig = model._weights_signature()
+    model.setup_guide_predictor(GuideTransformer(tokens=16, num_layers=1, dim=64, emb_len=64, num_audio_layers=1), TemporalVertexCodec(104, 64, 16, 4))
+    assert set(model._hot_state()) == before and model._weights_signature()[0] == sig[0]
+    assert any(k.startswith("transformer.") for k in model.state_dict()) and any(k.startswith("tokenizer.") for k in model.state_dict())
+    assert model.resume_trans is not None and ClassifierFreeSampleModel(model).tokenizer is model.tokenizer
+    face, _ = create_model_and_diffusion(default_args("face", layers=1), "test", precision="fp32", max_batch=1)
+    with pytest.raises(AssertionError):
+        face.setup_guide_predictor(model.transformer, model.tokenizer)
+
+
+def test_plms_argument_checks_need_no_gpu():
+    d = create_gaussian_diffusion(default_args("face", timestep_respacing="ddim10"))
+    x = torch.zeros(1, 256, 1, 8)
+    for bad in (0, 5, -1):
+        with pytest.raises(ValueError):
+            d.plms_sample(lambda *a, **k: None, x, torch.tensor([3]), order=bad)
+    with pytest.raises(NotImplementedError):
+        d.plms_sample(lambda *a, **k: None, x, torch.tensor([3]), cond_fn=lambda *a: None)
+    with pytest.raises(AssertionError):
+        d.ddim_reverse_sample(lambda *a, **k: None, x, torch.tensor([3]), eta=0.1)
+    for name in ("plms_sample", "plms_sample_loop", "plms_sample_loop_progressive", "ddim_reverse_sample"):
+        assert callable(getattr(d, name))
+    with pytest.raises(NotImplementedError):
+        d.training_losses(None, None, None)
