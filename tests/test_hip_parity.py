@@ -320,6 +320,30 @@ def test_chain_kernels_with_frame_counts_that_are_not_a_multiple_of_4(dev, fmt, 
     assert e_pair < 3e-2 and e_ref < 0.25
 
 
+@pytest.mark.parametrize("fmt,B,frames", [("face", 4, 240)])
+def test_chain_workgroup_shapes_are_bit_identical(dev, fmt, B, frames, monkeypatch):
+    """The library picks the 4- or the 8-wave chain workgroup shape per box from in-situ timings (chain_pick_nw), so the two
+    must agree to the last bit: same GEMM accumulation order per output, one shared 8-partial LayerNorm reduction tree.
+    (Also verified by output digests at face B=8 / B=32 and pose B=16, T=600: scratch/ab_hash.py.  OPEN: pose B=3, T=450 -- a
+    ragged last panel with a frame count that is not a multiple of 4 -- did NOT compare equal in the one run the GPU budget
+    allowed; which of the two it is, and whether the shapes or the run-to-run order differ, is the first thing to settle next
+    round.  Results there are still within the bf16 tolerances: test_chain_kernels_with_frame_counts_that_are_not_a_multiple_of_4.)"""
+    spec, model = get_model(fmt, "bf16", dev)
+    inp = synthetic_inputs(spec, B, frames, SEED)
+    y = y_for(spec, inp, dev, 10.0 if fmt == "face" else 2.0)
+    times = torch.tensor([901, 417, 33, 0][:B], device=dev)
+    x = inp["x_T"].to(dev)
+    cfg = ClassifierFreeSampleModel(model)
+    outs = {}
+    for nw in ("4", "8"):
+        monkeypatch.setenv("A2P_CHAIN_NW", nw)
+        outs[nw] = cfg(x, times, y).clone()
+    monkeypatch.delenv("A2P_CHAIN_NW")
+    auto = [cfg(x, times, y).clone() for _ in range(7)]          # calibration forwards alternate the shapes, then one sticks
+    assert torch.equal(outs["4"], outs["8"])
+    assert all(torch.equal(a, outs["4"]) for a in auto)
+
+
 # ----------------------------------------------------------------------------- edge shapes / sampler API surface
 @pytest.mark.parametrize("fmt,B,frames", [("face", 1, 100), ("pose", 3, 64), ("face", 2, 4), ("face", 2, 30), ("pose", 2, 90)])
 def test_edge_shapes_fp32_vs_oracle(dev, fmt, B, frames):
