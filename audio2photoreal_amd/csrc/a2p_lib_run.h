@@ -525,12 +525,11 @@ static int run_forward(a2p_ctx* c, const float* x_in, const int64_t* t_orig, int
   // forward of < ~1000 rows (config 0: B=1, T=240 -> 480 rows = 10 panels) is faster as many small 2-D tiles
   // (measured: 0.99 vs 1.10 ms per step at 480 rows, equal at 1200, chain ahead from 2400 rows on).
   const bool use_chain = chain_supported(c) && ((int64_t)N * T >= 960 || getenv("A2P_CHAIN_MT"));
-  // The time path (7 latency-bound launches, ~70 us at B=8) is not needed before the first out_proj epilogue and could run
-  // on the side stream next to input projection / norm1+QKV / self attention of layer 0 (-2 % step time).  OFF by default:
-  // with the two queues active, 1-30 % of forwards on SOME MI355X boxes came out different for one whole sample
-  // (scratch/stress2.py; never with the side stream off or joined immediately; rotating the events and replacing the
-  // hipMemcpyAsync did not help; every buffer either stream writes is private to it until the join).  Until that is
-  // understood the overlap is opt-in: A2P_SIDE_STREAM=1.
+  // The time path (7 latency-bound launches, ~70 us at B=8) is not needed before the first out_proj epilogue and can run on
+  // the side stream next to input projection / norm1+QKV / self attention of layer 0 (-2 % step time).  Opt-in
+  // (A2P_SIDE_STREAM=1): with the two queues active, 1-30 % of forwards on some boxes used to differ for one sample; that was
+  // traced to tpath_post_kernel consuming a load right behind its s_waitcnt (kernels_misc.h, DESIGN.md section 6
+  // "Reproducibility") and fixed there -- 0 / 1500 differing forwards since -- but 2 % is inside the box-to-box spread.
   const bool overlap_tpath = use_chain && getenv("A2P_SIDE_STREAM") && !getenv("A2P_NO_SIDE_STREAM");
   if (overlap_tpath) {
     c->ev_fork = c->ev_fork_pool[c->ev_turn & 7];
