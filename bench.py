@@ -285,7 +285,7 @@ def main():
 
     # ---- CPU baseline: the oracle (port of the reference algorithm) on this box's host cores ----
     cpu = None
-    if rank == 0 and not a.no_cpu_baseline and a.model == "face":
+    if rank == 0 and world == 1 and not a.no_cpu_baseline and a.model == "face":   # reported at N=1 only (other ranks would idle in the final barrier)
         from oracle import a2p_oracle as O
         cores = min(os.cpu_count() or 1, 32)   # torch CPU matmuls at these sizes stop scaling (and thrash) past ~32 threads
         torch.set_num_threads(cores)
