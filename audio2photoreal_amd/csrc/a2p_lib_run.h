@@ -219,6 +219,10 @@ static const int kTuneForwards = 5;
 static int chain_pick_nw(a2p_ctx* c, int64_t rows, hipEvent_t* e0, hipEvent_t* e1) {
   *e0 = *e1 = nullptr;
   if (const char* f = getenv("A2P_CHAIN_NW")) return atoi(f) == 8 ? 8 : 4;
+  // d = 256 (body model): the two shapes agree bit-for-bit at B=16 / T=600 but differ at bf16-rounding level (max |diff| 2e-2)
+  // on small forwards (B=3..4, T~450) for a reason not yet found (scratch/pose_nw_check.py); until it is, the body model
+  // keeps the long-tested 4-wave shape so that results never depend on a timing decision.
+  if (c->d != 512) return 4;
   if (const char* m = getenv("A2P_CHAIN_MT")) {  // a forced panel height the 8-wave kernels do not have
     const int mt = atoi(m);
     if (mt > (c->d == 512 ? 3 : 4)) return 4;
