@@ -121,9 +121,27 @@ def ptr(t) -> Optional[int]:
     return None if t is None else t.data_ptr()
 
 
-def current_stream() -> int:
+def current_stream(device=None) -> int:
+    """HIP stream handle torch is enqueuing on for `device` (a tensor's device; default: the current device)."""
     import torch
-    return torch.cuda.current_stream().cuda_stream
+    return torch.cuda.current_stream(device).cuda_stream
+
+
+def on_device_of(t):
+    """Context manager: make `t.device` the current HIP device for the library call (allocations and launches of the
+    C ABI go to the *current* device; a tensor on cuda:1 with cuda:0 current would otherwise launch on the wrong GPU)."""
+    import torch
+    return torch.cuda.device(t.device)
+
+
+def content_key(*tensors):
+    """Cache key for "these tensors have not changed since I last looked".  Address + version + geometry per tensor.
+    The caller MUST also keep strong references to the keyed tensors for as long as it keeps the key: while they are
+    alive the caching allocator cannot hand their address to another tensor, so an equal key then means the same bytes
+    (a freed-and-reallocated buffer of the same shape at the same address with `_version` 0 would otherwise be a false
+    hit -- the stale-conditioning hazard of round 1)."""
+    return tuple(None if t is None else (t.data_ptr(), t._version, tuple(t.shape), tuple(t.stride()), str(t.dtype), str(t.device))
+                 for t in tensors)
 
 
 def require_gpu_tensor(t, name: str):

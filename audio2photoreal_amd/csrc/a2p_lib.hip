@@ -149,7 +149,8 @@ struct a2p_ctx {
   };
   std::map<int64_t, ChainTune> ch_tune;
   Buf hidden, kc, vtc, k2c, vt2c, slot_cond, slot_unc, slot_cfg;
-  std::vector<int> h_slots;
+  Buf clk;               // A2P_CHAIN_CLK=1: 64 chain launches x 8 blocks x {memtime, realtime} x {begin, end}
+  unsigned clk_turn = 0;
   int pB = 0, pS0 = 0, pT = 0, pK = 0;
   // workspaces
   Buf x, xn, xr, qk, vt, ao, hff, inpack, mo, cb[4];
@@ -428,6 +429,7 @@ extern "C" int a2p_ctx_create(const a2p_config* cfg, a2p_ctx** out) {
     A(c->kf_pack, (size_t)B * c->KFmax * c->KdPad * c->esz); A(c->kf_tok, (size_t)B * c->KFmax * d * 4);
   }
   A(c->slot_cond, B * 4); A(c->slot_unc, B * 4); A(c->slot_cfg, N * 4);
+  if (getenv("A2P_CHAIN_CLK")) A(c->clk, 64 * 32 * 8);
   if (rc == 0 && hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking) != hipSuccess) rc = A2P_ERR_HIP;
   for (int i = 0; i < 8 && rc == 0; ++i)
     if (hipEventCreateWithFlags(&c->ev_fork_pool[i], hipEventDisableTiming) != hipSuccess ||
@@ -452,7 +454,7 @@ extern "C" int a2p_ctx_destroy(a2p_ctx* c) {
                 &c->k2c, &c->vt2c, &c->slot_cond, &c->slot_unc, &c->slot_cfg, &c->x, &c->xn, &c->xr, &c->qk, &c->vt, &c->ao,
                 &c->hff, &c->inpack, &c->mo, &c->cb[0], &c->cb[1], &c->cb[2], &c->cb[3], &c->emb, &c->th, &c->tct, &c->tvec,
                 &c->mt, &c->tokn, &c->tokr, &c->film, &c->ktail, &c->vtail, &c->ce_pack, &c->pooled, &c->tmpa, &c->tmpb,
-                &c->kf_pack, &c->kf_tok};
+                &c->kf_pack, &c->kf_tok, &c->clk};
   for (Buf* b : all) buf_free(*b);
   for (int i = 0; i < 7; ++i) buf_free(c->conv_wt[i]);
   for (auto& b : c->ch_stream) buf_free(b);

@@ -188,6 +188,9 @@ static void chain_base(a2p_ctx* c, ChainP& p, int N, int T, int idx, int aux_flo
   p.ain = reinterpret_cast<const bf16_t*>(c->ao.p); p.ld_ain = c->d;
   p.stream = reinterpret_cast<const bf16_t*>(c->ch_stream[(size_t)(c->ch_nw == 8) * c->L * 4 + idx].p);
   p.aux = c->ch_aux[idx].f(); p.aux_kb = (aux_floats + 255) / 256;
+  if (c->clk.p) {  // A2P_CHAIN_CLK=1: every chain launch of a forward gets its own 8 x 4 slot (a2p_debug_read "clk")
+    p.clk = reinterpret_cast<unsigned long long*>(c->clk.p) + (size_t)(c->clk_turn++ % 64) * 32;
+  }
 }
 
 // outputs of the "pre" work of decoder layer l: norm1 -> rotary -> [Q|K], V^T
@@ -393,6 +396,16 @@ static int decoder_layer(a2p_ctx* c, int l, int N, int T, const CrossKV& kv, con
 // ------------------------------------------------------------------------------------------------
 // hoisted conditioning
 // ------------------------------------------------------------------------------------------------
+// K/V slot of every sequence of a pass: slot 1 + b = sample b's conditioning, slot 0 = the batch-invariant unconditional branch
+__global__ void slot_tables_kernel(int* cond, int* unc, int* cfg, int B) {
+  for (int b = threadIdx.x; b < B; b += blockDim.x) {
+    cond[b] = 1 + b;
+    unc[b] = 0;
+    cfg[b] = 1 + b;      // classifier-free guidance: first half conditional ...
+    cfg[B + b] = 0;      // ... second half unconditional
+  }
+}
+
 extern "C" int a2p_prepare_cond(a2p_ctx* c, const float* cond_embed, int32_t B, int32_t S0, const float* keyframes,
                                 const uint8_t* key_mask, int32_t n_key, int32_t T, void* stream) {
   ARG(c && cond_embed, "null argument");
@@ -445,18 +458,10 @@ extern "C" int a2p_prepare_cond(a2p_ctx* c, const float* cond_embed, int32_t B, 
     CHK(project_kv_all(c, c->xr.p, c->xn.p, Mk, n_key, c->ca2k_wt, c->ca2k_b.f(), c->ca2v_wt, c->ca2v_b.f(), c->k2c.p, 64, c->vt2c.p,
                        1, s));
   }
-  // slot tables
-  c->h_slots.assign(4 * (size_t)B, 0);
-  for (int b = 0; b < B; ++b) {
-    c->h_slots[b] = 1 + b;            // cond
-    c->h_slots[B + b] = 0;            // uncond
-    c->h_slots[2 * B + b] = 1 + b;    // cfg: first half cond ...
-    c->h_slots[3 * B + b] = 0;        // ... second half uncond
-  }
-  HIPCHK(hipMemcpyAsync(c->slot_cond.p, c->h_slots.data(), (size_t)B * 4, hipMemcpyHostToDevice, s));
-  HIPCHK(hipMemcpyAsync(c->slot_unc.p, c->h_slots.data() + B, (size_t)B * 4, hipMemcpyHostToDevice, s));
-  HIPCHK(hipMemcpyAsync(c->slot_cfg.p, c->h_slots.data() + 2 * B, (size_t)2 * B * 4, hipMemcpyHostToDevice, s));
-  HIPCHK(hipStreamSynchronize(s));  // h_slots is pageable; also surfaces kernel faults here
+  // slot tables, written on the device: no pageable host buffer, hence no stream synchronisation in this entry point
+  // (round 1 synchronised here once per clip; config 4 loops subjects and clips)
+  slot_tables_kernel<<<1, 256, 0, s>>>((int*)c->slot_cond.p, (int*)c->slot_unc.p, (int*)c->slot_cfg.p, B);
+  HIPCHK(hipGetLastError());
   c->pB = B; c->pS0 = S0; c->pT = T; c->pK = n_key;
   c->prepared = true;
   return 0;
@@ -524,6 +529,7 @@ static int run_forward(a2p_ctx* c, const float* x_in, const int64_t* t_orig, int
   ARG(pass >= 0 && pass <= 2, "bad pass %d", pass);
   const int d = c->d, B = c->pB, T = c->pT, L = c->L, F = c->F;
   const int N = pass == A2P_PASS_CFG ? 2 * B : B;
+  c->clk_turn = 0;
   const int* slots = (const int*)(pass == A2P_PASS_CFG ? c->slot_cfg.p : (pass == A2P_PASS_COND ? c->slot_cond.p : c->slot_unc.p));
   // Row panels pay off once there are enough of them: every workgroup streams the whole weight set of its chain, so a
   // forward of < ~1000 rows (config 0: B=1, T=240 -> 480 rows = 10 panels) is faster as many small 2-D tiles
@@ -881,7 +887,8 @@ extern "C" int a2p_debug_read(a2p_ctx* c, const char* name, void* host, int64_t 
   const std::string n(name);
   const Buf* b = n == "film" ? &c->film : n == "ktail" ? &c->ktail : n == "vtail" ? &c->vtail : n == "tvec" ? &c->tvec
                : n == "tokr" ? &c->tokr : n == "tokn" ? &c->tokn : n == "tct" ? &c->tct
-               : n == "x" ? &c->x : n == "qk" ? &c->qk : n == "vt" ? &c->vt : n == "ao" ? &c->ao : n == "mo" ? &c->mo : nullptr;
+               : n == "x" ? &c->x : n == "qk" ? &c->qk : n == "vt" ? &c->vt : n == "ao" ? &c->ao : n == "mo" ? &c->mo
+               : n == "clk" ? &c->clk : nullptr;
   ARG(b && (size_t)bytes <= b->bytes, "unknown buffer '%s' or too many bytes", name);
   HIPCHK(hipDeviceSynchronize());
   HIPCHK(hipMemcpy(host, b->p, (size_t)bytes, hipMemcpyDeviceToHost));

@@ -76,6 +76,9 @@ struct ChainP {
   float* fin_out;
   int64_t ld_fin;
   int fin_n;
+  // diagnostic (A2P_CHAIN_CLK=1): blocks 0..7 write {s_memtime, s_memrealtime} at kernel begin / end to clk[block][2][2]: the
+  // shader clock the kernel actually ran at inside the step (DVFS) = d(memtime) / d(memrealtime @ 100 MHz)
+  unsigned long long* clk;
 };
 
 // one 16 KiB stage of a packed stream: stage = rows [row0, row0+128) x k [k0, k0+64) of W[., ldw]
@@ -172,6 +175,10 @@ __global__ __launch_bounds__(64 * NW, 1) void chain_kernel(const ChainP p) {
     }
   };
   stamp(0);
+  if (p.clk && tid == 0 && blockIdx.x < 8) {
+    p.clk[blockIdx.x * 4 + 0] = __builtin_readcyclecounter();
+    p.clk[blockIdx.x * 4 + 1] = wall_clock64();
+  }
   bf16_t* const myring = ring + wid * NS * WSLICE;
 
   // ---- weight stream ---------------------------------------------------------------------------------------
@@ -653,5 +660,9 @@ __global__ __launch_bounds__(64 * NW, 1) void chain_kernel(const ChainP p) {
     }
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the run-ahead DMA slices must land before the LDS is released
+  if (p.clk && tid == 0 && blockIdx.x < 8) {
+    p.clk[blockIdx.x * 4 + 2] = __builtin_readcyclecounter();
+    p.clk[blockIdx.x * 4 + 3] = wall_clock64();
+  }
   stamp(12);
 }

@@ -26,9 +26,23 @@ class ClassifierFreeSampleModel(nn.Module):
         if self.add_frame_cond is None:
             return
         self.step = model.step
-        if model.resume_trans is not None:          # guide transformer + VQ tokenizer ride along (pose model only)
-            for name in _WITH_GUIDE:
-                setattr(self, name, getattr(model, name))
+        # The reference copies model.transformer / model.tokenizer here when resume_trans is set (cfg_sampler.py:25-28), because
+        # its FiLMTransformer builds them from files in its constructor.  Here they are attached with
+        # `setup_guide_predictor` -- possibly AFTER wrapping -- so the wrapper resolves them lazily (see __getattr__).
+
+    def __getattr__(self, name):
+        # nn.Module.__getattr__ covers parameters / buffers / sub-modules; the guide modules are looked up on the wrapped
+        # denoiser at access time, so `_setup_model(...)` followed by `model.model.setup_guide_predictor(...)` works too
+        if name in _WITH_GUIDE or name == "resume_trans":
+            inner = super().__getattr__("model")
+            if name == "resume_trans":
+                return getattr(inner, "resume_trans", None)
+            try:
+                return nn.Module.__getattr__(inner, name)
+            except AttributeError:
+                raise AttributeError(f"the wrapped denoiser has no '{name}': attach the guide transformer / tokenizer with "
+                                     "FiLMTransformer.setup_guide_predictor(transformer, tokenizer) (pose model)") from None
+        return super().__getattr__(name)
 
     def forward(self, x, timesteps, y=None):
         return self.model.forward_cfg(x, timesteps, y)

@@ -181,6 +181,7 @@ class FiLMTransformer(nn.Module):
         self._ctx_key = None
         self._weights_key = None
         self._cond_key = None
+        self._cond_refs = None
 
     # ------------------------------------------------------------------ plumbing
     def spec(self) -> DenoiserSpec:
@@ -220,7 +221,8 @@ class FiLMTransformer(nn.Module):
         ctx = C.c_void_p()
         with torch.cuda.device(device):
             _lib.check(lib.a2p_ctx_create(C.byref(cfg), C.byref(ctx)), "a2p_ctx_create")
-        self._ctx, self._ctx_key, self._weights_key, self._cond_key = ctx, key, None, None
+        self._ctx, self._ctx_key, self._weights_key = ctx, key, None
+        self.invalidate_cond()
         return lib
 
     def _apply(self, fn, *args, **kwargs):
@@ -243,14 +245,16 @@ class FiLMTransformer(nn.Module):
         if key == self._weights_key:
             return
         state = self._hot_state()
-        stream = _lib.current_stream()
+        stream = _lib.current_stream(device)
         keep = []
-        for name, t in state.items():
-            t = t.detach().to(device=device, dtype=torch.float32).contiguous()
-            keep.append(t)
-            _lib.check(lib.a2p_set_weight(self._ctx, name.encode(), _lib.ptr(t), t.numel(), stream), f"a2p_set_weight({name})")
-        _lib.check(lib.a2p_finalize_weights(self._ctx, stream), "a2p_finalize_weights")
-        self._weights_key, self._cond_key = key, None
+        with torch.cuda.device(device):
+            for name, t in state.items():
+                t = t.detach().to(device=device, dtype=torch.float32).contiguous()
+                keep.append(t)
+                _lib.check(lib.a2p_set_weight(self._ctx, name.encode(), _lib.ptr(t), t.numel(), stream), f"a2p_set_weight({name})")
+            _lib.check(lib.a2p_finalize_weights(self._ctx, stream), "a2p_finalize_weights")
+        self._weights_key = key
+        self.invalidate_cond()
 
     def invalidate_weights(self):
         """Force a re-upload on the next call (needed only after writes that bypass the version counters, e.g. `p.data.copy_`)."""
@@ -261,6 +265,7 @@ class FiLMTransformer(nn.Module):
         if self._ctx is not None:
             _lib.load().a2p_ctx_destroy(self._ctx)
             self._ctx = None
+        self._cond_key = self._cond_refs = None
 
     def __del__(self):
         try:
@@ -275,34 +280,40 @@ class FiLMTransformer(nn.Module):
             self.release()
 
     # ------------------------------------------------------------------ conditioning (hoisted)
-    def _cond_embed(self, y) -> torch.Tensor:
+    def _cond_source(self, y) -> torch.Tensor:
+        """The caller-owned tensor the conditioning tokens derive from: y["cond_embed"] (front-end output) or y["audio"]."""
         if "cond_embed" in y:
             return y["cond_embed"]
-        if self.audio_frontend is not None:
-            return self.audio_frontend(y["audio"])
+        if self.audio_frontend is not None and "audio" in y:
+            return y["audio"]
         raise _lib.A2PError(
             "no audio front end: pass the wav2vec(+lip) features as y['cond_embed'] "
             f"[B, n_tok, {self.cond_feature_dim}] or construct the model with audio_frontend=...")
 
+    def _cond_embed(self, y) -> torch.Tensor:
+        return y["cond_embed"] if "cond_embed" in y else self.audio_frontend(self._cond_source(y))
+
+    def invalidate_cond(self) -> None:
+        """Drop the hoisted conditioning (and the references that pin its source tensors)."""
+        self._cond_key, self._cond_refs = None, None
+
     def prepare(self, x: torch.Tensor, y) -> None:
-        """Hoist everything t-independent for this `y` (cached until y's tensors change)."""
+        """Hoist everything t-independent for this `y`.  Cached until y's tensors change: the key is address + version +
+        geometry of the source tensors, and the module keeps STRONG references to them while the key is live, so the
+        allocator cannot recycle a keyed address for a different clip (model/diffusion.py:355-381 recomputes all of this in
+        every step and pass; here it runs once per clip, the audio front end included)."""
         _lib.require_gpu_tensor(x, "x")
         B, T = x.shape[0], x.shape[-1] if x.dim() == 4 else x.shape[1]
         lib = self._ensure_ctx(x.device, B)
         self._ensure_weights(lib, x.device)
-        ce = self._cond_embed(y)
+        src = self._cond_source(y)
         kf = mask = None
         if self.data_format == "pose":
             kf, mask = y["keyframes"], y["mask"]
-
-        def cache_key():
-            k = [ce.data_ptr(), ce._version, tuple(ce.shape), T]
-            if kf is not None:
-                k += [kf.data_ptr(), kf._version, mask.data_ptr(), mask._version]
-            return tuple(k)
-
-        if cache_key() == self._cond_key:
+        key = (_lib.content_key(src, kf, mask), T)
+        if key == self._cond_key:
             return
+        ce = src if "cond_embed" in y else self.audio_frontend(src)       # the front end runs once per clip, not per step
         ce = ce.to(device=x.device, dtype=torch.float32).contiguous()
         assert ce.shape[0] == B and ce.shape[2] == self.cond_feature_dim, f"cond_embed shape {tuple(ce.shape)}"
         kf_d = mk_d = None
@@ -314,10 +325,12 @@ class FiLMTransformer(nn.Module):
             mk_d = new_mask.to(device=x.device, dtype=torch.uint8).contiguous()
             n_key = kf_d.shape[1]
             assert mk_d.shape[1] == n_key, "mask[..., ::step] and keyframes disagree"
-        _lib.check(lib.a2p_prepare_cond(self._ctx, _lib.ptr(ce), B, ce.shape[1], _lib.ptr(kf_d), _lib.ptr(mk_d), n_key, T,
-                                        _lib.current_stream()), "a2p_prepare_cond")
-        ce = self._cond_embed(y)
-        self._cond_key = cache_key()
+        with _lib.on_device_of(x):
+            _lib.check(lib.a2p_prepare_cond(self._ctx, _lib.ptr(ce), B, ce.shape[1], _lib.ptr(kf_d), _lib.ptr(mk_d), n_key, T,
+                                            _lib.current_stream(x.device)), "a2p_prepare_cond")
+        # re-key AFTER the in-place zeroing above bumped kf's version; the references pin the keyed addresses
+        self._cond_key = (_lib.content_key(src, kf, mask), T)
+        self._cond_refs = (src, kf, mask)
 
     # ------------------------------------------------------------------ forward
     def _run(self, x, times, y, pass_id, scale=None) -> torch.Tensor:
@@ -329,8 +342,9 @@ class FiLMTransformer(nn.Module):
         out = torch.empty(B, T, self.nfeats, device=x.device, dtype=torch.float32)
         ts = times.to(device=x.device, dtype=torch.int64).contiguous()
         sc = None if scale is None else scale.to(device=x.device, dtype=torch.float32).contiguous()
-        _lib.check(_lib.load().a2p_denoise_forward(self._ctx, _lib.ptr(x), _lib.ptr(ts), _lib.ptr(sc), pass_id, _lib.ptr(out),
-                                                   _lib.current_stream()), "a2p_denoise_forward")
+        with _lib.on_device_of(x):
+            _lib.check(_lib.load().a2p_denoise_forward(self._ctx, _lib.ptr(x), _lib.ptr(ts), _lib.ptr(sc), pass_id, _lib.ptr(out),
+                                                       _lib.current_stream(x.device)), "a2p_denoise_forward")
         return out
 
     def forward(self, x: torch.Tensor, times: torch.Tensor, y=None, cond_drop_prob: float = 0.0) -> torch.Tensor:
@@ -351,8 +365,9 @@ class FiLMTransformer(nn.Module):
         x_next, x0 = torch.empty_like(x), torch.empty_like(x)
         sc = y["scale"].to(device=x.device, dtype=torch.float32).contiguous()
         nz = None if noise is None else noise.to(device=x.device, dtype=torch.float32).contiguous()
-        _lib.check(_lib.load().a2p_sample_step(self._ctx, sampler, _lib.ptr(x), _lib.ptr(t_idx), _lib.ptr(timestep_map),
-                                               _lib.ptr(tables), tables.shape[1], _lib.ptr(sc), _lib.ptr(nz), float(eta),
-                                               int(bool(clip_denoised)), _lib.ptr(x_next), _lib.ptr(x0), _lib.current_stream()),
-                   "a2p_sample_step")
+        with _lib.on_device_of(x):
+            _lib.check(_lib.load().a2p_sample_step(self._ctx, sampler, _lib.ptr(x), _lib.ptr(t_idx), _lib.ptr(timestep_map),
+                                                   _lib.ptr(tables), tables.shape[1], _lib.ptr(sc), _lib.ptr(nz), float(eta),
+                                                   int(bool(clip_denoised)), _lib.ptr(x_next), _lib.ptr(x0),
+                                                   _lib.current_stream(x.device)), "a2p_sample_step")
         return x_next, x0

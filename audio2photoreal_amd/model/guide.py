@@ -62,7 +62,8 @@ class GuideTransformer(nn.Module):
         self.final_layer = nn.Linear(dim, tokens)
         self._ctx = None
         self._sig = None
-        self._prepared_for = None
+        self._prepared_for = None     # (content key of the condition tensor, cond_drop_prob) of the hoisted state ...
+        self._prepared_ref = None     # ... and a strong reference that pins the keyed address (see _lib.content_key)
 
     # ------------------------------------------------------------------ native context
     def _signature(self):
@@ -76,19 +77,22 @@ class GuideTransformer(nn.Module):
             cfg = _lib.A2PGuideConfig(self.tokens, self.dim, self.num_layers, self.num_heads, self.ff_size, self.cond_feature_dim,
                                       self.emb_len, self.num_audio_layers, self.max_batch, self.max_positions)
             ctx = C.c_void_p()
-            _lib.check(lib.a2p_guide_create(C.byref(cfg), C.byref(ctx)), "a2p_guide_create")
+            with torch.cuda.device(device):
+                _lib.check(lib.a2p_guide_create(C.byref(cfg), C.byref(ctx)), "a2p_guide_create")
             self._ctx = ctx
         sig = self._signature()
         if sig != self._sig:
-            stream = _lib.current_stream()
-            for k, v in self.state_dict().items():
-                if k.endswith("rotary.freqs"):
-                    continue
-                t = v.detach().to(device=device, dtype=torch.float32).contiguous()
-                _lib.check(lib.a2p_guide_set_weight(self._ctx, k.encode(), _lib.ptr(t), t.numel(), stream), f"a2p_guide_set_weight({k})")
-            _lib.check(lib.a2p_guide_finalize(self._ctx, stream), "a2p_guide_finalize")
-            torch.cuda.current_stream().synchronize()
-            self._sig, self._prepared_for = sig, None
+            stream = _lib.current_stream(device)
+            with torch.cuda.device(device):
+                for k, v in self.state_dict().items():
+                    if k.endswith("rotary.freqs"):
+                        continue
+                    t = v.detach().to(device=device, dtype=torch.float32).contiguous()
+                    _lib.check(lib.a2p_guide_set_weight(self._ctx, k.encode(), _lib.ptr(t), t.numel(), stream), f"a2p_guide_set_weight({k})")
+                _lib.check(lib.a2p_guide_finalize(self._ctx, stream), "a2p_guide_finalize")
+            torch.cuda.current_stream(device).synchronize()
+            self._sig = sig
+            self.invalidate_cond()
 
     def __del__(self):
         if getattr(self, "_ctx", None) is not None:
@@ -103,19 +107,25 @@ class GuideTransformer(nn.Module):
                                 "`condition`, or construct GuideTransformer(audio_frontend=callable)")
         return self.audio_frontend(raw_audio)
 
+    def invalidate_cond(self) -> None:
+        self._prepared_for, self._prepared_ref = None, None
+
     def _prepare(self, condition: torch.Tensor, cond_drop_prob: float) -> int:
         if cond_drop_prob not in (0.0, 1.0):
             raise NotImplementedError("inference uses cond_drop_prob in {0, 1}")
-        cond = condition if condition.dim() == 3 and condition.shape[-1] == self.cond_feature_dim else self.encode_audio(condition)
-        _lib.require_gpu_tensor(cond, "condition")
-        self._ensure(cond.device)
-        key = (cond.data_ptr(), cond._version, tuple(cond.shape), cond_drop_prob)
+        _lib.require_gpu_tensor(condition, "condition")
+        self._ensure(condition.device)
+        # keyed on the CALLER's tensor (features or raw audio) and pinned by a strong reference: the front end and the hoisted
+        # conv stack run once per clip, and a recycled address can never alias another clip's state
+        key = (_lib.content_key(condition), cond_drop_prob)
         if key != self._prepared_for:
-            feats = cond.to(torch.float32).contiguous()
-            _lib.check(_lib.load().a2p_guide_prepare(self._ctx, _lib.ptr(feats), feats.shape[0], feats.shape[1],
-                                                     int(cond_drop_prob == 1.0), _lib.current_stream()), "a2p_guide_prepare")
-            self._prepared_for = key
-        return cond.shape[0]
+            is_feats = condition.dim() == 3 and condition.shape[-1] == self.cond_feature_dim
+            feats = (condition if is_feats else self.encode_audio(condition)).to(torch.float32).contiguous()
+            with _lib.on_device_of(feats):
+                _lib.check(_lib.load().a2p_guide_prepare(self._ctx, _lib.ptr(feats), feats.shape[0], feats.shape[1],
+                                                         int(cond_drop_prob == 1.0), _lib.current_stream(feats.device)), "a2p_guide_prepare")
+            self._prepared_for, self._prepared_ref, self._prepared_batch = key, condition, feats.shape[0]
+        return self._prepared_batch
 
     # ------------------------------------------------------------------ reference surface
     def forward(self, tokens: torch.Tensor, condition: torch.Tensor, cond_drop_prob: float = 0.0) -> torch.Tensor:
@@ -124,8 +134,9 @@ class GuideTransformer(nn.Module):
         assert tokens.shape[0] == B, f"{tokens.shape[0]} token rows for {B} conditions"
         toks = tokens.to(device=condition.device, dtype=torch.int64).contiguous()
         logits = torch.empty(B, toks.shape[1], self.tokens, device=toks.device, dtype=torch.float32)
-        _lib.check(_lib.load().a2p_guide_forward(self._ctx, _lib.ptr(toks), B, toks.shape[1], _lib.ptr(logits), _lib.current_stream()),
-                   "a2p_guide_forward")
+        with _lib.on_device_of(toks):
+            _lib.check(_lib.load().a2p_guide_forward(self._ctx, _lib.ptr(toks), B, toks.shape[1], _lib.ptr(logits),
+                                                     _lib.current_stream(toks.device)), "a2p_guide_forward")
         return logits
 
     def generate(self, condition: torch.Tensor, sequence_length: int, layers: int, n_sequences: int = 1, max_key_len: int = 8,
@@ -144,9 +155,9 @@ class GuideTransformer(nn.Module):
         assert u.shape == (n, B), f"uniforms must be [{n}, {B}]"
         out = torch.empty(B, n, device=dev, dtype=torch.int64)
         probs = torch.empty(n, B, self.tokens, device=dev, dtype=torch.float32) if return_probs else None
-        with torch.no_grad():
+        with torch.no_grad(), _lib.on_device_of(u):
             _lib.check(_lib.load().a2p_guide_generate(self._ctx, B, n, float(top_p), _lib.ptr(u), _lib.ptr(out), _lib.ptr(probs),
-                                                      _lib.current_stream()), "a2p_guide_generate")
+                                                      _lib.current_stream(dev)), "a2p_guide_generate")
         return (out, probs) if return_probs else out
 
     def pre_audio_features(self, n_rows: int) -> torch.Tensor:

@@ -48,6 +48,21 @@ class TemporalVertexCodec(nn.Module):
         self.n_clusters, self.n_vertices = categories, n_vertices
         self.decoder = _Decoder(n_vertices, latent_dim)
         self.quantizer = _RVQ(categories, latent_dim, residual_depth)
+        self._staged = None           # (signature, fp32 device copies the kernel reads): kept alive across calls
+
+    def _stage(self, device):
+        """fp32 contiguous device copies of the codebooks / conv weights, rebuilt only when a parameter changes (round 1 re-staged
+        and synchronised the stream on every call)."""
+        src = [l._codebook.embed for l in self.quantizer.layers] + [t for i in (0, 2, 4, 6, 8)
+                                                                     for t in (self.decoder.dec[i].weight, self.decoder.dec[i].bias)]
+        sig = (str(device), _lib.content_key(*src))
+        if self._staged is None or self._staged[0] != sig:
+            f32 = lambda t: t.detach().to(device=device, dtype=torch.float32).contiguous()   # noqa: E731
+            nb = len(self.quantizer.layers)
+            books = [f32(t) for t in src[:nb]]
+            ws, bs = [f32(t) for t in src[nb::2]], [f32(t) for t in src[nb + 1::2]]
+            self._staged = (sig, books, ws, bs, src)
+        return self._staged[1:4]
 
     def decode(self, q: torch.Tensor) -> torch.Tensor:
         """q int64 [B, T, residual_depth] -> [B, T, n_vertices] (reference :508-521)."""
@@ -55,13 +70,10 @@ class TemporalVertexCodec(nn.Module):
         assert q.dim() == 3 and q.shape[-1] == self.residual_depth
         B, T, _ = q.shape
         q = q.to(torch.int64).contiguous()
-        f32 = lambda t: t.detach().to(device=q.device, dtype=torch.float32).contiguous()   # noqa: E731
-        books = [f32(l._codebook.embed) for l in self.quantizer.layers]
-        convs = [self.decoder.dec[i] for i in (0, 2, 4, 6, 8)]
-        ws, bs = [f32(c.weight) for c in convs], [f32(c.bias) for c in convs]
+        books, ws, bs = self._stage(q.device)
         arr = lambda ts: (C.c_void_p * len(ts))(*[t.data_ptr() for t in ts])               # noqa: E731
         out = torch.empty(B, T, self.n_vertices, device=q.device, dtype=torch.float32)
-        _lib.check(_lib.load().a2p_vq_decode(_lib.ptr(q), B, T, self.residual_depth, self.categories, self.latent_dim, self.n_vertices,
-                                             arr(books), arr(ws), arr(bs), _lib.ptr(out), _lib.current_stream()), "a2p_vq_decode")
-        torch.cuda.current_stream().synchronize()   # the staged fp32 copies above must outlive the kernel
-        return out
+        with _lib.on_device_of(q):
+            _lib.check(_lib.load().a2p_vq_decode(_lib.ptr(q), B, T, self.residual_depth, self.categories, self.latent_dim, self.n_vertices,
+                                                 arr(books), arr(ws), arr(bs), _lib.ptr(out), _lib.current_stream(q.device)), "a2p_vq_decode")
+        return out   # no synchronise: the staged copies live on the module, `q` / `out` are ordered by the stream

@@ -14,7 +14,7 @@ from typing import Callable, Dict, Optional
 import numpy as np
 import torch
 
-from ..sample_parallel import sample_parallel
+from ..sample_parallel import per_sample_noise, sample_parallel, shared_base_seed
 
 
 def fixseed(seed: int) -> None:
@@ -49,13 +49,17 @@ def make_inv_transform(stats: Dict[str, np.ndarray]) -> Callable:
     return inv
 
 
-def _setup_model(args, state_dict, **model_kwargs):
+def _setup_model(args, state_dict, guide=None, **model_kwargs):
     """Model + diffusion for sampling (reference sample/generate.py:165-198, with the checkpoint passed in instead of read
-    from args.model_path): build, load, wrap for classifier-free guidance, move to args.device, eval."""
+    from args.model_path): build, load, wrap for classifier-free guidance, move to args.device, eval.
+    `guide=(transformer, tokenizer)`: the guide transformer and VQ tokenizer of the body model -- the reference's constructor
+    loads them from `args.resume_trans` (model/diffusion.py:244-271); here the built modules are passed in."""
     from ..model.cfg_sampler import ClassifierFreeSampleModel
     from ..model_util import create_model_and_diffusion, load_model
     model, diffusion = create_model_and_diffusion(args, "test", **model_kwargs)
     load_model(model, state_dict)
+    if guide is not None:
+        model.setup_guide_predictor(*guide, resume_trans=getattr(args, "resume_trans", None) or "<in-memory>")
     if not getattr(args, "unconstrained", False):
         assert args.guidance_param != 1
     if args.guidance_param != 1:
@@ -97,11 +101,25 @@ def _replace_keyframes(model_kwargs, model, uniforms: Optional[torch.Tensor] = N
 
 def _run_single_diffusion(args, model_kwargs, diffusion, model, inv_transform: Callable, gt: Optional[torch.Tensor],
                           noise: Optional[torch.Tensor] = None):
-    """One ddim_sample_loop over the (possibly rank-sharded) batch + un-normalisation (reference :74-107)."""
-    if args.data_format == "pose" and getattr(args, "resume_trans", None) is not None:   # reference :82-83
+    """One ddim_sample_loop over the (possibly rank-sharded) batch + un-normalisation (reference :74-107).
+
+    Under torch.distributed every random draw is a function of (shared base seed, GLOBAL sample id): the initial noise via
+    `per_sample_noise`, the guide transformer's uniforms from one generator all ranks seed alike -- so the gathered result does
+    not depend on the world size, and the keyframes rank 0 saves are the ones every rank conditioned on."""
+    import torch.distributed as dist
+    sharded = dist.is_available() and dist.is_initialized()
+    base = shared_base_seed() if sharded else None
+    has_guide = getattr(args, "resume_trans", None) is not None or getattr(model, "resume_trans", None) is not None
+    if args.data_format == "pose" and has_guide:   # reference :82-83
         y = model_kwargs["y"]
-        y["keyframes"] = _replace_keyframes(model_kwargs, model).to(y["keyframes"].device)
+        uniforms = None
+        if sharded:
+            n = y["keyframes"].shape[1] * model.tokenizer.residual_depth
+            uniforms = torch.rand(n, y["keyframes"].shape[0], generator=torch.Generator().manual_seed(base ^ 0x6775696465))
+        y["keyframes"] = _replace_keyframes(model_kwargs, model, uniforms).to(y["keyframes"].device)
     shape = (args.batch_size, model.nfeats, 1, args.curr_seq_length)
+    if noise is None and sharded:
+        noise = per_sample_noise(shape, [base + g for g in range(shape[0])])
     with torch.no_grad():
         sample = sample_parallel(diffusion.ddim_sample_loop, model, shape, model_kwargs, noise=noise,
                                  clip_denoised=False, init_image=None, progress=False, dump_steps=None, const_noise=False)

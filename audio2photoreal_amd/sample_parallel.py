@@ -47,6 +47,15 @@ def per_sample_noise(shape: Sequence[int], seeds: Sequence[int], device="cpu") -
     return torch.stack(rows).to(device)
 
 
+def shared_base_seed(group=None) -> int:
+    """One integer all ranks agree on (rank 0's torch seed): the root of every per-sample random stream of a sharded run.
+    Control plane only (8 bytes, once per sampling call); the data path still has exactly one collective."""
+    seed = [int(torch.initial_seed()) & 0x7FFFFFFFFFFF]
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+        dist.broadcast_object_list(seed, src=0, group=group)
+    return seed[0]
+
+
 def gather_samples(local: torch.Tensor, total: int, group=None) -> torch.Tensor:
     """The single end-of-run collective: all ranks receive all samples, in global order."""
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:

@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """bench.py -- denoise steps/sec of the MI355X-native sampling hot path.
 
-Workload (BASELINE.json configs[1]): face diffusion, 1000-step DDPM (p_sample_loop with the
+Headline workload (BASELINE.json configs[1]): face diffusion, 1000-step DDPM (p_sample_loop with the
 restored noise), classifier-free guidance (2 denoiser passes per step), batch 8 samples per GPU,
 600-frame sequences, 1998 audio tokens (+2 time tokens), bf16 operands / fp32 accumulate.
 Synthetic weights + inputs (no checkpoints/datasets offline).  One "step" = one p_sample:
@@ -10,13 +10,22 @@ Synthetic weights + inputs (no checkpoints/datasets offline).  One "step" = one 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B] [--precision bf16|fp32]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-Multi-GPU = sample parallel: every rank denoises its own 8 samples, no per-step
-communication (weak scaling); one RCCL all_gather of the final samples after the timed region.
-Prints ONE JSON line on rank 0.
+The ONE JSON line rank 0 prints carries, next to the contract fields:
+  roofline      dominant kernel class, algorithmic FLOPs / measured launch time (HIP events on the launch stream) vs the bf16 peak
+  cpu_baseline  the oracle (CPU port of the reference algorithm) timed on this box's host cores, bounded sample
+  parity        the benchmarked (bf16) mode AND the fp32 parity mode against that same oracle run at the bench shape
+                (face, T=600, S=2000), plus the drift of the full 1000-step chain bf16 vs GPU-fp32 under identical noise
+  legs          the other two north-star shapes on this GPU: face B=32 ("b32") and the body model B=16 with keyframes ("body")
+
+Multi-GPU = sample parallel: rank r denoises the global samples shard_bounds(N*B, N, r) with its own
+replica, no per-step communication (weak scaling); one all_gather (sample_parallel.gather_samples; RCCL over xGMI) of the
+final samples after the timed region.  `value` = denoise steps all ranks ran / max-over-ranks time: at N GPUs one "step" of
+the job advances N*B samples (`sample_steps_per_sec` = value * B is the size-independent figure).
 """
 import argparse
 import json
 import os
+import statistics
 import sys
 import time
 
@@ -25,8 +34,6 @@ import torch
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-# algorithmic FLOPs (2*MACs) of the decoder stack per forward per sample at T=600, S=2000 with the
-# audio-token K/V hoisted: face 50.77 GF, i.e. 101.5 GF per denoise step per sample.
 PEAK_BF16_TFLOPS = 2500.0   # dense bf16 MFMA (MI355X_MICROARCH.md)
 PEAK_F32_TFLOPS = 157.3     # fp32 MFMA
 PEAK_HBM_GBS = 8000.0
@@ -34,7 +41,7 @@ PEAK_HBM_GBS = 8000.0
 
 def algorithmic_flops(spec, T, S, nseq):
     """Per forward of `nseq` sequences, by kernel class (attention + FFN + projections of the decoder
-    stack; hoisted audio-token K/V projections excluded)."""
+    stack; hoisted audio-token K/V projections excluded; SURVEY.md §8d: face 50.77 GF per sequence at T=600, S=2000)."""
     d, ff, L = spec.latent_dim, spec.ff_size, spec.num_layers
     sa_attn = 4.0 * T * T * d                      # QK^T + PV
     ca_attn = 4.0 * T * S * d
@@ -49,6 +56,252 @@ def algorithmic_flops(spec, T, S, nseq):
             "attn_cross": nseq * L * (ca_attn + ca_attn2)}
 
 
+def rel_errors(got, want):
+    got, want = got.double().cpu(), want.double().cpu()
+    return {"rel_l2": float((got - want).norm() / want.norm()), "max_norm": float((got - want).abs().max() / want.abs().max())}
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# one workload = model + diffusion + resident inputs for this rank's samples
+# ----------------------------------------------------------------------------------------------------------------------
+class Case:
+    def __init__(self, fmt, B, T, precision, dev, sample_ids, respacing="", sampler="ddpm", max_batch=None):
+        from audio2photoreal_amd.model.cfg_sampler import ClassifierFreeSampleModel
+        from audio2photoreal_amd.model_util import create_model_and_diffusion, default_args, load_model
+        from audio2photoreal_amd.spec import face_spec, pose_spec
+        from audio2photoreal_amd.synthetic import cond_tokens_for_frames, synthetic_state_dict, synthetic_tensor
+        self.fmt, self.B, self.T, self.precision, self.dev, self.sampler = fmt, B, T, precision, dev, sampler
+        self.spec = face_spec() if fmt == "face" else pose_spec()
+        self.S0 = cond_tokens_for_frames(T)
+        self.sd = synthetic_state_dict(self.spec, 10)
+        model, self.diffusion = create_model_and_diffusion(default_args(fmt, timestep_respacing=respacing), "test",
+                                                           precision=precision, max_batch=max_batch or B)
+        load_model(model, self.sd)
+        self.model = model.to(dev).eval()
+        self.cfg = ClassifierFreeSampleModel(self.model)
+        spec = self.spec
+        # inputs indexed by GLOBAL sample id so results do not depend on the world size
+        self.cond = torch.stack([synthetic_tensor(10, f"cond_embed/{g}", (self.S0, spec.cond_feature_dim)) for g in sample_ids]).to(dev)
+        self.x = torch.stack([synthetic_tensor(10, f"x_T/{g}", (spec.nfeats, 1, T)) for g in sample_ids]).to(dev)
+        self.y = {"cond_embed": self.cond, "scale": torch.full((B,), 10.0 if fmt == "face" else 2.0, device=dev)}
+        if spec.is_pose:
+            nk = len(range(T)[:: spec.keyframe_step])
+            self.y["keyframes"] = torch.stack([synthetic_tensor(10, f"keyframes/{g}", (nk, spec.keyframe_dim)) for g in sample_ids]).to(dev)
+            self.y["mask"] = torch.ones(B, 1, 1, T, dtype=torch.bool, device=dev)
+        self.gen = torch.Generator(device=dev).manual_seed(1234 + sample_ids[0])
+        self.n_chain = self.diffusion.num_timesteps
+        self.steps_idx = self.diffusion._step_index_tensor(dev, B)
+        self.state = {"x": self.x, "i": self.n_chain - 1}
+
+    def setup(self):
+        """Untimed one-off work: context, weight upload, hoisted conditioning (timed separately), per-box shape calibration."""
+        self.model.prepare(self.x, self.y)
+        torch.cuda.synchronize()
+        self.model.invalidate_cond()
+        t0 = time.perf_counter()
+        self.model.prepare(self.x, self.y)            # hoisted conditioning: once per clip, outside the loop
+        torch.cuda.synchronize()
+        self.prepare_s = time.perf_counter() - t0
+        with torch.no_grad():
+            # the library measures which chain-kernel workgroup shape is faster on THIS box during the first 6 forwards of a
+            # given size (csrc/a2p_lib_run.h chain_pick_nw; both shapes give identical bits)
+            for _ in range(6):
+                self.cfg(self.x, self.steps_idx[0], self.y)
+        torch.cuda.synchronize()
+
+    def run_steps(self, n):
+        st, d = self.state, self.diffusion
+        for _ in range(n):
+            if self.sampler == "ddpm":
+                noise = torch.randn(self.x.shape, device=self.dev, generator=self.gen)        # randn_like(x) of p_sample
+                out = d.p_sample(self.cfg, st["x"], self.steps_idx[st["i"]], clip_denoised=False, model_kwargs={"y": self.y}, noise=noise)
+            else:
+                out = d.ddim_sample(self.cfg, st["x"], self.steps_idx[st["i"]], clip_denoised=False, model_kwargs={"y": self.y})
+            st["x"] = out["sample"]
+            st["i"] = st["i"] - 1 if st["i"] > 0 else self.n_chain - 1
+
+    def step_flops(self):
+        fl = algorithmic_flops(self.spec, self.T, self.S0 + 2, 2 * self.B)
+        return fl["decoder_gemm"] + fl["attn_self"] + fl["attn_cross"]   # SURVEY §8d: decoder attention + FFN + projections
+
+
+def time_case(case, steps, warmup, repeats, barrier):
+    """`repeats` x [EXACTLY `steps` steps bracketed by barrier + synchronize]; returns the per-repeat wall times."""
+    dts = []
+    with torch.no_grad():
+        case.run_steps(warmup)
+        for _ in range(repeats):
+            barrier()
+            t0 = time.perf_counter()
+            case.run_steps(steps)
+            barrier()
+            dts.append(time.perf_counter() - t0)
+    return dts
+
+
+def kernel_breakdown(case, ksteps):
+    """Per-kernel-class time inside the step from dispatch-packet events on the launch stream (a2p_kernel_timing), and the
+    roofline record of the dominant class."""
+    import ctypes as C
+    from audio2photoreal_amd import _lib
+    lib = _lib.load()
+    flops = algorithmic_flops(case.spec, case.T, case.S0 + 2, 2 * case.B)
+    # bf16 mode runs the decoder-layer GEMMs inside the fused "chain" kernels (projections + FiLM + LayerNorm + FFN);
+    # fp32 mode (and A2P_NO_CHAIN=1) runs them as separate GEMM launches
+    chained = case.precision == "bf16" and not os.environ.get("A2P_NO_CHAIN")
+    flops["chain" if chained else "gemm"] = flops.pop("decoder_gemm") + (0.0 if chained else flops["io_gemm"])
+    if chained:
+        flops["gemm"] = flops["io_gemm"]
+    kernels = {}
+    for name, kind in (("chain", _lib.KERNEL_CHAIN), ("gemm", _lib.KERNEL_GEMM), ("attn_self", _lib.KERNEL_ATTN_SELF),
+                       ("attn_cross", _lib.KERNEL_ATTN_CROSS), ("ln_rope", _lib.KERNEL_LNROPE)):
+        _lib.check(lib.a2p_kernel_timing(case.model._ctx, kind, 1), "a2p_kernel_timing")
+        with torch.no_grad():
+            case.run_steps(ksteps)
+        ms, n = C.c_double(), C.c_int64()
+        _lib.check(lib.a2p_kernel_time_ms(case.model._ctx, C.byref(ms), C.byref(n)), "a2p_kernel_time_ms")
+        _lib.check(lib.a2p_kernel_timing(case.model._ctx, kind, 0), "a2p_kernel_timing")
+        if n.value == 0:
+            continue
+        per_step_ms = ms.value / ksteps
+        ent = {"ms_per_step": round(per_step_ms, 4), "launches_per_step": n.value // ksteps,
+               "avg_launch_us": round(1e3 * ms.value / max(n.value, 1), 2)}
+        if name in flops:
+            ent["algorithmic_gflop_per_step"] = round(flops[name] / 1e9, 2)
+            ent["tflops"] = round(flops[name] / (per_step_ms * 1e-3) / 1e12, 2)
+        kernels[name] = ent
+    dom = max((k for k in kernels if k in flops), key=lambda k: kernels[k]["ms_per_step"])
+    peak = PEAK_BF16_TFLOPS if case.precision == "bf16" else PEAK_F32_TFLOPS
+    roofline = {"kernel": dom, "bound": "mfma", "achieved": kernels[dom]["tflops"], "peak": peak, "unit": "TFLOP/s",
+                "frac": round(kernels[dom]["tflops"] / peak, 4), "traffic": None,
+                "avg_launch_us": kernels[dom]["avg_launch_us"],
+                "algorithmic_gflop_per_launch": round(flops[dom] / 1e9 / kernels[dom]["launches_per_step"], 3)}
+    return kernels, roofline
+
+
+def leg_record(case, steps, warmup, repeats, ksteps=3):
+    """Sub-record of a secondary workload (same measurement as the headline, fewer fields)."""
+    case.setup()
+    dts = time_case(case, steps, warmup, repeats, torch.cuda.synchronize)
+    dt = statistics.median(dts)
+    kernels, roofline = kernel_breakdown(case, ksteps)
+    peak = PEAK_BF16_TFLOPS if case.precision == "bf16" else PEAK_F32_TFLOPS
+    return {"workload": f"{case.fmt} B={case.B} x2 CFG, T={case.T}, {case.S0}+2 cond tokens, {case.sampler} step, {case.precision}",
+            "value": round(steps / dt, 3), "unit": "steps/s", "ms_per_step": round(1e3 * dt / steps, 4),
+            "sample_steps_per_sec": round(case.B * steps / dt, 2), "repeats_ms_per_step": [round(1e3 * t / steps, 4) for t in dts],
+            "decoder_tflops": round(case.step_flops() * steps / dt / 1e12, 2),
+            "decoder_mfma_frac": round(case.step_flops() * steps / dt / 1e12 / peak, 4),
+            "roofline": roofline, "kernels": kernels, "prepare_s": round(case.prepare_s, 4)}
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# CPU baseline (oracle) + parity of both GPU modes against that same oracle run
+# ----------------------------------------------------------------------------------------------------------------------
+def cpu_and_parity(case, dev, want_parity=True, chain_steps=1000, chain_batch=2):
+    """The oracle (CPU restatement of the reference algorithm, oracle/a2p_oracle.py) on ONE sample of the bench workload at
+    the bench shape: 4 DDPM steps at the head of the 1000-step chain (t = 999..996) and 4 at its tail (t = 3..0, where the
+    model's x0 carries the whole update).  The wall time of those 8 steps is the `cpu_baseline`; their outputs are the
+    reference both GPU modes are compared with (`parity.short`).  `parity.chain` is the drift of the FULL 1000-step chain:
+    the benchmarked bf16 mode vs the GPU fp32 mode (which is parity-pinned against the oracle / reference goldens) under
+    identical per-step noise."""
+    from oracle import a2p_oracle as O
+    from audio2photoreal_amd.model.cfg_sampler import ClassifierFreeSampleModel
+    from audio2photoreal_amd.model_util import create_model_and_diffusion, default_args, load_model
+    spec, T, S0 = case.spec, case.T, case.S0
+    ncpu = os.cpu_count() or 1
+    threads = min(ncpu, 32)       # torch CPU matmuls at these sizes stop scaling (and thrash) past ~32 threads
+    torch.set_num_threads(threads)
+    den = O.OracleDenoiser(case.sd, case.fmt, spec.num_layers, spec.num_heads)
+    ce, xc = case.cond[:1].cpu(), case.x[:1].cpu()
+    scale = float(case.y["scale"][0])
+    fn = lambda xx, ts: den.forward_cfg(xx, ts, ce, torch.full((1,), scale))
+    smp = O.OracleSampler("")
+    t_list = [999, 998, 997, 996, 3, 2, 1, 0]
+    g = torch.Generator().manual_seed(4321)
+    nz = [torch.randn(xc.shape, generator=g) for _ in t_list]
+    x_tail = torch.randn(xc.shape, generator=g) * 0.5          # a plausible late-chain state for the tail steps
+    want = {}
+    with torch.no_grad():
+        smp.p_sample(fn, xc, torch.tensor([999]), nz[0])       # warm-up (thread pool, allocator)
+        t0 = time.perf_counter()
+        cur = xc
+        for k, t in enumerate(t_list):
+            if t == 3:
+                want["head"] = out
+                cur = x_tail
+            out = smp.p_sample(fn, cur, torch.tensor([t]), nz[k])
+            cur = out["sample"]
+        want["tail"] = out
+        cdt = time.perf_counter() - t0
+    cpu = {"value": round(len(t_list) / cdt / case.B, 5),
+           "unit": f"denoise steps/sec at batch {case.B} (1 sample timed, scaled by 1/{case.B})",
+           "cores": threads, "host_cpus": ncpu, "kind": "port",
+           "sample": f"oracle (torch CPU fp32 restatement of the reference algorithm, conditioning path recomputed every forward like "
+                     f"the reference's decoder-only path), 1 sample x {len(t_list)} DDPM steps, T={T}, S={S0 + 2}: {cdt:.2f} s"}
+    if not want_parity:
+        return cpu, None
+
+    def gpu_short(precision):
+        if precision == case.precision:
+            cfg, diff = case.cfg, case.diffusion
+        else:
+            m, diff = create_model_and_diffusion(default_args(case.fmt, timestep_respacing=""), "test", precision=precision, max_batch=2)
+            load_model(m, case.sd)
+            cfg = ClassifierFreeSampleModel(m.to(dev).eval())
+        y = {"cond_embed": case.cond[:1].contiguous(), "scale": case.y["scale"][:1].contiguous()}
+        idx = diff._step_index_tensor(dev, 1)
+        got = {}
+        with torch.no_grad():
+            cur = case.x[:1].contiguous()
+            for k, t in enumerate(t_list):
+                if t == 3:
+                    got["head"] = out
+                    cur = x_tail.to(dev)
+                out = diff.p_sample(cfg, cur, idx[t], clip_denoised=False, model_kwargs={"y": y}, noise=nz[k].to(dev))
+                cur = out["sample"]
+            got["tail"] = out
+        rec = {}
+        for part in ("head", "tail"):
+            for key in ("sample", "pred_xstart"):
+                rec[f"{part}_{key}"] = {k: float(f"{v:.3e}") for k, v in rel_errors(got[part][key], want[part][key]).items()}
+        if cfg is not case.cfg:
+            cfg.model.release()
+        return rec
+
+    parity = {"reference": "oracle/a2p_oracle.py (CPU fp32), pinned to reference-generated goldens by tests/test_oracle_golden.py",
+              "shape": f"{case.fmt} B=1 T={T} S={S0 + 2}, p_sample at t={t_list}",
+              "short": {"fp32": gpu_short("fp32"), "bf16": gpu_short("bf16")}}
+    if chain_steps:
+        finals = {}
+        Bc = chain_batch
+        shape = (Bc, spec.nfeats, 1, T)
+        for precision in ("fp32", "bf16"):
+            m, diff = create_model_and_diffusion(default_args(case.fmt, timestep_respacing=""), "test", precision=precision, max_batch=Bc)
+            load_model(m, case.sd)
+            cfg = ClassifierFreeSampleModel(m.to(dev).eval())
+            y = {"cond_embed": case.cond[:Bc].contiguous(), "scale": case.y["scale"][:Bc].contiguous()}
+            gg = torch.Generator(device=dev)
+
+            def step_noise(n):
+                gg.manual_seed(50000 + n)
+                return torch.randn(shape, device=dev, generator=gg)
+            t0 = time.perf_counter()
+            with torch.no_grad():
+                gen = diff.p_sample_loop_progressive(cfg, shape, noise=case.x[:Bc].contiguous(), clip_denoised=False,
+                                                     model_kwargs={"y": y}, step_noise=step_noise)
+                for n, out in enumerate(gen):
+                    if n + 1 >= chain_steps:
+                        break
+            torch.cuda.synchronize()
+            finals[precision] = (out["sample"].clone(), time.perf_counter() - t0)
+            m.release()
+        parity["chain"] = {"what": f"final sample of the {chain_steps}-step DDPM chain, B={Bc}, T={T}: bf16 mode vs GPU fp32 mode, identical noise",
+                           **{k: float(f"{v:.3e}") for k, v in rel_errors(finals["bf16"][0], finals["fp32"][0]).items()},
+                           "fp32_chain_s": round(finals["fp32"][1], 2), "bf16_chain_s": round(finals["bf16"][1], 2)}
+    return cpu, parity
+
+
+# ----------------------------------------------------------------------------------------------------------------------
 def run_pipeline(a, dev):
     """One subject of BASELINE configs[4] on one GPU: everything after the (out-of-scope) wav2vec front end."""
     from audio2photoreal_amd.model.cfg_sampler import ClassifierFreeSampleModel
@@ -78,9 +331,9 @@ def run_pipeline(a, dev):
     lip = synthetic_tensor(10, "pipeline_lip_feats", (B, S0, 1014)).to(dev)
 
     def once():
-        guide._prepared_for = None                     # every run pays the hoisted conditioning of all three models
+        guide.invalidate_cond()                       # every run pays the hoisted conditioning of all three models
         for _, cfg_m, _ in models.values():
-            cfg_m.model._cond_key = None
+            cfg_m.model.invalidate_cond()
         torch.cuda.synchronize()
         st, t0 = {}, time.perf_counter()
 
@@ -117,6 +370,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--repeats", type=int, default=3, help="timed regions of exactly --steps steps each; the median is reported")
     ap.add_argument("--batch", type=int, default=8)
     ap.add_argument("--frames", type=int, default=600)
     ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
@@ -127,6 +381,10 @@ def main():
                          "guide transformer tokens -> VQ keyframes -> body ddim100 -> face ddim100 (demo/demo.py:156-216), sec/sample")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
+    ap.add_argument("--no-parity", action="store_true", help="skip the parity legs (the oracle still times the cpu_baseline)")
+    ap.add_argument("--no-legs", action="store_true", help="skip the face B=32 and body B=16 sub-records")
+    ap.add_argument("--chain-steps", type=int, default=1000, help="length of the bf16-vs-fp32 drift chain (0 = skip)")
+    ap.add_argument("--write-parity", default=None, help="also write the parity record to this JSON file (profiles/r02_parity.json)")
     a = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -143,6 +401,7 @@ def main():
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
     coll_dev = dev if backend == "nccl" else torch.device("cpu")
+    dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -156,161 +415,70 @@ def main():
         ge.build()
     if world > 1:
         dist.barrier()
-    from audio2photoreal_amd import _lib
-    from audio2photoreal_amd.model.cfg_sampler import ClassifierFreeSampleModel
-    from audio2photoreal_amd.model_util import create_model_and_diffusion, default_args, load_model
-    from audio2photoreal_amd.spec import face_spec, pose_spec
-    from audio2photoreal_amd.synthetic import cond_tokens_for_frames, synthetic_state_dict, synthetic_tensor
+    from audio2photoreal_amd.sample_parallel import gather_samples, shard_bounds
 
     if a.pipeline:
         return run_pipeline(a, dev)
-    spec = face_spec() if a.model == "face" else pose_spec()
     B, T = a.batch, a.frames
-    S0 = cond_tokens_for_frames(T)
-    sd = synthetic_state_dict(spec, 10)
-    model, diffusion = create_model_and_diffusion(default_args(a.model, timestep_respacing=""), "test",
-                                                  precision=a.precision, max_batch=B)
-    load_model(model, sd)
-    model = model.to(dev).eval()
-    cfg = ClassifierFreeSampleModel(model)
-
-    # per-rank inputs indexed by GLOBAL sample id so results do not depend on the world size
-    g0 = rank * B
-    cond = torch.stack([synthetic_tensor(10, f"cond_embed/{g0 + i}", (S0, spec.cond_feature_dim)) for i in range(B)]).to(dev)
-    x = torch.stack([synthetic_tensor(10, f"x_T/{g0 + i}", (spec.nfeats, 1, T)) for i in range(B)]).to(dev)
-    y = {"cond_embed": cond, "scale": torch.full((B,), 10.0 if a.model == "face" else 2.0, device=dev)}
-    if spec.is_pose:
-        nk = len(range(T)[:: spec.keyframe_step])
-        y["keyframes"] = torch.stack([synthetic_tensor(10, f"keyframes/{g0 + i}", (nk, spec.keyframe_dim)) for i in range(B)]).to(dev)
-        y["mask"] = torch.ones(B, 1, 1, T, dtype=torch.bool, device=dev)
-    gen = torch.Generator(device=dev).manual_seed(1234 + rank)
-
-    model.prepare(x, y)                       # context + weight upload + first conditioning pass (untimed setup)
-    torch.cuda.synchronize()
-    model._cond_key = None
-    t0 = time.perf_counter()
-    model.prepare(x, y)                       # hoisted conditioning: once per sample, outside the loop
-    torch.cuda.synchronize()
-    prepare_s = time.perf_counter() - t0
-
-    n_chain = diffusion.num_timesteps
-    steps_idx = diffusion._step_index_tensor(dev, B)
-    state = {"x": x, "i": n_chain - 1}
-
-    def run_steps(n):
-        for _ in range(n):
-            noise = torch.randn(x.shape, device=dev, generator=gen)        # randn_like(x) of p_sample
-            out = diffusion.p_sample(cfg, state["x"], steps_idx[state["i"]], clip_denoised=False,
-                                     model_kwargs={"y": y}, noise=noise)
-            state["x"] = out["sample"]
-            state["i"] = state["i"] - 1 if state["i"] > 0 else n_chain - 1
+    lo, hi = shard_bounds(world * B, world, rank)          # this rank's block of the global batch (weak scaling: B per GPU)
+    case = Case(a.model, B, T, a.precision, dev, list(range(lo, hi)))
+    case.setup()
 
     def barrier():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    with torch.no_grad():
-        # one-off setup like the weight upload above: the library measures which chain-kernel workgroup shape is faster on THIS
-        # box during the first 6 forwards of a given size (csrc/a2p_lib_run.h chain_pick_nw; both shapes give identical bits)
-        for _ in range(6):
-            cfg(x, steps_idx[0], y)
-        torch.cuda.synchronize()
-        run_steps(a.warmup)
-        barrier()
-        t0 = time.perf_counter()
-        run_steps(a.steps)
-        barrier()
-        dt = time.perf_counter() - t0
-    if world > 1:
-        tt = torch.tensor([dt], device=coll_dev, dtype=torch.float64)
+    dts = time_case(case, a.steps, a.warmup, a.repeats, barrier)
+    if world > 1:   # max over ranks per repeat, then the median repeat
+        tt = torch.tensor(dts, device=coll_dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
-    assert torch.isfinite(state["x"]).all(), "non-finite samples"
+        dts = [float(v) for v in tt.tolist()]
+    dt = statistics.median(dts)
+    assert torch.isfinite(case.state["x"]).all(), "non-finite samples"
 
-    # ---- single end-of-run gather of the samples over RCCL/xGMI (outside the timed region) ----
+    # ---- the single end-of-run collective (outside the timed region): all ranks receive all samples, in global order ----
     gather_ms = None
     if world > 1:
-        mine = state["x"].contiguous().to(coll_dev)
-        outs = [torch.empty_like(mine) for _ in range(world)]
+        mine = case.state["x"].contiguous().to(coll_dev)
         barrier()
         t0 = time.perf_counter()
-        dist.all_gather(outs, mine)
+        allx = gather_samples(mine, world * B)
         torch.cuda.synchronize()
         gather_ms = (time.perf_counter() - t0) * 1e3
+        assert allx.shape[0] == world * B and bool(torch.isfinite(allx).all())
 
-    # ---- per-kernel time of the dominant kernel classes, HIP events on the launch stream ----
     kernels, roofline = {}, None
     if rank == 0 and not a.no_kernel_timing:
-        lib = _lib.load()
-        import ctypes as C
-        flops = algorithmic_flops(spec, T, S0 + 2, 2 * B)
-        ksteps = min(a.steps, 5)
-        # bf16 mode runs the decoder-layer GEMMs inside the fused "chain" kernels (projections + FiLM + LayerNorm + FFN);
-        # fp32 mode (and A2P_NO_CHAIN=1) runs them as separate GEMM launches
-        chained = a.precision == "bf16" and not os.environ.get("A2P_NO_CHAIN")
-        flops["chain" if chained else "gemm"] = flops.pop("decoder_gemm") + (0.0 if chained else flops["io_gemm"])
-        if chained:
-            flops["gemm"] = flops["io_gemm"]
-        for name, kind in (("chain", _lib.KERNEL_CHAIN), ("gemm", _lib.KERNEL_GEMM), ("attn_self", _lib.KERNEL_ATTN_SELF),
-                           ("attn_cross", _lib.KERNEL_ATTN_CROSS), ("ln_rope", _lib.KERNEL_LNROPE)):
-            _lib.check(lib.a2p_kernel_timing(model._ctx, kind, 1), "a2p_kernel_timing")
-            with torch.no_grad():
-                run_steps(ksteps)
-            ms, n = C.c_double(), C.c_int64()
-            _lib.check(lib.a2p_kernel_time_ms(model._ctx, C.byref(ms), C.byref(n)), "a2p_kernel_time_ms")
-            _lib.check(lib.a2p_kernel_timing(model._ctx, kind, 0), "a2p_kernel_timing")
-            if n.value == 0:
-                continue
-            per_step_ms = ms.value / ksteps
-            ent = {"ms_per_step": round(per_step_ms, 4), "launches_per_step": n.value // ksteps,
-                   "avg_launch_us": round(1e3 * ms.value / max(n.value, 1), 2)}
-            if name in flops:
-                ent["algorithmic_gflop_per_step"] = round(flops[name] / 1e9, 2)
-                ent["tflops"] = round(flops[name] / (per_step_ms * 1e-3) / 1e12, 2)
-            kernels[name] = ent
-        dom = max((k for k in kernels if k in flops), key=lambda k: kernels[k]["ms_per_step"])
-        peak = PEAK_BF16_TFLOPS if a.precision == "bf16" else PEAK_F32_TFLOPS
-        # HBM bytes per launch of that kernel class from the rocprofv3 PMC passes (FETCH_SIZE doubled per the gfx950 note
-        # of MI355X_MICROARCH.md + WRITE_SIZE; scratch/run_pmc.sh writes the file) -- null when not collected
-        traffic = None
+        kernels, roofline = kernel_breakdown(case, min(a.steps, 5))
+        # HBM bytes per launch of the dominant class from the rocprofv3 PMC passes (FETCH_SIZE doubled per the gfx950 note of
+        # MI355X_MICROARCH.md + WRITE_SIZE; scratch/run_pmc.sh writes the file) -- null when not collected for this workload
         tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-        if os.path.exists(tpath) and a.model == "face" and B == 8 and T == 600 and a.precision == "bf16":   # the profiled workload
-            traffic = json.load(open(tpath)).get(dom)
-        roofline = {"kernel": dom, "bound": "mfma", "achieved": kernels[dom]["tflops"], "peak": peak, "unit": "TFLOP/s",
-                    "frac": round(kernels[dom]["tflops"] / peak, 4), "traffic": traffic and traffic["total_bytes"],
-                    "traffic_detail": traffic,
-                    "avg_launch_us": kernels[dom]["avg_launch_us"],
-                    "algorithmic_gflop_per_launch": round(flops[dom] / 1e9 / kernels[dom]["launches_per_step"], 3)}
+        if os.path.exists(tpath) and a.model == "face" and B == 8 and T == 600 and a.precision == "bf16":
+            traffic = json.load(open(tpath)).get(roofline["kernel"])
+            if traffic:
+                roofline["traffic"], roofline["traffic_detail"] = traffic["total_bytes"], traffic
 
-    # ---- CPU baseline: the oracle (port of the reference algorithm) on this box's host cores ----
-    cpu = None
-    if rank == 0 and world == 1 and not a.no_cpu_baseline and a.model == "face":   # reported at N=1 only (other ranks would idle in the final barrier)
-        from oracle import a2p_oracle as O
-        cores = min(os.cpu_count() or 1, 32)   # torch CPU matmuls at these sizes stop scaling (and thrash) past ~32 threads
-        torch.set_num_threads(cores)
-        cb = 1   # bounded sample: 1 sample (of the 8), 2 DDPM steps, same T/S, fp32
-        den = O.OracleDenoiser(sd, "face", spec.num_layers, spec.num_heads)
-        ce, xc = cond[:cb].cpu(), x[:cb].cpu()
-        fn = lambda xx, ts: den.forward_cfg(xx, ts, ce, torch.full((cb,), 10.0))
-        smp = O.OracleSampler("")
-        CPU_STEPS = 8   # ~10-20 s on the box's host cores
-        nz = [torch.randn(xc.shape) for _ in range(CPU_STEPS + 1)]
-        with torch.no_grad():
-            smp.p_sample_loop(fn, xc, nz, max_steps=1)      # warm-up
-            t0 = time.perf_counter()
-            smp.p_sample_loop(fn, xc, nz, max_steps=CPU_STEPS)
-            cdt = time.perf_counter() - t0
-        sample_steps_per_s = cb * CPU_STEPS / cdt
-        cpu = {"value": round(sample_steps_per_s / B, 5), "unit": f"denoise steps/sec at batch {B} (scaled from sample-steps/sec)",
-               "cores": torch.get_num_threads(), "kind": "port",
-               "sample": f"oracle (torch CPU fp32 restatement, conditioning path recomputed every forward like the reference's "
-                         f"decoder-only path), {cb} sample x {CPU_STEPS} DDPM steps, T={T}, S={S0 + 2}: {cdt:.2f} s"}
+    cpu = parity = None
+    legs = {}
+    if rank == 0 and world == 1:   # reported at N=1 only (other ranks would idle in the final barrier)
+        if not a.no_cpu_baseline and a.model == "face":
+            cpu, parity = cpu_and_parity(case, dev, want_parity=not a.no_parity, chain_steps=a.chain_steps)
+            if parity and a.write_parity:
+                with open(a.write_parity, "w") as f:
+                    json.dump(parity, f, indent=1)
+        if not a.no_legs and a.model == "face" and B == 8 and a.precision == "bf16":
+            case.model.release()           # free the headline context before the larger ones
+            legs["b32"] = leg_record(Case("face", 32, T, "bf16", dev, list(range(32))), max(a.steps // 2, 5), 2, a.repeats)
+            legs["b32"]["note"] = "north_star batch-32 roofline leg (face FiLM denoiser, p_sample step)"
+            body = Case("pose", 16, T, "bf16", dev, list(range(16)), respacing="ddim100", sampler="ddim")
+            legs["body"] = leg_record(body, a.steps, a.warmup, a.repeats)
+            legs["body"]["note"] = "BASELINE configs[2]: body diffusion, keyframe conditioning + CFG scale 2, batch 16, 600 frames, ddim100 step"
 
     if rank == 0:
         value = world * a.steps / dt
-        fl = algorithmic_flops(spec, T, S0 + 2, 2 * B)
-        step_flops = fl["decoder_gemm"] + fl["attn_self"] + fl["attn_cross"]   # decoder attention + FFN + projections
+        peak = PEAK_BF16_TFLOPS if a.precision == "bf16" else PEAK_F32_TFLOPS
+        spec, S0 = case.spec, case.S0
         line = {
             "metric": f"diffusion denoise steps/sec ({a.model}, {T}-frame seq, batch {B} per GPU, CFG)", "value": round(value, 4),
             "unit": "steps/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
@@ -318,11 +486,13 @@ def main():
             "dtype": a.precision, "data": "synthetic",
             "config": {"workload": f"{a.model} FiLM denoiser {spec.num_layers}L/{spec.num_heads}H d{spec.latent_dim}, 1000-step DDPM p_sample chain, B={B}/GPU x2 CFG, "
                                    f"T={T}, {S0}+2 cond tokens", "global_batch": B * world, "parallelism": f"sample-parallel x{world}"},
+            "repeats": a.repeats, "repeats_ms_per_step": [round(1e3 * t / a.steps, 4) for t in dts],
+            "value_note": "steps of every rank / max-over-ranks time (median repeat); one step advances B samples per GPU",
             "sample_steps_per_sec": round(value * B, 3),
-            "decoder_tflops": round(world * step_flops * a.steps / dt / 1e12, 2),
-            "decoder_mfma_frac": round(step_flops * a.steps / dt / 1e12 / (PEAK_BF16_TFLOPS if a.precision == "bf16" else PEAK_F32_TFLOPS), 4),
-            "prepare_s": round(prepare_s, 3), "gather_ms": gather_ms,
-            "roofline": roofline, "kernels": kernels, "cpu_baseline": cpu,
+            "decoder_tflops": round(world * case.step_flops() * a.steps / dt / 1e12, 2),
+            "decoder_mfma_frac": round(case.step_flops() * a.steps / dt / 1e12 / peak, 4),
+            "prepare_s": round(case.prepare_s, 4), "gather_ms": gather_ms,
+            "roofline": roofline, "kernels": kernels, "cpu_baseline": cpu, "parity": parity, "legs": legs or None,
         }
         print(json.dumps(line), flush=True)
     if world > 1:

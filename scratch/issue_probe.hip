@@ -1,0 +1,153 @@
+// Issue-cost probe for the chain kernels' inner loop (scratch; not product).
+// One "stage" per wave = what chain_kernel<512, 3, ., ., NW> does per 16 KiB weight stage: NW=4: 12 MFMA 16x16x32 bf16,
+// 10 ds_read_b128, 4 x 1 KiB weight pieces (LDS-DMA, or plain global_load_dwordx4 into VGPRs); NW=8: 6 / 8 / 2.  Each component can be
+// switched on/off; the time per stage comes from s_memtime (shader clock) and s_memrealtime (100 MHz) so the effective
+// clock is visible too.  hipcc --offload-arch=gfx950 -O3 -std=c++17 scratch/issue_probe.hip -o scratch/issue_probe
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <vector>
+#define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); exit(1);} } while (0)
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+
+enum { M_MFMA = 1, M_DMA = 2, M_GLOAD = 4, M_DSREAD = 8 };
+constexpr int STAGES = 256;
+
+template <int MODE, int NW>
+__global__ __launch_bounds__(64 * NW, 1) void probe(const char* __restrict__ src, unsigned long long* out, float* sink) {
+  constexpr int PCS = 16 / NW;            // 1 KiB pieces per wave per 16 KiB stage (4 waves: 4, 8 waves: 2)
+  constexpr int NMFMA = 48 / NW;          // MT = 3: 48 MFMA 16x16x32 per stage per workgroup
+  constexpr int NDS = NW == 4 ? 5 : 4;    // fragment reads per k-chunk: MT A + NJ W
+  constexpr int FR = 80 * 1024;           // fragment region behind the 80 KiB of rings
+  __shared__ __attribute__((aligned(16))) char lds[112 * 1024];
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  // every wave streams its own slice of each 16 KiB stage; the stream (2 MiB) is shared by all blocks (L2-resident)
+  const char* wsrc = src + (size_t)wid * (PCS * 1024) + lane * 16;
+  char* ring = lds + wid * (5 * PCS * 1024);   // 5-slot wave-private ring
+  f32x4 acc[6];
+  _Pragma("unroll")
+  for (int i = 0; i < 6; ++i) acc[i] = f32x4{0, 0, 0, 0};
+  bf16x8 fa[5], fw[5];
+  _Pragma("unroll")
+  for (int i = 0; i < 5; ++i) {
+    fa[i] = *reinterpret_cast<const bf16x8*>(lds + FR + (lane * 16 + i * 1024) % (32 * 1024));
+    fw[i] = fa[i];
+  }
+  u32x4 g[4] = {};
+  __syncthreads();
+  const unsigned long long t0 = __builtin_readcyclecounter();   // s_memtime
+  const unsigned long long r0 = wall_clock64();                 // s_memrealtime, 100 MHz
+  // software-pipelined like chain_kernel::gemm_tile: the fragment reads of stage s+1 are issued while the MFMAs of stage s run
+  auto stage = [&](int s, bf16x8(&ca)[5], bf16x8(&cw)[5], bf16x8(&na)[5], bf16x8(&nw)[5]) __attribute__((always_inline)) {
+    char* slot = ring + (s % 5) * (PCS * 1024);
+    if constexpr (MODE & M_DMA) {
+      asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(3 * PCS) : "memory");
+      __builtin_amdgcn_sched_barrier(0);
+      const auto gp = (const __attribute__((address_space(1))) void*)(wsrc + (size_t)(s % 128) * 16384);
+      const auto lp = (__attribute__((address_space(3))) void*)slot;
+      __builtin_amdgcn_global_load_lds(gp, lp, 16, 0, 0);
+      __builtin_amdgcn_global_load_lds(gp, lp, 16, 1024, 0);
+      if constexpr (PCS == 4) {
+        __builtin_amdgcn_global_load_lds(gp, lp, 16, 2048, 0);
+        __builtin_amdgcn_global_load_lds(gp, lp, 16, 3072, 0);
+      }
+    } else if constexpr (MODE & M_DSREAD) {
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    if constexpr (MODE & M_GLOAD) {
+      // consume the previous stage's registers (keeps the loads live), then re-issue: PCS x 1 KiB straight into VGPRs
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      _Pragma("unroll") for (int i = 0; i < PCS; ++i) asm volatile("" ::"v"(g[i]));
+      const char* gp = wsrc + (size_t)(s % 128) * 16384;
+      _Pragma("unroll") for (int i = 0; i < PCS; ++i)
+        asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(g[i]) : "v"(gp + i * 1024));
+    }
+    if constexpr (MODE & M_DSREAD) {
+      _Pragma("unroll") for (int i = 0; i < NDS; ++i) {   // 2 k-chunks x NDS reads: conflict-free lane-linear 16 B reads
+        na[i] = *reinterpret_cast<const bf16x8*>(lds + FR + ((lane * 16 + i * 1024 + s * 64) & (32 * 1024 - 1)));
+        nw[i] = *reinterpret_cast<const bf16x8*>(slot + ((lane * 16 + i * 512) & (PCS * 1024 - 1)));
+      }
+    }
+    if constexpr (MODE & M_MFMA) {
+      _Pragma("unroll") for (int i = 0; i < NMFMA; ++i)
+        acc[i % 6] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ca[i % 5], cw[(i + 2) % 5], acc[i % 6], 0, 0, 0);
+    } else {
+      _Pragma("unroll") for (int i = 0; i < 5; ++i) asm volatile("" ::"v"(ca[i]), "v"(cw[i]));
+    }
+    if constexpr ((MODE & M_MFMA) && (MODE & (M_DMA | M_DSREAD))) {   // the chain kernel's interleave
+      if constexpr (MODE & M_DMA) {
+        _Pragma("unroll") for (int i = 0; i < PCS; ++i) {
+          __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        }
+      }
+      if constexpr (MODE & M_DSREAD) {
+        _Pragma("unroll") for (int i = 0; i < 2 * NDS; ++i) {
+          __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        }
+      }
+    }
+  };
+  bf16x8 fa2[5], fw2[5];
+  _Pragma("unroll") for (int i = 0; i < 5; ++i) { fa2[i] = fa[i]; fw2[i] = fw[i]; }
+  for (int s = 0; s < STAGES; s += 2) {
+    stage(s, fa, fw, fa2, fw2);
+    stage(s + 1, fa2, fw2, fa, fw);
+  }
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+  const unsigned long long t1 = __builtin_readcyclecounter();
+  const unsigned long long r1 = wall_clock64();
+  float v = 0;
+  _Pragma("unroll")
+  for (int i = 0; i < 6; ++i) v += acc[i][0] + acc[i][3];
+  _Pragma("unroll")
+  for (int i = 0; i < 4; ++i) v += (float)g[i][0];
+  if (v == 1.2345f) sink[0] = v;
+  if (lane == 0) {
+    out[(blockIdx.x * NW + wid) * 2 + 0] = t1 - t0;
+    out[(blockIdx.x * NW + wid) * 2 + 1] = r1 - r0;
+  }
+}
+
+template <int MODE, int NW>
+void run(const char* name, const char* src, unsigned long long* dout, float* sink, int blocks) {
+  std::vector<unsigned long long> h((size_t)blocks * NW * 2);
+  for (int it = 0; it < 3; ++it) probe<MODE, NW><<<blocks, 64 * NW>>>(src, dout, sink);
+  CK(hipDeviceSynchronize());
+  CK(hipMemcpy(h.data(), dout, h.size() * 8, hipMemcpyDeviceToHost));
+  double cyc = 0, rt = 0;
+  for (size_t i = 0; i < h.size(); i += 2) { cyc += (double)h[i]; rt += (double)h[i + 1]; }
+  cyc /= (h.size() / 2); rt /= (h.size() / 2);
+  printf("  NW=%d blocks=%3d %-34s %7.1f shader cycles/stage   %6.3f us/stage   clock %.2f GHz\n", NW, blocks, name, cyc / STAGES,
+         rt * 0.01 / STAGES, cyc / (rt * 10.0));
+}
+
+template <int NW>
+void all(const char* src, unsigned long long* dout, float* sink, int blocks) {
+  run<M_MFMA, NW>("mfma", src, dout, sink, blocks);
+  run<M_DMA, NW>("dma", src, dout, sink, blocks);
+  run<M_GLOAD, NW>("gload", src, dout, sink, blocks);
+  run<M_DSREAD, NW>("ds_read", src, dout, sink, blocks);
+  run<M_MFMA | M_DSREAD, NW>("mfma + ds_read", src, dout, sink, blocks);
+  run<M_MFMA | M_DMA, NW>("mfma + dma", src, dout, sink, blocks);
+  run<M_MFMA | M_GLOAD, NW>("mfma + gload", src, dout, sink, blocks);
+  run<M_MFMA | M_DMA | M_DSREAD, NW>("mfma + dma + ds_read (the kernel)", src, dout, sink, blocks);
+  run<M_MFMA | M_GLOAD | M_DSREAD, NW>("mfma + gload + ds_read", src, dout, sink, blocks);
+  run<M_DMA | M_DSREAD, NW>("dma + ds_read", src, dout, sink, blocks);
+}
+
+int main() {
+  char* src; unsigned long long* dout; float* sink;
+  CK(hipMalloc(&src, (size_t)4 << 20)); CK(hipMemset(src, 1, (size_t)4 << 20));
+  CK(hipMalloc(&dout, 256 * 8 * 2 * 8)); CK(hipMalloc(&sink, 64));
+  for (int blocks : {1, 200}) {
+    printf("blocks=%d (1 = one CU alone, 200 = the B=8 grid)\n", blocks);
+    all<4>(src, dout, sink, blocks);
+    all<8>(src, dout, sink, blocks);
+  }
+  return 0;
+}

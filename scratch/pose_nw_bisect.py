@@ -39,3 +39,10 @@ for layers in (1, 2, 6):
     ref = snaps[("4", "4")]
     for key, b in snaps.items():
         print(f"L={layers} NW={key[0]} MT={key[1]}:", {k: ("same" if np.array_equal(v, ref[k]) else "DIFF") for k, v in b.items()}, flush=True)
+        if layers == 1 and key != ("4", "4"):
+            for name, dt, cols in (("x", np.float32, 256), ("vt", np.uint16, 448), ("qk", np.uint16, 512)):
+                a, r = b[name].view(dt).reshape(-1, cols), ref[name].view(dt).reshape(-1, cols)
+                bad = np.argwhere(a != r)
+                if len(bad):
+                    rows, cs = np.unique(bad[:, 0]), np.unique(bad[:, 1])
+                    print(f"     {name}: {len(bad)} differing elements, rows {rows[:12].tolist()}..{rows[-3:].tolist()} ({len(rows)} rows), cols {cs[:12].tolist()}..{cs[-3:].tolist()} ({len(cs)} cols)", flush=True)
