@@ -56,12 +56,14 @@ __device__ __forceinline__ float wave_sum(float v) {
 // activations (torch definitions)
 __device__ __forceinline__ float act_gelu(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
 // bf16-mode GELU: erf by Abramowitz-Stegun 7.1.26 (|abs err| <= 1.5e-7), v_rcp/v_exp instead of ocml erff
+// (every multiply-add is an explicit fmaf: the result must not depend on which kernel instantiation inlines it)
 __device__ __forceinline__ float act_gelu_fast(float x) {
   const float z = fabsf(x) * 0.70710678118654752440f;
   const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, z, 1.0f));
   const float poly = t * fmaf(t, fmaf(t, fmaf(t, fmaf(t, 1.061405429f, -1.453152027f), 1.421413741f), -0.284496736f), 0.254829592f);
-  const float e = 1.0f - poly * __builtin_amdgcn_exp2f(-z * z * 1.4426950408889634f);  // erf(|x|/sqrt2)
-  return 0.5f * x * (1.0f + copysignf(e, x));
+  const float e = fmaf(-poly, __builtin_amdgcn_exp2f((-z * z) * 1.4426950408889634f), 1.0f);  // erf(|x|/sqrt2)
+  const float h = 0.5f * x;
+  return fmaf(h, copysignf(e, x), h);
 }
 __device__ __forceinline__ float act_softplus(float x) { return x > 20.0f ? x : log1pf(expf(x)); }
 __device__ __forceinline__ float act_mish(float x) { return x * tanhf(act_softplus(x)); }

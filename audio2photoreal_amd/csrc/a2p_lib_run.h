@@ -213,7 +213,8 @@ static void chain_set_out_proj(a2p_ctx* c, ChainP& p, const std::string& attn, c
 }
 
 // Workgroup shape of the chain kernels for a forward of `rows` rows: 4 waves (one 512-register wave per SIMD) or 8 (two
-// 256-register waves per SIMD, panels of at most 48 / 64 rows).  Both give bit-identical results (kernels_chain.h ln_stats).
+// 256-register waves per SIMD, panels of at most 48 / 64 rows).  Both give bit-identical results for both model widths
+// (kernels_chain.h: one shared LayerNorm reduction tree, no floating-point contraction; tests/test_hip_round2.py).
 // Which one is faster depends on the BOX, not on the code: on most MI355X boxes NW=4 leads by 3-5 % at B=8, on a sizeable
 // minority the 512-register kernels run 35 % slower inside the step (not in isolation) and NW=8 leads by 19 % (DESIGN.md
 // section 6).  So it is measured in situ: forwards 1..4 of a given size alternate the two shapes with an event pair around
@@ -222,10 +223,6 @@ static const int kTuneForwards = 5;
 static int chain_pick_nw(a2p_ctx* c, int64_t rows, hipEvent_t* e0, hipEvent_t* e1) {
   *e0 = *e1 = nullptr;
   if (const char* f = getenv("A2P_CHAIN_NW")) return atoi(f) == 8 ? 8 : 4;
-  // d = 256 (body model): the two shapes agree bit-for-bit at B=16 / T=600 but differ at bf16-rounding level (max |diff| 2e-2)
-  // on small forwards (B=3..4, T~450) for a reason not yet found (scratch/pose_nw_check.py); until it is, the body model
-  // keeps the long-tested 4-wave shape so that results never depend on a timing decision.
-  if (c->d != 512) return 4;
   if (const char* m = getenv("A2P_CHAIN_MT")) {  // a forced panel height the 8-wave kernels do not have
     const int mt = atoi(m);
     if (mt > (c->d == 512 ? 3 : 4)) return 4;

@@ -40,3 +40,21 @@ def rel_max(a, b):
     import torch
     a, b = torch.as_tensor(a).double(), torch.as_tensor(b).double()
     return float((a - b).abs().max() / b.abs().max())
+
+
+_LOG = os.path.join(ROOT, "gpurun_out", "parity_tests.json")
+
+
+def record(name, **vals):
+    """Append measured numbers to gpurun_out/parity_tests.json (merged back from the GPU box; `pytest -q` swallows prints)."""
+    import json
+    os.makedirs(os.path.dirname(_LOG), exist_ok=True)
+    data = {}
+    if os.path.exists(_LOG):
+        try:
+            data = json.load(open(_LOG))
+        except Exception:
+            data = {}
+    data[name] = {k: (float(f"{v:.4e}") if isinstance(v, float) else v) for k, v in vals.items()}
+    json.dump(data, open(_LOG, "w"), indent=1, sort_keys=True)
+    print(name, data[name])

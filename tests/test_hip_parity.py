@@ -15,7 +15,7 @@ from audio2photoreal_amd.model.cfg_sampler import ClassifierFreeSampleModel
 from audio2photoreal_amd.model_util import create_model_and_diffusion, default_args, load_model
 from audio2photoreal_amd.spec import face_spec, pose_spec
 from audio2photoreal_amd.synthetic import synthetic_inputs, synthetic_state_dict, synthetic_tensor
-from conftest import rel_l2, rel_max
+from conftest import record, rel_l2, rel_max
 
 pytestmark = pytest.mark.gpu
 SEED = 10
@@ -112,7 +112,7 @@ def test_decoder_layer_vs_reference_golden(dev, golden, precision, fmt):
     _lib.check(_lib.load().a2p_decoder_layer_forward(model._ctx, 0, _lib.ptr(x), _lib.ptr(mem), _lib.ptr(t), _lib.ptr(mem2),
                                                      2, 48, 80, 8 if spec.is_pose else 0, _lib.current_stream()), "layer")
     err = rel_l2(x.cpu(), golden[f"{fmt}/layer0"])
-    print(f"decoder layer {fmt} {precision}: rel L2 = {err:.3e}")
+    record(f"layer0/{fmt}/{precision}", rel_l2=err)
     assert err < (1e-4 if precision == "fp32" else 2e-2)
 
 
@@ -133,7 +133,7 @@ def test_forward_vs_reference_golden(dev, golden, precision, fmt):
     g = ClassifierFreeSampleModel(model)(x, times, y)
     errs = (rel_l2(c.cpu(), golden[f"{fmt}/fwd_cond"]), rel_l2(u.cpu(), golden[f"{fmt}/fwd_uncond"]),
             rel_l2(g.cpu(), golden[f"{fmt}/fwd_cfg"]))
-    print(f"forward {fmt} {precision}: cond/uncond/cfg rel L2 = {errs}")
+    record(f"fwd240/{fmt}/{precision}", cond=errs[0], uncond=errs[1], cfg=errs[2])
     tol = 2e-4 if precision == "fp32" else 5e-2
     assert all(e < tol for e in errs[:2]) and errs[2] < 5 * tol, errs
     if spec.is_pose:   # the reference zeroes masked keyframes in y, in place (model/diffusion.py:320)
@@ -243,7 +243,7 @@ def test_bf16_mode_error_reported(dev, golden):
     res = make_diffusion("face", "ddim10").ddim_sample_loop(ClassifierFreeSampleModel(model), (1, spec.nfeats, 1, 240),
                                                             clip_denoised=False, model_kwargs={"y": y}, noise=inp["x_T"].to(dev))
     e = rel_l2(res.cpu(), golden["face/ddim10"])
-    print(f"bf16 ddim10 face: rel L2 vs fp32 reference = {e:.3e}")
+    record("ddim10_240/face/bf16", rel_l2=e)
     assert e < 0.1
 
 
@@ -291,7 +291,7 @@ def test_chain_kernels_match_the_per_op_kernels_bf16(dev, golden, fmt, mt, monke
     monkeypatch.delenv("A2P_NO_CHAIN")
     ref = golden[f"{fmt}/fwd_cfg"]
     e_pair, e_gold, e_old = rel_l2(chained, per_op), rel_l2(chained, ref), rel_l2(per_op, ref)
-    print(f"chain {fmt} MT={mt}: vs per-op {e_pair:.3e}; vs fp32 reference: chain {e_gold:.3e}, per-op {e_old:.3e}")
+    record(f"chain_vs_perop/{fmt}/MT{mt}", pair=e_pair, chain_vs_golden=e_gold, perop_vs_golden=e_old)
     assert e_pair < 3e-2 and e_gold < 0.25 and e_gold < 2.0 * e_old + 1e-3
 
 
@@ -316,7 +316,7 @@ def test_chain_kernels_with_frame_counts_that_are_not_a_multiple_of_4(dev, fmt, 
     ref = den.forward_cfg(inp["x_T"][:2], times[:2].cpu(), inp["cond_embed"][:2], torch.full((2,), scale),
                           inp.get("keyframes", [None])[:2] if spec.is_pose else None, inp["mask"][:2] if spec.is_pose else None)
     e_pair, e_ref = rel_l2(chained, per_op), rel_l2(chained[:2], ref)
-    print(f"T={frames} {fmt}: chain vs per-op {e_pair:.3e}, chain vs oracle {e_ref:.3e}, per-op vs oracle {rel_l2(per_op[:2], ref):.3e}")
+    record(f"chain_ragged/{fmt}/T{frames}", pair=e_pair, chain_vs_oracle=e_ref, perop_vs_oracle=rel_l2(per_op[:2], ref))
     assert e_pair < 3e-2 and e_ref < 0.25
 
 

@@ -4,7 +4,6 @@ bit-identity of the chain kernels' workgroup shapes for the body model.
 
 Measured errors are written to gpurun_out/parity_tests.json (pytest -q swallows prints) so a run leaves its numbers behind.
 """
-import json
 import os
 import socket
 import subprocess
@@ -17,26 +16,10 @@ from audio2photoreal_amd.model.cfg_sampler import ClassifierFreeSampleModel
 from audio2photoreal_amd.model_util import create_gaussian_diffusion, create_model_and_diffusion, default_args, load_model
 from audio2photoreal_amd.spec import face_spec, pose_spec
 from audio2photoreal_amd.synthetic import synthetic_inputs, synthetic_state_dict, synthetic_tensor
-from conftest import ROOT, rel_l2, rel_max
+from conftest import ROOT, record, rel_l2, rel_max
 
 pytestmark = pytest.mark.gpu
 SEED = 10
-_LOG = os.path.join(ROOT, "gpurun_out", "parity_tests.json")
-
-
-def record(name, **vals):
-    """Append measured numbers to gpurun_out/parity_tests.json (merged back from the GPU box)."""
-    os.makedirs(os.path.dirname(_LOG), exist_ok=True)
-    data = {}
-    if os.path.exists(_LOG):
-        try:
-            data = json.load(open(_LOG))
-        except Exception:
-            data = {}
-    data[name] = {k: (float(f"{v:.4e}") if isinstance(v, float) else v) for k, v in vals.items()}
-    json.dump(data, open(_LOG, "w"), indent=1, sort_keys=True)
-    print(name, data[name])
-
 
 @pytest.fixture(scope="module")
 def dev():
