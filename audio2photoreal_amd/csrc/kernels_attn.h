@@ -98,6 +98,9 @@ __global__ __launch_bounds__(256, 3) void attn_kernel(AttnP p) {
   const int l15 = lane & 15, g = lane >> 4;
   const int seq = blockIdx.z, head = blockIdx.y;
   const int q0 = blockIdx.x * BQ + wid * (QT * 16);
+  // waves of the last query block whose whole range lies past Tq (T=600: 1 of 20 waves) still take part in the tile DMA and
+  // the barriers but skip the MFMA / softmax work: their issue slots go to the co-resident waves
+  const bool wave_active = __builtin_amdgcn_readfirstlane(q0) < p.Tq;
   const int slot = p.kv_slot ? p.kv_slot[seq] : seq;
   const bool kv_nt = p.kv_stream && slot != 0;  // slot 0 (null conditioning) is shared by the whole unconditional half: keep it cached
   const int S_total = p.S_main + p.S_tail;
@@ -219,6 +222,7 @@ __global__ __launch_bounds__(256, 3) void attn_kernel(AttnP p) {
       __syncthreads();
     }
 
+    if (!wave_active) return;
     // ---- S^T = K Q^T for 4 key tiles x QT query tiles ----
     f32x4 s[4][QT];
 #pragma unroll

@@ -101,7 +101,12 @@ __global__ __launch_bounds__(256) void chain_pack_kernel(const ChainPackDesc* __
   const int cw = 128 / nw;  // out-cols (weight rows) per wave: 32 (4 waves) or 16 (8 waves)
   for (int q = threadIdx.x; q < 1024; q += 256) {  // 16-byte chunk q = (wave, row-in-slice, chunk position)
     const int w = q / (cw * 8), r = (q % (cw * 8)) >> 3, pos = q & 7;
-    const int row = d.row0 + w * cw + r, chunk = pos ^ ((r >> 1) & 7);
+    // Column ownership (chain_kernel::col_of): MFMA sub-tile row i = 4*g + e of 16-column sub-tile J of 32-column group W4 is
+    // output column W4*32 + g*8 + J*4 + e, so that the two sub-tiles of a 4-wave lane are ADJACENT (8 contiguous columns per
+    // lane: 16-byte bf16 stores / LDS writes, 32 contiguous bytes of the fp32 residual).  4 waves: W4 = w, J = r >> 4;
+    // 8 waves: W4 = w >> 1, J = w & 1 -- the same column sets per (W4, J), which keeps the two shapes bit-identical.
+    const int w4 = nw == 4 ? w : (w >> 1), J = nw == 4 ? (r >> 4) : (w & 1), i = r & 15;
+    const int row = d.row0 + w4 * 32 + (i >> 2) * 8 + J * 4 + (i & 3), chunk = pos ^ ((r >> 1) & 7);
     uint4 v = make_uint4(0, 0, 0, 0);
     if (row < d.nrows) v = *reinterpret_cast<const uint4*>(d.W + (int64_t)row * d.ldw + d.k0 + chunk * 8);
     out[q] = v;
@@ -133,6 +138,10 @@ __device__ __forceinline__ f32x4 chain_ld4(const float* p) {
 __device__ __forceinline__ void chain_st4(float* p, f32x4 v) {
   if constexpr (CHAIN_NT_ST) __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(p));
   else *reinterpret_cast<f32x4*>(p) = v;
+}
+__device__ __forceinline__ void chain_st_bf8(bf16_t* p, bf16x8 v) {
+  if constexpr (CHAIN_NT_ST) __builtin_nontemporal_store(v, reinterpret_cast<bf16x8*>(p));
+  else *reinterpret_cast<bf16x8*>(p) = v;
 }
 __device__ __forceinline__ void chain_st_bf4(bf16_t* p, bf16x4 v) {
   if constexpr (CHAIN_NT_ST) __builtin_nontemporal_store(v, reinterpret_cast<bf16x4*>(p));
@@ -176,6 +185,7 @@ __global__ __launch_bounds__(64 * NW, 1) void chain_kernel(const ChainP p) {
 
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int l15 = lane & 15, g = lane >> 4;
+  const int W4 = NW == 4 ? wid : (wid >> 1), J0 = NW == 4 ? 0 : (wid & 1);  // 32-column group and first 16-column sub-tile of this wave
   const int m0 = blockIdx.x * BM;
   auto stamp = [&](int i) __attribute__((always_inline)) {
     if constexpr (ABL & 64) {
@@ -192,9 +202,11 @@ __global__ __launch_bounds__(64 * NW, 1) void chain_kernel(const ChainP p) {
 
   // ---- weight stream ---------------------------------------------------------------------------------------
   const bf16_t* wsrc = p.stream + wid * WSLICE + lane * 8;  // this lane's 16 bytes of instruction 0 of stage 0
-  int issued = 0;
+  // ring positions as running element offsets with a compare-and-wrap (a `% NS` with NS = 5 costs a multiply-high chain of
+  // scalar instructions per stage, and with one wave per SIMD every instruction is 4 issue cycles)
+  int issue_off = 0, consume_off = 0;
   auto issue_stage = [&]() __attribute__((always_inline)) {
-    bf16_t* buf = myring + (issued % NS) * WSLICE;
+    bf16_t* buf = myring + issue_off;
     if constexpr (!(ABL & 4)) {  // 4 x 1 KiB; the instruction offset advances the global AND the LDS address (one M0 write per stage)
       const auto gp = (const __attribute__((address_space(1))) void*)wsrc;
       const auto lp = (__attribute__((address_space(3))) void*)buf;
@@ -206,9 +218,8 @@ __global__ __launch_bounds__(64 * NW, 1) void chain_kernel(const ChainP p) {
       }
     }
     wsrc += CHAIN_STAGE_ELEMS;  // past the end of the stream: the host pads CHAIN_STREAM_PAD stages
-    ++issued;
+    issue_off = issue_off + WSLICE == NS * WSLICE ? 0 : issue_off + WSLICE;
   };
-  int consumed = 0;
   // wait for this wave's oldest slice (NS-2 newer ones stay in flight), hand the just-freed slot to the DMA
   auto stage_begin = [&]() __attribute__((always_inline)) -> const bf16_t* {
     // lgkmcnt(0): the fragment reads of the slot that is about to be refilled have returned
@@ -217,8 +228,8 @@ __global__ __launch_bounds__(64 * NW, 1) void chain_kernel(const ChainP p) {
     // reads, which un-pipelines the loop (cdna_hip_programming.md §5.4 rule 18)
     __builtin_amdgcn_sched_barrier(0);
     issue_stage();
-    const bf16_t* wb = myring + (consumed % NS) * WSLICE;
-    ++consumed;
+    const bf16_t* wb = myring + consume_off;
+    consume_off = consume_off + WSLICE == NS * WSLICE ? 0 : consume_off + WSLICE;
     return wb;
   };
   // one k-step (64) of a [BM x 128] tile = this wave's fragments of 2 MFMA k-chunks.  Reads and MFMAs are split so the
@@ -307,12 +318,12 @@ __global__ __launch_bounds__(64 * NW, 1) void chain_kernel(const ChainP p) {
   auto init_bias = [&](f32x4(&acc)[MT][NJ], const float* bias_lds) __attribute__((always_inline)) {
     f32x4 b[2];
     if constexpr (NJ == 2)
-      asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %2 offset:64\n\ts_waitcnt lgkmcnt(0)"
+      asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %2 offset:16\n\ts_waitcnt lgkmcnt(0)"
                    : "=&v"(b[0]), "=&v"(b[1])
-                   : "v"(lds_off(bias_lds + wid * CW + g * 4))
+                   : "v"(lds_off(bias_lds + W4 * 32 + g * 8))
                    : "memory");
     else
-      asm volatile("ds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=&v"(b[0]) : "v"(lds_off(bias_lds + wid * CW + g * 4)) : "memory");
+      asm volatile("ds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=&v"(b[0]) : "v"(lds_off(bias_lds + W4 * 32 + g * 8 + J0 * 4)) : "memory");
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int j = 0; j < NJ; ++j)
@@ -323,20 +334,21 @@ __global__ __launch_bounds__(64 * NW, 1) void chain_kernel(const ChainP p) {
   auto init_bias_t = [&](f32x4(&acc)[MT][NJ], const float* bias_lds) __attribute__((always_inline)) {
     float b[2];
     if constexpr (NJ == 2)
-      asm volatile("ds_read_b32 %0, %2\n\tds_read_b32 %1, %2 offset:64\n\ts_waitcnt lgkmcnt(0)"
+      asm volatile("ds_read_b32 %0, %2\n\tds_read_b32 %1, %2 offset:16\n\ts_waitcnt lgkmcnt(0)"
                    : "=&v"(b[0]), "=&v"(b[1])
-                   : "v"(lds_off(bias_lds + wid * CW + l15))
+                   : "v"(lds_off(bias_lds + W4 * 32 + (l15 >> 2) * 8 + (l15 & 3)))
                    : "memory");
     else
-      asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=&v"(b[0]) : "v"(lds_off(bias_lds + wid * CW + l15)) : "memory");
+      asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=&v"(b[0]) : "v"(lds_off(bias_lds + W4 * 32 + (l15 >> 2) * 8 + J0 * 4 + (l15 & 3))) : "memory");
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int j = 0; j < NJ; ++j)
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt) acc[mt][j] = f32x4{b[j], b[j], b[j], b[j]};
   };
-  // column of sub-tile (tile t, half j) for this lane
-  auto col_of = [&](int t, int j) __attribute__((always_inline)) { return t * 128 + wid * CW + j * 16 + g * 4; };
+  // first of the 4 consecutive output columns this lane holds of sub-tile (tile t, half j): see chain_pack_kernel.  With 4 waves
+  // the two halves of a lane are adjacent (col_of(t, 1) == col_of(t, 0) + 4)
+  auto col_of = [&](int t, int j) __attribute__((always_inline)) { return t * 128 + W4 * 32 + g * 8 + (J0 + j) * 4; };
 
   // ---- kernel start: panel + aux DMA, residual rows, stream prefetch ----------------------------------------
   f32x4 xrow[MT][NSUB];
@@ -382,30 +394,36 @@ __global__ __launch_bounds__(64 * NW, 1) void chain_kernel(const ChainP p) {
 #pragma unroll
     for (int j = 0; j < NJ; ++j) b[j] = *reinterpret_cast<const f32x4*>(bias + col_of(t, j));
     if (film) {
-      f32x4 sc[NJ][MT], sh[NJ][MT];
+      // tall panels (MT >= 4 with 512-register waves): one batch per column half instead of one per tile -- half the live FiLM
+      // operands (the single-batch form spilled into the FFN loop), one more L2 round trip per tile
+      constexpr int JB = (MT >= 4 && NW == 4) ? 1 : NJ;
 #pragma unroll
-      for (int j = 0; j < NJ; ++j)
+      for (int j0 = 0; j0 < NJ; j0 += JB) {
+        f32x4 sc[JB][MT], sh[JB][MT];
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt) {
-          const float* fp = film + (int64_t)row_seq[mt] * p.film_seq_stride + col_of(t, j);
-          sc[j][mt] = *reinterpret_cast<const f32x4*>(fp);
-          sh[j][mt] = *reinterpret_cast<const f32x4*>(fp + p.film_shift_off);
+        for (int j = 0; j < JB; ++j)
+#pragma unroll
+          for (int mt = 0; mt < MT; ++mt) {
+            const float* fp = film + (int64_t)row_seq[mt] * p.film_seq_stride + col_of(t, j0 + j);
+            sc[j][mt] = *reinterpret_cast<const f32x4*>(fp);
+            sh[j][mt] = *reinterpret_cast<const f32x4*>(fp + p.film_shift_off);
+          }
+#pragma unroll
+        for (int j = 0; j < JB; ++j) {
+          asm volatile("" : "+v"(b[j0 + j]));
+#pragma unroll
+          for (int mt = 0; mt < MT; ++mt) asm volatile("" : "+v"(sc[j][mt]), "+v"(sh[j][mt]));
         }
 #pragma unroll
-      for (int j = 0; j < NJ; ++j) {
-        asm volatile("" : "+v"(b[j]));
+        for (int j = 0; j < JB; ++j)
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt) asm volatile("" : "+v"(sc[j][mt]), "+v"(sh[j][mt]));
+          for (int mt = 0; mt < MT; ++mt) {
+            f32x4& xr = xrow[mt][t * NJ + j0 + j];
+            const f32x4 y = acc[mt][j0 + j] + b[j0 + j], s1 = sc[j][mt] + 1.0f;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) xr[e] += fmaf(s1[e], y[e], sh[j][mt][e]);
+          }
       }
-#pragma unroll
-      for (int j = 0; j < NJ; ++j)
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt) {
-          f32x4& xr = xrow[mt][t * NJ + j];
-          const f32x4 y = acc[mt][j] + b[j], s1 = sc[j][mt] + 1.0f;
-#pragma unroll
-          for (int e = 0; e < 4; ++e) xr[e] += fmaf(s1[e], y[e], sh[j][mt][e]);
-        }
     } else {
 #pragma unroll
       for (int j = 0; j < NJ; ++j)
@@ -496,23 +514,34 @@ __global__ __launch_bounds__(64 * NW, 1) void chain_kernel(const ChainP p) {
         for (int mt = 0; mt < MT; ++mt) asm volatile("" : "+v"(cs[mt][ns]));
       }
     }
+    // rows -> bf16 panel: with 4 waves a lane's two sub-tiles are adjacent columns, so one 16-byte LDS write per (row, tile)
+    auto norm4 = [&](int mt, int ns) __attribute__((always_inline)) -> bf16x4 {
+      // (x - mean) * rstd as one fma per element: x * rstd + (-mean * rstd)
+      const float rs = ln_rstd[mt], nm = -ln_mean[mt] * rs;
+      float v0 = fmaf(fmaf(xrow[mt][ns][0], rs, nm), ga[ns][0], be[ns][0]);
+      float v1 = fmaf(fmaf(xrow[mt][ns][1], rs, nm), ga[ns][1], be[ns][1]);
+      float v2 = fmaf(fmaf(xrow[mt][ns][2], rs, nm), ga[ns][2], be[ns][2]);
+      float v3 = fmaf(fmaf(xrow[mt][ns][3], rs, nm), ga[ns][3], be[ns][3]);
+      if constexpr (ROPE) {
+        const f32x4 t = cs[mt][ns];
+        const float r0 = fmaf(v0, t[0], -(v1 * t[1])), r1 = fmaf(v1, t[0], v0 * t[1]);
+        const float r2 = fmaf(v2, t[2], -(v3 * t[3])), r3 = fmaf(v3, t[2], v2 * t[3]);
+        v0 = r0; v1 = r1; v2 = r2; v3 = r3;
+      }
+      return bf16x4{(bf16_t)v0, (bf16_t)v1, (bf16_t)v2, (bf16_t)v3};
+    };
 #pragma unroll
-    for (int ns = 0; ns < NSUB; ++ns) {
-      const int n = col_of(ns / NJ, ns % NJ);
+    for (int t = 0; t < NT; ++t) {
+      const int n = col_of(t, 0);
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt) {
-        float v0 = fmaf((xrow[mt][ns][0] - ln_mean[mt]) * ln_rstd[mt], ga[ns][0], be[ns][0]);
-        float v1 = fmaf((xrow[mt][ns][1] - ln_mean[mt]) * ln_rstd[mt], ga[ns][1], be[ns][1]);
-        float v2 = fmaf((xrow[mt][ns][2] - ln_mean[mt]) * ln_rstd[mt], ga[ns][2], be[ns][2]);
-        float v3 = fmaf((xrow[mt][ns][3] - ln_mean[mt]) * ln_rstd[mt], ga[ns][3], be[ns][3]);
-        if constexpr (ROPE) {
-          const f32x4 t = cs[mt][ns];
-          const float r0 = fmaf(v0, t[0], -(v1 * t[1])), r1 = fmaf(v1, t[0], v0 * t[1]);
-          const float r2 = fmaf(v2, t[2], -(v3 * t[3])), r3 = fmaf(v3, t[2], v2 * t[3]);
-          v0 = r0; v1 = r1; v2 = r2; v3 = r3;
+        bf16_t* dst = panelA + (mt * 16 + l15) * D + ((((n >> 3) ^ l15) << 3) | (n & 7));
+        if constexpr (NJ == 2) {
+          const bf16x4 lo = norm4(mt, t * NJ), hi = norm4(mt, t * NJ + 1);
+          *reinterpret_cast<bf16x8*>(dst) = bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        } else {
+          *reinterpret_cast<bf16x4*>(dst) = norm4(mt, t);
         }
-        const bf16x4 o = {(bf16_t)v0, (bf16_t)v1, (bf16_t)v2, (bf16_t)v3};
-        *reinterpret_cast<bf16x4*>(panelA + (mt * 16 + l15) * D + ((((n >> 3) ^ l15) << 3) | (n & 7))) = o;
       }
     }
     chain_bar();  // the panel is complete before any wave's fragment reads
@@ -535,24 +564,40 @@ __global__ __launch_bounds__(64 * NW, 1) void chain_kernel(const ChainP p) {
       if (!transposed) init_bias(acc, bias_lds + t * 128);
       else init_bias_t(acc, bias_lds + t * 128);
       gemm_tile(acc, panelA, D, KS, transposed);
-#pragma unroll
-      for (int j = 0; j < NJ; ++j) {
+      if (!transposed) {  // 8 (4 waves) / 4 (8 waves) contiguous columns per lane: one 16- / 8-byte store per row
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
-          const f32x4 v = acc[mt][j];
           if constexpr (ABL & 1) {
-            asm volatile("" ::"v"(v));
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) asm volatile("" ::"v"(acc[mt][j]));
             continue;
           }
-          const bf16x4 o = {(bf16_t)v[0], (bf16_t)v[1], (bf16_t)v[2], (bf16_t)v[3]};
-          if (!transposed) {
-            if (m0 + mt * 16 + l15 >= p.M) continue;
-            chain_st_bf4(out + (int64_t)row_m[mt] * ldo + col_of(t, j), o);
-          } else {  // rows m .. m+3 (m % 4 == 0) of column n: one 8-byte store when the frame count is a multiple of 4 (the
-                    // four rows then share a sequence and the address is aligned), else row by row (T = 30 k frames, k odd)
+          if (m0 + mt * 16 + l15 >= p.M) continue;
+          bf16_t* dst = out + (int64_t)row_m[mt] * ldo + col_of(t, 0);
+          const f32x4 v = acc[mt][0];
+          if constexpr (NJ == 2) {
+            const f32x4 u = acc[mt][1];
+            chain_st_bf8(dst, bf16x8{(bf16_t)v[0], (bf16_t)v[1], (bf16_t)v[2], (bf16_t)v[3], (bf16_t)u[0], (bf16_t)u[1], (bf16_t)u[2], (bf16_t)u[3]});
+          } else {
+            chain_st_bf4(dst, bf16x4{(bf16_t)v[0], (bf16_t)v[1], (bf16_t)v[2], (bf16_t)v[3]});
+          }
+        }
+      } else {
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+#pragma unroll
+          for (int mt = 0; mt < MT; ++mt) {
+            const f32x4 v = acc[mt][j];
+            if constexpr (ABL & 1) {
+              asm volatile("" ::"v"(v));
+              continue;
+            }
+            const bf16x4 o = {(bf16_t)v[0], (bf16_t)v[1], (bf16_t)v[2], (bf16_t)v[3]};
+            // rows m .. m+3 (m % 4 == 0) of column n: one 8-byte store when the frame count is a multiple of 4 (the four rows
+            // then share a sequence and the address is aligned), else row by row (T = 30 k frames, k odd)
             const int m = m0 + mt * 16 + g * 4;
             if (m >= p.M) continue;
-            const int sq = m / p.rows_per_seq, n = t * 128 + wid * CW + j * 16 + l15;
+            const int sq = m / p.rows_per_seq, n = t * 128 + W4 * 32 + (l15 >> 2) * 8 + (J0 + j) * 4 + (l15 & 3);
             if ((p.rows_per_seq & 3) == 0) {
               chain_st_bf4(out + (int64_t)sq * p.vt_seq_stride + (int64_t)n * ldo + (m - sq * p.rows_per_seq), o);
             } else {
@@ -624,15 +669,20 @@ __global__ __launch_bounds__(64 * NW, 1) void chain_kernel(const ChainP p) {
         init_bias(acc, aux + h * 128);
         gemm_tile(acc, panelA, D, KS);
         if (h > 0 && !(ABL & 8)) chain_bar();  // every wave finished the linear2 partial of the previous chunk
-#pragma unroll
-        for (int j = 0; j < NJ; ++j) {
-          const int c = wid * CW + j * 16 + g * 4;  // column inside the hidden chunk
+        {
+          const int c = W4 * 32 + g * 8 + J0 * 4;  // first column inside the hidden chunk (col_of within the tile)
+          auto gelu4 = [&](const f32x4 v) __attribute__((always_inline)) {
+            return bf16x4{(bf16_t)act_gelu_fast(v[0]), (bf16_t)act_gelu_fast(v[1]), (bf16_t)act_gelu_fast(v[2]), (bf16_t)act_gelu_fast(v[3])};
+          };
 #pragma unroll
           for (int mt = 0; mt < MT; ++mt) {
-            const f32x4 v = acc[mt][j];
-            const bf16x4 o = {(bf16_t)act_gelu_fast(v[0]), (bf16_t)act_gelu_fast(v[1]), (bf16_t)act_gelu_fast(v[2]),
-                              (bf16_t)act_gelu_fast(v[3])};
-            *reinterpret_cast<bf16x4*>(panelH + (mt * 16 + l15) * HLD + ((((c >> 3) ^ l15) << 3) | (c & 7))) = o;
+            bf16_t* dst = panelH + (mt * 16 + l15) * HLD + ((((c >> 3) ^ l15) << 3) | (c & 7));
+            if constexpr (NJ == 2) {
+              const bf16x4 lo = gelu4(acc[mt][0]), hi = gelu4(acc[mt][1]);
+              *reinterpret_cast<bf16x8*>(dst) = bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+            } else {
+              *reinterpret_cast<bf16x4*>(dst) = gelu4(acc[mt][0]);
+            }
           }
         }
         if (!(ABL & 8)) chain_bar();  // the hidden chunk is complete
