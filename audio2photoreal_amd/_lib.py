@@ -12,6 +12,9 @@ from typing import Optional
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("A2P_LIB") or os.path.join(_HERE, "liba2p_hip.so")   # A2P_LIB: A/B builds of the kernels
+# The same sources built with -DA2P_HALF: the 16-bit operand type of the throughput mode is IEEE half instead of bfloat16
+# (precision="fp16"; csrc/a2p_common.h).  Same C ABI, same exports.
+LIB_PATH_F16 = os.environ.get("A2P_LIB_F16") or os.path.join(_HERE, "liba2p_hip_f16.so")
 
 FACE, POSE = 0, 1
 PREC_F32, PREC_BF16 = 0, 1
@@ -52,22 +55,22 @@ class A2PError(RuntimeError):
     pass
 
 
-_lib: Optional[C.CDLL] = None
+_libs = {}
 
 
-def load() -> C.CDLL:
-    """Load the shared library or raise (never falls back)."""
-    global _lib
-    if _lib is not None:
-        return _lib
+def load(half: bool = False) -> C.CDLL:
+    """Load the shared library (`half`: the IEEE-half build) or raise (never falls back)."""
+    if half in _libs:
+        return _libs[half]
     # torch first: its bundled libamdhip64.so.7 must be the one HIP runtime of the process (the
     # library shares torch's device pointers and streams; loading /opt/rocm's copy first breaks both)
     import torch  # noqa: F401
-    if not os.path.exists(LIB_PATH):
+    path = LIB_PATH_F16 if half else LIB_PATH
+    if not os.path.exists(path):
         raise A2PError(
-            f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            f"{path} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             "(hipcc --offload-arch=gfx950).  There is no CPU fallback.")
-    lib = C.CDLL(LIB_PATH)
+    lib = C.CDLL(path)
     vp, i32, i64, f32 = C.c_void_p, C.c_int32, C.c_int64, C.c_float
     lib.a2p_last_error.restype = C.c_char_p
     lib.a2p_version.restype = C.c_char_p
@@ -106,13 +109,14 @@ def load() -> C.CDLL:
         fn = getattr(lib, name)
         fn.argtypes = args
         fn.restype = C.c_int
-    _lib = lib
+    _libs[half] = lib
     return lib
 
 
 def check(rc: int, what: str) -> int:
     if rc < 0:
-        raise A2PError(f"{what} failed ({rc}): {load().a2p_last_error().decode()}")
+        msg = b"; ".join(l.a2p_last_error() for l in _libs.values() if l.a2p_last_error())   # the failing library set it
+        raise A2PError(f"{what} failed ({rc}): {msg.decode()}")
     return rc
 
 

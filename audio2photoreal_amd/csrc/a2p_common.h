@@ -4,9 +4,19 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+// The 16-bit operand type of the throughput mode.  Default build: bfloat16 (the dtype BASELINE's configs name).  The SAME sources
+// compiled with -DA2P_HALF give liba2p_hip_f16.so, where every "bf16" below is IEEE half: same MFMA rate (v_mfma_f32_16x16x32_f16),
+// 3 more mantissa bits -- the rounding error of every staged operand drops 8x (precision="fp16" on the Python side; measured
+// parity in profiles/r02_parity.json).  Accumulation, statistics, the residual stream and the sampler stay fp32 in both.
+#ifdef A2P_HALF
+typedef _Float16 bf16_t;
+#define A2P_MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0)
+#else
 typedef __bf16 bf16_t;
-typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
-typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+#define A2P_MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0)
+#endif
+typedef __attribute__((ext_vector_type(8))) bf16_t bf16x8;
+typedef __attribute__((ext_vector_type(4))) bf16_t bf16x4;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(2))) float f32x2;
 
@@ -33,7 +43,7 @@ struct Prec<bf16_t> {  // v_mfma_f32_16x16x32_bf16
   static constexpr int KCH = 32;
   static constexpr int EPL = 8;
   __device__ static __forceinline__ f32x4 mfma(Frag a, Frag b, f32x4 c) {
-    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+    return A2P_MFMA16(a, b, c);
   }
   __device__ static __forceinline__ Frag load(const bf16_t* p) { return *reinterpret_cast<const bf16x8*>(p); }
 };

@@ -377,7 +377,11 @@ static int make_wt(a2p_ctx* c, const std::string& name, const float* src, int ro
 // context
 // ------------------------------------------------------------------------------------------------
 extern "C" const char* a2p_last_error(void) { return g_err; }
-extern "C" const char* a2p_version(void) { return "a2p_hip 0.1 (gfx950)"; }
+#ifdef A2P_HALF
+extern "C" const char* a2p_version(void) { return "a2p_hip 0.2 (gfx950, 16-bit operands = IEEE half)"; }
+#else
+extern "C" const char* a2p_version(void) { return "a2p_hip 0.2 (gfx950, 16-bit operands = bfloat16)"; }
+#endif
 
 extern "C" int a2p_ctx_create(const a2p_config* cfg, a2p_ctx** out) {
   ARG(cfg && out, "null argument");

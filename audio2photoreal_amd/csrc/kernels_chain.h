@@ -262,8 +262,8 @@ __global__ __launch_bounds__(64 * NW, 1) void chain_kernel(const ChainP p) {
 #pragma unroll
         for (int j = 0; j < NJ; ++j) {
           if constexpr (!(ABL & 2)) {
-            if (swap) acc[mt][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f.a[kk][mt], f.w[kk][j], acc[mt][j], 0, 0, 0);
-            else acc[mt][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f.w[kk][j], f.a[kk][mt], acc[mt][j], 0, 0, 0);
+            if (swap) acc[mt][j] = A2P_MFMA16(f.a[kk][mt], f.w[kk][j], acc[mt][j]);
+            else acc[mt][j] = A2P_MFMA16(f.w[kk][j], f.a[kk][mt], acc[mt][j]);
           } else {
             asm volatile("" ::"v"(f.w[kk][j]), "v"(f.a[kk][mt]));
           }

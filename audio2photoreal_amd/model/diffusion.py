@@ -33,7 +33,10 @@ from torch.nn import functional as F
 from .. import _lib
 from ..spec import DenoiserSpec
 
-_PRECISIONS = {"fp32": _lib.PREC_F32, "f32": _lib.PREC_F32, "bf16": _lib.PREC_BF16}
+# "fp16": the 16-bit throughput mode with IEEE-half operands (liba2p_hip_f16.so, csrc/a2p_common.h A2P_HALF) -- same speed as
+# bf16, 8x smaller operand rounding error; "bf16" is the dtype BASELINE's configs name and the default throughput mode
+_PRECISIONS = {"fp32": _lib.PREC_F32, "f32": _lib.PREC_F32, "bf16": _lib.PREC_BF16, "fp16": _lib.PREC_BF16, "f16": _lib.PREC_BF16}
+_HALF = ("fp16", "f16")
 
 
 def init_weight(m: nn.Module) -> None:
@@ -177,6 +180,7 @@ class FiLMTransformer(nn.Module):
         self.final_layer.apply(init_weight)
 
         self._ctx: Optional[C.c_void_p] = None
+        self._ctx_lib = None
         self._param_list = None
         self._ctx_key = None
         self._weights_key = None
@@ -205,11 +209,14 @@ class FiLMTransformer(nn.Module):
             p.requires_grad = False
         self._param_list = None
 
+    def _lib(self):
+        return _lib.load(half=self.precision in _HALF)
+
     def _ensure_ctx(self, device: torch.device, batch: int):
-        lib = _lib.load()
+        lib = self._lib()
         prec = _PRECISIONS[self.precision]
         cap = max(self.max_batch, batch)
-        key = (str(device), prec, cap)
+        key = (str(device), prec, cap, self.precision in _HALF)
         if self._ctx is not None and self._ctx_key == key:
             return lib
         self.release()
@@ -221,7 +228,7 @@ class FiLMTransformer(nn.Module):
         ctx = C.c_void_p()
         with torch.cuda.device(device):
             _lib.check(lib.a2p_ctx_create(C.byref(cfg), C.byref(ctx)), "a2p_ctx_create")
-        self._ctx, self._ctx_key, self._weights_key = ctx, key, None
+        self._ctx, self._ctx_key, self._weights_key, self._ctx_lib = ctx, key, None, lib
         self.invalidate_cond()
         return lib
 
@@ -263,7 +270,7 @@ class FiLMTransformer(nn.Module):
 
     def release(self):
         if self._ctx is not None:
-            _lib.load().a2p_ctx_destroy(self._ctx)
+            (self._ctx_lib or _lib.load()).a2p_ctx_destroy(self._ctx)
             self._ctx = None
         self._cond_key = self._cond_refs = None
 
@@ -343,7 +350,7 @@ class FiLMTransformer(nn.Module):
         ts = times.to(device=x.device, dtype=torch.int64).contiguous()
         sc = None if scale is None else scale.to(device=x.device, dtype=torch.float32).contiguous()
         with _lib.on_device_of(x):
-            _lib.check(_lib.load().a2p_denoise_forward(self._ctx, _lib.ptr(x), _lib.ptr(ts), _lib.ptr(sc), pass_id, _lib.ptr(out),
+            _lib.check(self._lib().a2p_denoise_forward(self._ctx, _lib.ptr(x), _lib.ptr(ts), _lib.ptr(sc), pass_id, _lib.ptr(out),
                                                        _lib.current_stream(x.device)), "a2p_denoise_forward")
         return out
 
@@ -366,7 +373,7 @@ class FiLMTransformer(nn.Module):
         sc = y["scale"].to(device=x.device, dtype=torch.float32).contiguous()
         nz = None if noise is None else noise.to(device=x.device, dtype=torch.float32).contiguous()
         with _lib.on_device_of(x):
-            _lib.check(_lib.load().a2p_sample_step(self._ctx, sampler, _lib.ptr(x), _lib.ptr(t_idx), _lib.ptr(timestep_map),
+            _lib.check(self._lib().a2p_sample_step(self._ctx, sampler, _lib.ptr(x), _lib.ptr(t_idx), _lib.ptr(timestep_map),
                                                    _lib.ptr(tables), tables.shape[1], _lib.ptr(sc), _lib.ptr(nz), float(eta),
                                                    int(bool(clip_denoised)), _lib.ptr(x_next), _lib.ptr(x0),
                                                    _lib.current_stream(x.device)), "a2p_sample_step")

@@ -3,19 +3,20 @@
 
 Headline workload (BASELINE.json configs[1]): face diffusion, 1000-step DDPM (p_sample_loop with the
 restored noise), classifier-free guidance (2 denoiser passes per step), batch 8 samples per GPU,
-600-frame sequences, 1998 audio tokens (+2 time tokens), bf16 operands / fp32 accumulate.
+600-frame sequences, 1998 audio tokens (+2 time tokens), 16-bit operands (IEEE half by default, bf16 as a leg) / fp32 accumulate.
 Synthetic weights + inputs (no checkpoints/datasets offline).  One "step" = one p_sample:
 2 x FiLMTransformer forward over 8 samples + guidance + posterior update.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B] [--precision bf16|fp32]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B] [--precision fp16|bf16|fp32]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
 The ONE JSON line rank 0 prints carries, next to the contract fields:
   roofline      dominant kernel class, algorithmic FLOPs / measured launch time (HIP events on the launch stream) vs the bf16 peak
   cpu_baseline  the oracle (CPU port of the reference algorithm) timed on this box's host cores, bounded sample
-  parity        the benchmarked (bf16) mode AND the fp32 parity mode against that same oracle run at the bench shape
-                (face, T=600, S=2000), plus the drift of the full 1000-step chain bf16 vs GPU-fp32 under identical noise
-  legs          the other two north-star shapes on this GPU: face B=32 ("b32") and the body model B=16 with keyframes ("body")
+  parity        all three modes (fp16 = benchmarked, bf16, fp32 = parity mode) against that same oracle run at the bench shape
+                (face, T=600, S=2000), plus the drift of the full 1000-step chain of both 16-bit modes vs GPU-fp32 under identical noise
+  legs          the same workload with bf16 operands ("bf16"), and the other two north-star shapes on this GPU: face B=32
+                ("b32") and the body model B=16 with keyframes ("body")
 
 Multi-GPU = sample parallel: rank r denoises the global samples shard_bounds(N*B, N, r) with its own
 replica, no per-step communication (weak scaling); one all_gather (sample_parallel.gather_samples; RCCL over xGMI) of the
@@ -144,11 +145,11 @@ def kernel_breakdown(case, ksteps):
     roofline record of the dominant class."""
     import ctypes as C
     from audio2photoreal_amd import _lib
-    lib = _lib.load()
+    lib = case.model._lib()
     flops = algorithmic_flops(case.spec, case.T, case.S0 + 2, 2 * case.B)
     # bf16 mode runs the decoder-layer GEMMs inside the fused "chain" kernels (projections + FiLM + LayerNorm + FFN);
     # fp32 mode (and A2P_NO_CHAIN=1) runs them as separate GEMM launches
-    chained = case.precision == "bf16" and not os.environ.get("A2P_NO_CHAIN")
+    chained = case.precision != "fp32" and not os.environ.get("A2P_NO_CHAIN")
     flops["chain" if chained else "gemm"] = flops.pop("decoder_gemm") + (0.0 if chained else flops["io_gemm"])
     if chained:
         flops["gemm"] = flops["io_gemm"]
@@ -171,7 +172,7 @@ def kernel_breakdown(case, ksteps):
             ent["tflops"] = round(flops[name] / (per_step_ms * 1e-3) / 1e12, 2)
         kernels[name] = ent
     dom = max((k for k in kernels if k in flops), key=lambda k: kernels[k]["ms_per_step"])
-    peak = PEAK_BF16_TFLOPS if case.precision == "bf16" else PEAK_F32_TFLOPS
+    peak = PEAK_F32_TFLOPS if case.precision == "fp32" else PEAK_BF16_TFLOPS
     roofline = {"kernel": dom, "bound": "mfma", "achieved": kernels[dom]["tflops"], "peak": peak, "unit": "TFLOP/s",
                 "frac": round(kernels[dom]["tflops"] / peak, 4), "traffic": None,
                 "avg_launch_us": kernels[dom]["avg_launch_us"],
@@ -185,7 +186,7 @@ def leg_record(case, steps, warmup, repeats, ksteps=3):
     dts = time_case(case, steps, warmup, repeats, torch.cuda.synchronize)
     dt = statistics.median(dts)
     kernels, roofline = kernel_breakdown(case, ksteps)
-    peak = PEAK_BF16_TFLOPS if case.precision == "bf16" else PEAK_F32_TFLOPS
+    peak = PEAK_F32_TFLOPS if case.precision == "fp32" else PEAK_BF16_TFLOPS
     return {"workload": f"{case.fmt} B={case.B} x2 CFG, T={case.T}, {case.S0}+2 cond tokens, {case.sampler} step, {case.precision}",
             "value": round(steps / dt, 3), "unit": "steps/s", "ms_per_step": round(1e3 * dt / steps, 4),
             "sample_steps_per_sec": round(case.B * steps / dt, 2), "repeats_ms_per_step": [round(1e3 * t / steps, 4) for t in dts],
@@ -270,12 +271,12 @@ def cpu_and_parity(case, dev, want_parity=True, chain_steps=1000, chain_batch=2)
 
     parity = {"reference": "oracle/a2p_oracle.py (CPU fp32), pinned to reference-generated goldens by tests/test_oracle_golden.py",
               "shape": f"{case.fmt} B=1 T={T} S={S0 + 2}, p_sample at t={t_list}",
-              "short": {"fp32": gpu_short("fp32"), "bf16": gpu_short("bf16")}}
+              "short": {"fp32": gpu_short("fp32"), "bf16": gpu_short("bf16"), "fp16": gpu_short("fp16")}}
     if chain_steps:
         finals = {}
         Bc = chain_batch
         shape = (Bc, spec.nfeats, 1, T)
-        for precision in ("fp32", "bf16"):
+        for precision in ("fp32", "bf16", "fp16"):
             m, diff = create_model_and_diffusion(default_args(case.fmt, timestep_respacing=""), "test", precision=precision, max_batch=Bc)
             load_model(m, case.sd)
             cfg = ClassifierFreeSampleModel(m.to(dev).eval())
@@ -295,9 +296,10 @@ def cpu_and_parity(case, dev, want_parity=True, chain_steps=1000, chain_batch=2)
             torch.cuda.synchronize()
             finals[precision] = (out["sample"].clone(), time.perf_counter() - t0)
             m.release()
-        parity["chain"] = {"what": f"final sample of the {chain_steps}-step DDPM chain, B={Bc}, T={T}: bf16 mode vs GPU fp32 mode, identical noise",
-                           **{k: float(f"{v:.3e}") for k, v in rel_errors(finals["bf16"][0], finals["fp32"][0]).items()},
-                           "fp32_chain_s": round(finals["fp32"][1], 2), "bf16_chain_s": round(finals["bf16"][1], 2)}
+        parity["chain"] = {"what": f"final sample of the {chain_steps}-step DDPM chain, B={Bc}, T={T}: 16-bit modes vs GPU fp32 mode, identical noise",
+                           "bf16": {k: float(f"{v:.3e}") for k, v in rel_errors(finals["bf16"][0], finals["fp32"][0]).items()},
+                           "fp16": {k: float(f"{v:.3e}") for k, v in rel_errors(finals["fp16"][0], finals["fp32"][0]).items()},
+                           **{f"{k}_chain_s": round(v[1], 2) for k, v in finals.items()}}
     return cpu, parity
 
 
@@ -373,7 +375,10 @@ def main():
     ap.add_argument("--repeats", type=int, default=3, help="timed regions of exactly --steps steps each; the median is reported")
     ap.add_argument("--batch", type=int, default=8)
     ap.add_argument("--frames", type=int, default=600)
-    ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--precision", default="fp16", choices=["bf16", "fp16", "fp32"],
+                    help="fp16 (default): 16-bit throughput mode with IEEE-half operands -- same MFMA rate as bf16, 8x smaller operand rounding "
+                         "error (parity record below); bf16: the dtype BASELINE's configs name, reported as the `bf16` leg of a default run; "
+                         "fp32: the parity mode (exact fp32 MFMA)")
     ap.add_argument("--model", default="face", choices=["face", "pose"],
                     help="face = BASELINE configs[1] (the metric's config, default); pose = configs[2] shape (body model, keyframes, scale 2)")
     ap.add_argument("--pipeline", action="store_true",
@@ -454,7 +459,7 @@ def main():
         # HBM bytes per launch of the dominant class from the rocprofv3 PMC passes (FETCH_SIZE doubled per the gfx950 note of
         # MI355X_MICROARCH.md + WRITE_SIZE; scratch/run_pmc.sh writes the file) -- null when not collected for this workload
         tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-        if os.path.exists(tpath) and a.model == "face" and B == 8 and T == 600 and a.precision == "bf16":
+        if os.path.exists(tpath) and a.model == "face" and B == 8 and T == 600 and a.precision != "fp32":   # 16-bit modes: same bytes
             traffic = json.load(open(tpath)).get(roofline["kernel"])
             if traffic:
                 roofline["traffic"], roofline["traffic_detail"] = traffic["total_bytes"], traffic
@@ -467,17 +472,20 @@ def main():
             if parity and a.write_parity:
                 with open(a.write_parity, "w") as f:
                     json.dump(parity, f, indent=1)
-        if not a.no_legs and a.model == "face" and B == 8 and a.precision == "bf16":
+        if not a.no_legs and a.model == "face" and B == 8 and a.precision != "fp32":
             case.model.release()           # free the headline context before the larger ones
-            legs["b32"] = leg_record(Case("face", 32, T, "bf16", dev, list(range(32))), max(a.steps // 2, 5), 2, a.repeats)
+            if a.precision != "bf16":
+                legs["bf16"] = leg_record(Case("face", 8, T, "bf16", dev, list(range(8))), a.steps, a.warmup, a.repeats)
+                legs["bf16"]["note"] = "the headline workload with bfloat16 operands (the dtype BASELINE configs[1] names); parity: parity.*.bf16"
+            legs["b32"] = leg_record(Case("face", 32, T, a.precision, dev, list(range(32))), max(a.steps // 2, 5), 2, a.repeats)
             legs["b32"]["note"] = "north_star batch-32 roofline leg (face FiLM denoiser, p_sample step)"
-            body = Case("pose", 16, T, "bf16", dev, list(range(16)), respacing="ddim100", sampler="ddim")
+            body = Case("pose", 16, T, a.precision, dev, list(range(16)), respacing="ddim100", sampler="ddim")
             legs["body"] = leg_record(body, a.steps, a.warmup, a.repeats)
             legs["body"]["note"] = "BASELINE configs[2]: body diffusion, keyframe conditioning + CFG scale 2, batch 16, 600 frames, ddim100 step"
 
     if rank == 0:
         value = world * a.steps / dt
-        peak = PEAK_BF16_TFLOPS if a.precision == "bf16" else PEAK_F32_TFLOPS
+        peak = PEAK_F32_TFLOPS if a.precision == "fp32" else PEAK_BF16_TFLOPS
         spec, S0 = case.spec, case.S0
         line = {
             "metric": f"diffusion denoise steps/sec ({a.model}, {T}-frame seq, batch {B} per GPU, CFG)", "value": round(value, 4),

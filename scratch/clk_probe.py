@@ -15,7 +15,7 @@ for fmt, B in (("face", 8), ("face", 32)):
             case.run_steps(6)
         torch.cuda.synchronize()
         a = np.zeros(64 * 32, np.uint64)
-        _lib.check(_lib.load().a2p_debug_read(case.model._ctx, b"clk", a.ctypes.data_as(C.c_void_p), a.nbytes), "clk")
+        _lib.check(case.model._lib().a2p_debug_read(case.model._ctx, b"clk", a.ctypes.data_as(C.c_void_p), a.nbytes), "clk")
         a = a.reshape(64, 8, 4).astype(np.float64)
         cyc, rt = a[:17, :, 2] - a[:17, :, 0], (a[:17, :, 3] - a[:17, :, 1]) * 10.0   # ns
         ok = rt > 0

@@ -57,11 +57,11 @@ def y_for(spec, inp, dev, scale):
 
 
 # ----------------------------------------------------------------------------- kernels
-@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+@pytest.mark.parametrize("precision", ["fp32", "bf16", "fp16"])
 def test_gemm_kernel(dev, precision):
     spec, model = get_model("face", precision, dev)
     model._ensure_ctx(dev, 1)
-    lib = _lib.load()
+    lib = model._lib()
     g = torch.Generator().manual_seed(1)
     for (M, N, K) in [(300, 512, 512), (129, 104, 256), (64, 1024, 2038), (1000, 256, 104)]:
         A = torch.randn(M, K, generator=g)
@@ -73,15 +73,16 @@ def test_gemm_kernel(dev, precision):
         _lib.check(lib.a2p_gemm(model._ctx, _lib.ptr(Ad), _lib.ptr(Wd), _lib.ptr(bd), _lib.ptr(out), M, N, K,
                                 _lib.current_stream()), "a2p_gemm")
         err = rel_l2(out.cpu(), ref)
-        assert err < (2e-6 if precision == "fp32" else 1e-2), (M, N, K, err)
+        record(f"gemm/{precision}/{M}x{N}x{K}", rel_l2=err)
+        assert err < {"fp32": 2e-6, "bf16": 1e-2, "fp16": 1.5e-3}[precision], (M, N, K, err)
 
 
-@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+@pytest.mark.parametrize("precision", ["fp32", "bf16", "fp16"])
 @pytest.mark.parametrize("fmt", ["face", "pose"])
 def test_attention_kernel(dev, precision, fmt):
     spec, model = get_model(fmt, precision, dev)
     model._ensure_ctx(dev, 1)
-    lib = _lib.load()
+    lib = model._lib()
     d, H = spec.latent_dim, spec.num_heads
     g = torch.Generator().manual_seed(2)
     for (N, Tq, S) in [(2, 100, 77), (1, 240, 800), (3, 33, 20)]:
@@ -95,29 +96,31 @@ def test_attention_kernel(dev, precision, fmt):
         _lib.check(lib.a2p_attention(model._ctx, _lib.ptr(qd), _lib.ptr(kd), _lib.ptr(vd),
                                      _lib.ptr(out), N, Tq, S, _lib.current_stream()), "a2p_attention")
         err = rel_l2(out.cpu(), ref)
-        assert err < (5e-6 if precision == "fp32" else 2e-2), (N, Tq, S, err)
+        record(f"attn/{fmt}/{precision}/{N}x{Tq}x{S}", rel_l2=err)
+        assert err < {"fp32": 5e-6, "bf16": 2e-2, "fp16": 3e-3}[precision], (N, Tq, S, err)
 
 
-@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+@pytest.mark.parametrize("precision", ["fp32", "bf16", "fp16"])
 @pytest.mark.parametrize("fmt", ["face", "pose"])
 def test_decoder_layer_vs_reference_golden(dev, golden, precision, fmt):
     spec, model = get_model(fmt, precision, dev)
     model._ensure_ctx(dev, 2)
-    model._ensure_weights(_lib.load(), dev)
+    model._ensure_weights(model._lib(), dev)
     d = spec.latent_dim
     x = synthetic_tensor(SEED, "layer_x", (2, 48, d)).to(dev)
     mem = synthetic_tensor(SEED, "layer_mem", (2, 80, d)).to(dev)
     t = synthetic_tensor(SEED, "layer_t", (2, d)).to(dev)
     mem2 = synthetic_tensor(SEED, "layer_mem2", (2, 8, d)).to(dev) if spec.is_pose else None
-    _lib.check(_lib.load().a2p_decoder_layer_forward(model._ctx, 0, _lib.ptr(x), _lib.ptr(mem), _lib.ptr(t), _lib.ptr(mem2),
+    _lib.check(model._lib().a2p_decoder_layer_forward(model._ctx, 0, _lib.ptr(x), _lib.ptr(mem), _lib.ptr(t), _lib.ptr(mem2),
                                                      2, 48, 80, 8 if spec.is_pose else 0, _lib.current_stream()), "layer")
     err = rel_l2(x.cpu(), golden[f"{fmt}/layer0"])
     record(f"layer0/{fmt}/{precision}", rel_l2=err)
-    assert err < (1e-4 if precision == "fp32" else 2e-2)
+    # measured on MI355X (profiles/r02_parity_tests.json): fp32 4e-7, bf16 1.6e-3, fp16 2e-4
+    assert err < {"fp32": 1e-4, "bf16": 3.2e-3, "fp16": 6e-4}[precision]
 
 
 # ----------------------------------------------------------------------------- denoiser
-@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+@pytest.mark.parametrize("precision", ["fp32", "bf16", "fp16"])
 @pytest.mark.parametrize("fmt", ["face", "pose"])
 def test_forward_vs_reference_golden(dev, golden, precision, fmt):
     spec, model = get_model(fmt, precision, dev)
@@ -134,8 +137,10 @@ def test_forward_vs_reference_golden(dev, golden, precision, fmt):
     errs = (rel_l2(c.cpu(), golden[f"{fmt}/fwd_cond"]), rel_l2(u.cpu(), golden[f"{fmt}/fwd_uncond"]),
             rel_l2(g.cpu(), golden[f"{fmt}/fwd_cfg"]))
     record(f"fwd240/{fmt}/{precision}", cond=errs[0], uncond=errs[1], cfg=errs[2])
-    tol = 2e-4 if precision == "fp32" else 5e-2
-    assert all(e < tol for e in errs[:2]) and errs[2] < 5 * tol, errs
+    # measured (profiles/r02_parity_tests.json): fp32 ~1e-6; bf16 cond/uncond 3.4-5.1e-3, guided 4.4e-3 (face) / 8.5e-3 (pose);
+    # fp16 8x below bf16.  Gates = 2x the measured values (round 1 asserted 5e-2 / 0.25 here)
+    tol, tol_cfg = {"fp32": (2e-4, 2e-4), "bf16": (1.1e-2, 1.8e-2), "fp16": (1.5e-3, 2.5e-3)}[precision]
+    assert all(e < tol for e in errs[:2]) and errs[2] < tol_cfg, errs
     if spec.is_pose:   # the reference zeroes masked keyframes in y, in place (model/diffusion.py:320)
         assert float(y["keyframes"][1, 3:].abs().max()) == 0.0
 
@@ -244,7 +249,7 @@ def test_bf16_mode_error_reported(dev, golden):
                                                             clip_denoised=False, model_kwargs={"y": y}, noise=inp["x_T"].to(dev))
     e = rel_l2(res.cpu(), golden["face/ddim10"])
     record("ddim10_240/face/bf16", rel_l2=e)
-    assert e < 0.1
+    assert e < 5e-2      # measured 2.5e-2 (round 1 asserted 0.1)
 
 
 def test_properties_full_size(dev):
@@ -292,7 +297,8 @@ def test_chain_kernels_match_the_per_op_kernels_bf16(dev, golden, fmt, mt, monke
     ref = golden[f"{fmt}/fwd_cfg"]
     e_pair, e_gold, e_old = rel_l2(chained, per_op), rel_l2(chained, ref), rel_l2(per_op, ref)
     record(f"chain_vs_perop/{fmt}/MT{mt}", pair=e_pair, chain_vs_golden=e_gold, perop_vs_golden=e_old)
-    assert e_pair < 3e-2 and e_gold < 0.25 and e_gold < 2.0 * e_old + 1e-3
+    # measured: chain vs per-op 3.0e-3 (face) / 8.4e-3 (pose), both 4.4e-3 / 8.5e-3 from the fp32 reference (round 1: 3e-2 / 0.25)
+    assert e_pair < (6.5e-3 if fmt == "face" else 1.7e-2) and e_gold < (9e-3 if fmt == "face" else 1.7e-2) and e_gold < 1.2 * e_old + 1e-3
 
 
 @pytest.mark.parametrize("fmt,B,frames", [("face", 4, 150), ("pose", 5, 210)])
@@ -317,7 +323,7 @@ def test_chain_kernels_with_frame_counts_that_are_not_a_multiple_of_4(dev, fmt, 
                           inp.get("keyframes", [None])[:2] if spec.is_pose else None, inp["mask"][:2] if spec.is_pose else None)
     e_pair, e_ref = rel_l2(chained, per_op), rel_l2(chained[:2], ref)
     record(f"chain_ragged/{fmt}/T{frames}", pair=e_pair, chain_vs_oracle=e_ref, perop_vs_oracle=rel_l2(per_op[:2], ref))
-    assert e_pair < 3e-2 and e_ref < 0.25
+    assert e_pair < (6.5e-3 if fmt == "face" else 1.8e-2) and e_ref < (9e-3 if fmt == "face" else 1.5e-2)   # measured 3.1e-3 / 8.8e-3, 4.3e-3 / 7.5e-3
 
 
 @pytest.mark.parametrize("fmt,B,frames", [("face", 4, 240)])
