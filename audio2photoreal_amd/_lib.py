@@ -36,6 +36,8 @@ EXPORTS = (
     "a2p_kernel_timing", "a2p_kernel_time_ms", "a2p_debug_read",
     "a2p_guide_create", "a2p_guide_destroy", "a2p_guide_set_weight", "a2p_guide_finalize", "a2p_guide_prepare",
     "a2p_guide_forward", "a2p_guide_generate", "a2p_guide_debug_read", "a2p_vq_decode",
+    "a2p_frontend_create", "a2p_frontend_destroy", "a2p_frontend_set_weight", "a2p_frontend_finalize",
+    "a2p_frontend_encode_audio", "a2p_frontend_encode_lip",
 )
 
 
@@ -49,6 +51,12 @@ class A2PGuideConfig(C.Structure):
     _fields_ = [(n, C.c_int32) for n in (
         "tokens", "dim", "num_layers", "num_heads", "ff_size", "cond_feature_dim", "emb_len", "num_audio_layers",
         "max_batch", "max_positions")] + [("reserved", C.c_int32 * 2)]
+
+
+class A2PFrontendConfig(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in (
+        "conv_dim", "resample", "lip", "d_model", "num_heads", "ff_size", "enc_layers", "dec_layers", "lip_out", "lip_pad",
+        "chunk_frames", "samples_per_frame", "max_batch", "max_frames")] + [("reserved", C.c_int32 * 2)]
 
 
 class A2PError(RuntimeError):
@@ -104,6 +112,12 @@ def load(half: bool = False) -> C.CDLL:
         "a2p_guide_generate": [vp, i32, i32, f32, vp, vp, vp, vp],
         "a2p_guide_debug_read": [vp, C.c_char_p, vp, i64],
         "a2p_vq_decode": [vp, i32, i32, i32, i32, i32, i32, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), vp, vp],
+        "a2p_frontend_create": [C.POINTER(A2PFrontendConfig), C.POINTER(vp)],
+        "a2p_frontend_destroy": [vp],
+        "a2p_frontend_set_weight": [vp, C.c_char_p, vp, i64, vp],
+        "a2p_frontend_finalize": [vp, vp],
+        "a2p_frontend_encode_audio": [vp, vp, i32, i64, vp, i32, vp],
+        "a2p_frontend_encode_lip": [vp, vp, i32, i64, vp, i32, i32, vp, vp],
     }
     for name, args in sig.items():
         fn = getattr(lib, name)

@@ -80,7 +80,7 @@ __device__ __forceinline__ float act_mish(float x) { return x * tanhf(act_softpl
 __device__ __forceinline__ float act_silu(float x) { return x / (1.0f + expf(-x)); }
 __device__ __forceinline__ float act_lrelu02(float x) { return x > 0.0f ? x : 0.2f * x; }
 
-enum { ACT_NONE = 0, ACT_GELU = 1, ACT_MISH = 2, ACT_SILU = 3, ACT_LRELU = 4 };
+enum { ACT_NONE = 0, ACT_GELU = 1, ACT_MISH = 2, ACT_SILU = 3, ACT_LRELU = 4, ACT_RELU = 5 };
 
 __device__ __forceinline__ float apply_act(float x, int act) {
   switch (act) {
@@ -88,6 +88,7 @@ __device__ __forceinline__ float apply_act(float x, int act) {
     case ACT_MISH: return act_mish(x);
     case ACT_SILU: return act_silu(x);
     case ACT_LRELU: return act_lrelu02(x);
+    case ACT_RELU: return x > 0.0f ? x : 0.0f;
     default: return x;
   }
 }

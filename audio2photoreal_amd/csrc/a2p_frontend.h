@@ -1,0 +1,440 @@
+// Fourth part of a2p_lib.hip (same translation unit): the audio front end (include/a2p_hip.h "front end" section;
+// SURVEY.md section 8 row f1).  Reference: FiLMTransformer.encode_audio / encode_lip (model/diffusion.py:285-313),
+// Audio2LipRegressionTransformer (:37-79), Wav2VecEncoder (model/modules/audio_encoder.py:24-46), RegressionTransformer
+// (model/modules/transformer_modules.py:560-627), setup_lip_regressor (model/utils.py:18-26).
+//
+// The reference runs all of this in EVERY denoising step and in both guidance passes; here it runs once per clip
+// (FiLMTransformer.prepare).  fp32 throughout (exact-fp32 MFMA GEMMs, the attention kernel at head_dim 128).
+//
+// What is pinned and what is not: the lip regressor's transformer, the 120-frame chunking, the nearest-exact interpolation
+// and the concatenation are all in /root/reference and are pinned by reference-generated goldens (tests/golden/
+// golden_frontend_v1.npz).  The two third-party pieces -- fairseq's (vq-)wav2vec feature extractor and torchaudio's
+// Resample -- are absent offline: the conv stack follows the published geometry (8 x Conv1d(512, k, stride, bias=False) +
+// ReLU, (k, s) = (10,5) (8,4) (4,2) (4,2) (4,2) (1,1) (1,1) (1,1)) and the resampler is either torchaudio's documented
+// windowed-sinc kernel (sinc_interp_hann, lowpass_filter_width 6, rolloff 0.99: "parity unpinned") or the plain 3:1
+// decimation the golden generator's stub uses.
+#pragma once
+
+struct a2p_frontend_ctx {
+  a2p_frontend_config cfg;
+  a2p_ctx core;  // fp32 host state for the shared launchers (GEMM / attention / LayerNorm dispatch); owns no buffers
+  std::map<std::string, int64_t> expect;
+  std::map<std::string, Buf> w;
+  bool finalized = false;
+  std::vector<Buf> conv_a, conv_l;  // repacked conv weights [Co][k*Ci] of the audio / lip feature extractors (layer 0: [Co][32])
+  Buf fir;                          // 41-tap 3:1 resampling kernel
+  Buf po_w, po_b;                   // project_output padded to a multiple of 4 outputs (the GEMM epilogue stores float4)
+  int lo_pad = 0;
+  Buf wav, pcm, act[2];             // per-sequence scratch: de-interleaved channel, 16 kHz samples, conv ping-pong
+  Buf cond, xs, xn, qk, vt, ao, hff, lipf;  // lip regressor workspaces
+  size_t cap_samples = 0;
+  int cap_seq = 0;
+};
+
+static const float* FW(a2p_frontend_ctx* f, const std::string& n) { return f->w.at(n).f(); }
+
+// ---------------------------------------------------------------------------------------------------------------
+// kernels
+// ---------------------------------------------------------------------------------------------------------------
+// channel `ch` of interleaved stereo [L][2] -> contiguous [L]
+__global__ void fe_deinterleave_kernel(const float* __restrict__ a, float* __restrict__ o, int64_t L, int ch) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < L) o[i] = a[i * 2 + ch];
+}
+
+// 48 kHz -> 16 kHz.  mode 0: x[::3] (the golden generator's stub); mode 1: torchaudio.transforms.Resample(48000, 16000) =
+// conv1d(pad(x, (19, 22)), kernel[41], stride 3)[: ceil(L / 3)].  Output is written at out[lead + n] (the lip path prepends
+// 320 zeros, audio_encoder.py:40-42).
+__global__ void fe_resample_kernel(const float* __restrict__ x, const float* __restrict__ fir, float* __restrict__ out, int64_t L,
+                                   int64_t n_out, int mode) {
+  const int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (n >= n_out) return;
+  if (mode == 0) {
+    out[n] = x[n * 3];
+    return;
+  }
+  float acc = 0.f;
+#pragma unroll 1
+  for (int j = 0; j < 41; ++j) {
+    const int64_t i = n * 3 + j - 19;
+    if (i >= 0 && i < L) acc = fmaf(fir[j], x[i], acc);
+  }
+  out[n] = acc;
+}
+
+// first conv layer: Conv1d(1, Co, k, stride) + ReLU on a mono signal -> channel-last rows [T0][Co]
+__global__ __launch_bounds__(256) void fe_conv0_kernel(const float* __restrict__ x, const float* __restrict__ w, float* __restrict__ out,
+                                                       int64_t T0, int Co, int k, int stride) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= T0 * Co) return;
+  const int64_t t = i / Co;
+  const int c = (int)(i - t * Co);
+  float acc = 0.f;
+  for (int j = 0; j < k; ++j) acc = fmaf(w[c * 32 + j], x[t * stride + j], acc);
+  out[i] = acc > 0.f ? acc : 0.f;
+}
+
+// Conv1d weight [Co][Ci][k] -> GEMM operand [Co][k*Ci] (tap-major: a channel-last window of k rows is one contiguous A row);
+// layer 0 (Ci == 1): [Co][32], taps beyond k zero
+__global__ void fe_repack_kernel(const float* __restrict__ w, float* __restrict__ o, int Co, int Ci, int k, int ldo) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (int64_t)Co * ldo) return;
+  const int co = (int)(i / ldo), r = (int)(i % ldo);
+  const int tap = r / Ci, ci = r % Ci;
+  o[i] = tap < k ? w[((int64_t)co * Ci + ci) * k + tap] : 0.f;
+}
+
+// rows [n][t][d] += pe[t][d]   (PositionalEncoding.forward, transformer_modules.py:295-302); zero_first: rows = pe (x == 0)
+__global__ void fe_add_pe_kernel(float* __restrict__ x, const float* __restrict__ pe, int64_t total, int T, int d, int zero_first) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const int c = (int)(i % d);
+  const int t = (int)((i / d) % T);
+  x[i] = (zero_first ? 0.f : x[i]) + pe[(int64_t)t * d + c];
+}
+
+// copy the conv-stack output of one sequence (channel-last [S][C]) into columns [col0, col0+C) of out[S][ld]
+__global__ void fe_scatter_cols_kernel(const float* __restrict__ src, float* __restrict__ out, int64_t S, int C, int64_t ld, int col0) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= S * C) return;
+  const int64_t s = i / C;
+  out[s * ld + col0 + (i - s * C)] = src[i];
+}
+
+// encode_lip's tail (model/diffusion.py:308-312): out[b][s][:Ca] = cond_in[b][s][:], out[b][s][Ca:] = lip[b][src(s)][:]
+// with F.interpolate(mode="nearest-exact"): src(s) = min(floor((s + 0.5) * T / S), T - 1)
+__global__ void fe_concat_kernel(const float* __restrict__ cond_in, const float* __restrict__ lip, float* __restrict__ out, int B, int S,
+                                 int T, int Ca, int Cl, int ld_lip) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t total = (int64_t)B * S * (Ca + Cl);
+  if (i >= total) return;
+  const int c = (int)(i % (Ca + Cl));
+  const int64_t bs = i / (Ca + Cl);
+  const int s = (int)(bs % S);
+  const int b = (int)(bs / S);
+  if (c < Ca) {
+    out[i] = cond_in[bs * Ca + c];
+  } else {
+    int t = (int)floorf(((float)s + 0.5f) * ((float)T / (float)S));
+    t = t < T - 1 ? t : T - 1;
+    out[i] = lip[((int64_t)b * T + t) * ld_lip + (c - Ca)];
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// context
+// ---------------------------------------------------------------------------------------------------------------
+static const int kFeK[8] = {10, 8, 4, 4, 4, 1, 1, 1}, kFeS[8] = {5, 4, 2, 2, 2, 1, 1, 1};
+
+static int64_t fe_conv_len(int64_t n, int layers = 8) {
+  for (int i = 0; i < layers; ++i) n = n < kFeK[i] ? 0 : (n - kFeK[i]) / kFeS[i] + 1;
+  return n;
+}
+
+extern "C" int a2p_frontend_create(const a2p_frontend_config* cfg, a2p_frontend_ctx** out) {
+  ARG(cfg && out, "null argument");
+  ARG(cfg->conv_dim == 512 && cfg->d_model == 512 && cfg->num_heads == 4 && cfg->ff_size % 64 == 0, "front end: conv_dim / d_model 512, 4 heads");
+  ARG(cfg->resample == 0 || cfg->resample == 1, "resample must be 0 (decimate) or 1 (windowed sinc)");
+  ARG(cfg->max_batch >= 1 && cfg->max_frames >= 1 && cfg->enc_layers >= 0 && cfg->dec_layers >= 0, "bad capacity");
+  a2p_frontend_ctx* f = new a2p_frontend_ctx();
+  f->cfg = *cfg;
+  f->core.bf16 = false; f->core.esz = 4; f->core.d = cfg->d_model; f->core.H = cfg->num_heads; f->core.DH = cfg->d_model / cfg->num_heads;
+  f->core.use_arena = false;
+  auto& e = f->expect;
+  const int64_t C = cfg->conv_dim, d = cfg->d_model, ff = cfg->ff_size;
+  for (int i = 0; i < 8; ++i)
+    e["audio_model.feature_extractor.conv_layers." + std::to_string(i) + ".0.weight"] = C * (i ? C : 1) * kFeK[i];
+  if (cfg->lip) {
+    const std::string L = "lip_model.";
+    for (int i = 0; i < 8; ++i)
+      e[L + "audio_encoder.wav2vec_model.feature_extractor.conv_layers." + std::to_string(i) + ".0.weight"] = C * (i ? C : 1) * kFeK[i];
+    e[L + "regression_model.cond_positional_encoding.pe"] = 1024 * d;
+    e[L + "regression_model.target_positional_encoding.pe"] = 1024 * d;
+    auto attn = [&](const std::string& p) {
+      e[p + ".in_proj_weight"] = 3 * d * d; e[p + ".in_proj_bias"] = 3 * d;
+      e[p + ".out_proj.weight"] = d * d; e[p + ".out_proj.bias"] = d;
+    };
+    auto norm = [&](const std::string& p) { e[p + ".weight"] = d; e[p + ".bias"] = d; };
+    auto ffn = [&](const std::string& p) {
+      e[p + ".ff.0.weight"] = ff * d; e[p + ".ff.0.bias"] = ff; e[p + ".ff.3.weight"] = d * ff; e[p + ".ff.3.bias"] = d;
+    };
+    for (int i = 0; i < cfg->enc_layers; ++i) {
+      const std::string p = L + "regression_model.transformer_encoder." + std::to_string(i) + ".";
+      norm(p + "norm1"); attn(p + "self_attn.self_attn"); norm(p + "norm2"); ffn(p + "feedforward");
+    }
+    for (int i = 0; i < cfg->dec_layers; ++i) {
+      const std::string p = L + "regression_model.transformer_decoder." + std::to_string(i) + ".";
+      norm(p + "norm1"); attn(p + "self_attn.self_attn"); norm(p + "norm2"); attn(p + "cross_attn.cross_attn"); norm(p + "norm3");
+      ffn(p + "feedforward");
+    }
+    e[L + "project_output.weight"] = (int64_t)cfg->lip_out * d; e[L + "project_output.bias"] = cfg->lip_out;
+  }
+  *out = f;
+  return 0;
+}
+
+extern "C" int a2p_frontend_destroy(a2p_frontend_ctx* f) {
+  if (!f) return 0;
+  (void)hipDeviceSynchronize();
+  for (auto& kv : f->w) buf_free(kv.second);
+  for (auto& b : f->conv_a) buf_free(b);
+  for (auto& b : f->conv_l) buf_free(b);
+  Buf* all[] = {&f->fir, &f->po_w, &f->po_b, &f->wav, &f->pcm, &f->act[0], &f->act[1], &f->cond, &f->xs, &f->xn, &f->qk, &f->vt, &f->ao, &f->hff, &f->lipf};
+  for (Buf* b : all) buf_free(*b);
+  delete f;
+  return 0;
+}
+
+extern "C" int a2p_frontend_set_weight(a2p_frontend_ctx* f, const char* name, const float* dev_ptr, int64_t numel, void* stream) {
+  ARG(f && name && dev_ptr, "null argument");
+  const std::string n(name);
+  auto it = f->expect.find(n);
+  if (it == f->expect.end()) return 1;  // other audio_model.* / lip_model.* tensors of a checkpoint (aggregator, quantiser): not on this path
+  if (it->second != numel) {
+    set_err("front-end parameter '%s': expected %lld elements, got %lld", name, (long long)it->second, (long long)numel);
+    return A2P_ERR_NOWEIGHT;
+  }
+  Buf& b = f->w[n];
+  if (!b.p) CHK(buf_alloc_tmp(b, (size_t)numel * 4));
+  HIPCHK(hipMemcpyAsync(b.p, dev_ptr, (size_t)numel * 4, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+  f->finalized = false;
+  return 0;
+}
+
+extern "C" int a2p_frontend_finalize(a2p_frontend_ctx* f, void* stream) {
+  ARG(f, "null argument");
+  hipStream_t s = (hipStream_t)stream;
+  for (auto& kv : f->expect)
+    if (!f->w.count(kv.first)) {
+      set_err("front-end parameter '%s' was never set", kv.first.c_str());
+      return A2P_ERR_NOWEIGHT;
+    }
+  const int C = f->cfg.conv_dim;
+  auto repack = [&](std::vector<Buf>& dst, const std::string& prefix) -> int {
+    dst.resize(8);
+    for (int i = 0; i < 8; ++i) {
+      const int Ci = i ? C : 1, ld = i ? kFeK[i] * C : 32;
+      CHK(buf_alloc_tmp(dst[i], (size_t)C * ld * 4));
+      const int64_t n = (int64_t)C * ld;
+      fe_repack_kernel<<<(int)((n + 255) / 256), 256, 0, s>>>(FW(f, prefix + std::to_string(i) + ".0.weight"), dst[i].f(), C, Ci, kFeK[i], ld);
+    }
+    return 0;
+  };
+  CHK(repack(f->conv_a, "audio_model.feature_extractor.conv_layers."));
+  if (f->cfg.lip) CHK(repack(f->conv_l, "lip_model.audio_encoder.wav2vec_model.feature_extractor.conv_layers."));
+  {  // torchaudio _get_sinc_resample_kernel(48000, 16000): orig 3, new 1, base 0.99, width ceil(6 * 3 / 0.99) = 19, 41 taps (float64)
+    const double base = 0.99, lpw = 6.0;
+    float h[41];
+    for (int j = 0; j < 41; ++j) {
+      double t = ((double)(j - 19) / 3.0) * base;
+      t = t < -lpw ? -lpw : (t > lpw ? lpw : t);
+      const double c = cos(t * M_PI / lpw / 2.0), win = c * c, tp = t * M_PI;
+      h[j] = (float)((tp == 0.0 ? 1.0 : sin(tp) / tp) * win * (base / 3.0));
+    }
+    CHK(buf_alloc_tmp(f->fir, sizeof(h)));
+    HIPCHK(hipMemcpyAsync(f->fir.p, h, sizeof(h), hipMemcpyHostToDevice, s));
+  }
+  if (f->cfg.lip) {
+    const int d = f->cfg.d_model, Lo = f->cfg.lip_out;
+    f->lo_pad = rup(Lo, 4);
+    CHK(buf_alloc_tmp(f->po_w, (size_t)f->lo_pad * d * 4)); CHK(buf_alloc_tmp(f->po_b, (size_t)f->lo_pad * 4));   // zero-filled
+    HIPCHK(hipMemcpyAsync(f->po_w.p, FW(f, "lip_model.project_output.weight"), (size_t)Lo * d * 4, hipMemcpyDeviceToDevice, s));
+    HIPCHK(hipMemcpyAsync(f->po_b.p, FW(f, "lip_model.project_output.bias"), (size_t)Lo * 4, hipMemcpyDeviceToDevice, s));
+  }
+  HIPCHK(hipStreamSynchronize(s));
+  f->finalized = true;
+  return 0;
+}
+
+// scratch for sequences of up to `samples48` input samples
+static int fe_reserve(a2p_frontend_ctx* f, size_t samples48) {
+  if (samples48 <= f->cap_samples) return 0;
+  const size_t n16 = samples48 / 3 + 512, t0 = n16 / 5 + 8, t1 = t0 / 4 + 8;
+  CHK(buf_alloc_tmp(f->wav, (samples48 + 64) * 4));
+  CHK(buf_alloc_tmp(f->pcm, (n16 + 64) * 4));
+  CHK(buf_alloc_tmp(f->act[0], t0 * f->cfg.conv_dim * 4));   // layer-0 output (the largest), later even layers
+  CHK(buf_alloc_tmp(f->act[1], t1 * f->cfg.conv_dim * 4));
+  f->cap_samples = samples48;
+  return 0;
+}
+
+// one mono 48 kHz sequence -> conv features, channel-last [S][C] in the returned buffer.  `lead` zeros are prepended at 16 kHz.
+static int fe_features(a2p_frontend_ctx* f, const float* wav48, int64_t L, int lead, const std::vector<Buf>& cw, const float** out,
+                       int64_t* S_out, hipStream_t s) {
+  const int C = f->cfg.conv_dim;
+  const int64_t n16 = f->cfg.resample == 0 ? (L + 2) / 3 : (L + 2) / 3;   // x[::3] and ceil(L / 3) have the same length
+  if (lead) HIPCHK(hipMemsetAsync(f->pcm.p, 0, (size_t)lead * 4, s));
+  fe_resample_kernel<<<(int)((n16 + 255) / 256), 256, 0, s>>>(wav48, f->fir.f(), f->pcm.f() + lead, L, n16, f->cfg.resample);
+  int64_t n = n16 + lead;
+  const int64_t T0 = (n - kFeK[0]) / kFeS[0] + 1;
+  ARG(T0 >= 1, "sequence of %lld samples is shorter than the first conv kernel", (long long)L);
+  fe_conv0_kernel<<<(int)((T0 * C + 255) / 256), 256, 0, s>>>(f->pcm.f(), cw[0].f(), f->act[0].f(), T0, C, kFeK[0], kFeS[0]);
+  n = T0;
+  int cur = 0;
+  for (int i = 1; i < 8; ++i) {
+    const int64_t To = (n - kFeK[i]) / kFeS[i] + 1;
+    ARG(To >= 1, "sequence too short for conv layer %d", i);
+    GemmP p = gemm_base(f->act[cur].p, (int64_t)kFeS[i] * C, cw[i].p, (int64_t)kFeK[i] * C, nullptr, f->act[cur ^ 1].p, C, (int)To, C, kFeK[i] * C);
+    p.act = ACT_RELU;
+    CHK(launch_gemm(&f->core, p, s));
+    n = To;
+    cur ^= 1;
+  }
+  *out = f->act[cur].f();
+  *S_out = n;
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+// FiLMTransformer.encode_audio (model/diffusion.py:285-293): both stereo channels through the vq-wav2vec feature extractor,
+// concatenated channel-wise -> [B, S, 2 * conv_dim]
+extern "C" int a2p_frontend_encode_audio(a2p_frontend_ctx* f, const float* audio, int32_t batch, int64_t samples, float* out,
+                                         int32_t n_tokens, void* stream) {
+  ARG(f && audio && out, "null argument");
+  ARG(f->finalized, "a2p_frontend_finalize has not been called");
+  ARG(batch >= 1 && samples >= 1, "bad shape");
+  hipStream_t s = (hipStream_t)stream;
+  const int C = f->cfg.conv_dim;
+  CHK(fe_reserve(f, (size_t)samples));
+  for (int b = 0; b < batch; ++b)
+    for (int ch = 0; ch < 2; ++ch) {
+      fe_deinterleave_kernel<<<(int)((samples + 255) / 256), 256, 0, s>>>(audio + (size_t)b * samples * 2, f->wav.f(), samples, ch);
+      const float* feat = nullptr;
+      int64_t S = 0;
+      CHK(fe_features(f, f->wav.f(), samples, 0, f->conv_a, &feat, &S, s));
+      ARG(S == n_tokens, "%lld samples give %lld audio tokens, the caller expects %d", (long long)samples, (long long)S, n_tokens);
+      fe_scatter_cols_kernel<<<(int)((S * C + 255) / 256), 256, 0, s>>>(feat, out + (size_t)b * S * 2 * C, S, C, 2 * C, ch * C);
+    }
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+// pre-norm attention block of the lip regressor on f->xs ([N*Tq][d]): x += out_proj(MHA(LN(x), mem, mem)) (transformer_modules.py:
+// 449-472 / 475-512); mem == nullptr: self attention on LN(x)
+static int fe_attn_block(a2p_frontend_ctx* f, const std::string& np, const std::string& ap, int N, int Tq, const float* mem, int S, hipStream_t s) {
+  a2p_ctx* c = &f->core;
+  const int d = f->cfg.d_model, M = N * Tq, Sk = mem ? S : Tq, Sld = rup(Sk, 64);
+  CHK(launch_ln_rope(c, false, f->xs.f(), d, FW(f, np + ".weight"), FW(f, np + ".bias"), f->xn.p, nullptr, d, M, Tq, 0, s));
+  const float* inw = FW(f, ap + ".in_proj_weight");
+  const float* inb = FW(f, ap + ".in_proj_bias");
+  const float* kv_src = mem ? mem : f->xn.f();
+  GemmP pq = gemm_base(f->xn.p, d, inw, d, inb, f->qk.p, d, M, d, d);
+  CHK(launch_gemm(c, pq, s));
+  float* kbuf = f->qk.f() + (size_t)M * d;  // K rows behind the Q rows: [N][Sld][d] (the attention kernel reads whole 64-key tiles)
+  GemmP pk = gemm_base(kv_src, d, inw + (size_t)d * d, d, inb + d, kbuf, d, N * Sk, d, d);
+  pk.rows_per_seq = Sk;
+  pk.out_seq_pad = Sld - Sk;
+  CHK(launch_gemm(c, pk, s));
+  GemmP pv = gemm_base(kv_src, d, inw + (size_t)2 * d * d, d, inb + 2 * d, f->vt.p, Sld, N * Sk, d, d);
+  pv.epi = EPI_STORE_T;
+  pv.rows_per_seq = Sk;
+  pv.t_seq_stride = (int64_t)d * Sld;
+  CHK(launch_gemm(c, pv, s));
+  AttnP a;
+  memset(&a, 0, sizeof(a));
+  a.Q = f->qk.p; a.q_seq_stride = (int64_t)Tq * d; a.ldq = d;
+  a.K = kbuf; a.k_slot_stride = (int64_t)Sld * d; a.ldk = d;
+  a.VT = f->vt.p; a.vt_slot_stride = (int64_t)d * Sld; a.ldvt = Sld;
+  a.O = f->ao.p; a.o_seq_stride = (int64_t)Tq * d; a.ldo = d;
+  a.tail_mod = 1; a.Tq = Tq; a.S_main = Sk; a.S_tail = 0;
+  a.scale_log2e = 1.4426950408889634f / sqrtf((float)c->DH);
+  CHK(launch_attn(c, a, N, A2P_KERNEL_ATTN_SELF, s));
+  GemmP po = gemm_base(f->ao.p, d, FW(f, ap + ".out_proj.weight"), d, FW(f, ap + ".out_proj.bias"), nullptr, 0, M, d, d);
+  po.epi = EPI_FILM_RES;
+  po.resid = f->xs.f();
+  po.ldx = d;
+  po.rows_per_seq = Tq;
+  return launch_gemm(c, po, s);
+}
+
+// x += W2 relu(W1 LN(x) + b1) + b2   (FeedforwardBlock, transformer_modules.py:351-368)
+static int fe_ffn_block(a2p_frontend_ctx* f, const std::string& np, const std::string& fp, int M, hipStream_t s) {
+  a2p_ctx* c = &f->core;
+  const int d = f->cfg.d_model, ff = f->cfg.ff_size;
+  CHK(launch_ln_rope(c, false, f->xs.f(), d, FW(f, np + ".weight"), FW(f, np + ".bias"), f->xn.p, nullptr, d, M, M, 0, s));
+  GemmP p1 = gemm_base(f->xn.p, d, FW(f, fp + ".ff.0.weight"), d, FW(f, fp + ".ff.0.bias"), f->hff.p, ff, M, ff, d);
+  p1.act = ACT_RELU;
+  CHK(launch_gemm(c, p1, s));
+  GemmP p2 = gemm_base(f->hff.p, ff, FW(f, fp + ".ff.3.weight"), ff, FW(f, fp + ".ff.3.bias"), nullptr, 0, M, d, ff);
+  p2.epi = EPI_FILM_RES;
+  p2.resid = f->xs.f();
+  p2.ldx = d;
+  p2.rows_per_seq = M;
+  return launch_gemm(c, p2, s);
+}
+
+// Audio2LipRegressionTransformer.forward for `N` chunks of `Tc` frames each (model/diffusion.py:63-79): chunk audio [N][Tc*1600]
+// mono 48 kHz, gathered from channel 0 of `audio`; result rows go to lip[b][t0 + t][lip_out]
+static int fe_lip_chunks(a2p_frontend_ctx* f, const float* audio, int64_t samples, int B, int T, int t0, int Tc, hipStream_t s) {
+  a2p_ctx* c = &f->core;
+  const int d = f->cfg.d_model, C = f->cfg.conv_dim, spf = f->cfg.samples_per_frame, Lo = f->cfg.lip_out;
+  const std::string R = "lip_model.regression_model.";
+  const int64_t Lc = (int64_t)Tc * spf;
+  const int64_t Sc = fe_conv_len((Lc + 2) / 3 + f->cfg.lip_pad);
+  ARG(Sc >= 1 && Sc <= 1024 && Tc <= 1024, "lip chunk of %d frames gives %lld wav2vec tokens (positional table holds 1024)", Tc, (long long)Sc);
+  const int N = B;
+  // Wav2VecEncoder (audio_encoder.py:34-46): resample, 320 zeros on the left, feature extractor; the aggregator is the identity
+  // in the stub geometry (the real wav2vec-large aggregator is absent offline)
+  for (int b = 0; b < B; ++b) {
+    fe_deinterleave_kernel<<<(int)((Lc + 255) / 256), 256, 0, s>>>(audio + ((size_t)b * samples + (size_t)t0 * spf) * 2, f->wav.f(), Lc, 0);
+    const float* feat = nullptr;
+    int64_t S = 0;
+    CHK(fe_features(f, f->wav.f(), Lc, f->cfg.lip_pad, f->conv_l, &feat, &S, s));
+    ARG(S == Sc, "internal: token count %lld != %lld", (long long)S, (long long)Sc);
+    HIPCHK(hipMemcpyAsync(f->cond.f() + (size_t)b * Sc * C, feat, (size_t)Sc * C * 4, hipMemcpyDeviceToDevice, s));
+  }
+  const int64_t nc = (int64_t)N * Sc * d, nx = (int64_t)N * Tc * d;
+  // RegressionTransformer.forward (transformer_modules.py:594-627): x = 0 + pe, cond += pe
+  fe_add_pe_kernel<<<(int)((nc + 255) / 256), 256, 0, s>>>(f->cond.f(), FW(f, R + "cond_positional_encoding.pe"), nc, (int)Sc, d, 0);
+  // encoder over the audio tokens: run it on f->xs, then park the result in f->cond
+  Buf xs_keep = f->xs;
+  f->xs = f->cond;
+  for (int i = 0; i < f->cfg.enc_layers; ++i) {
+    const std::string p = R + "transformer_encoder." + std::to_string(i) + ".";
+    CHK(fe_attn_block(f, p + "norm1", p + "self_attn.self_attn", N, (int)Sc, nullptr, 0, s));
+    CHK(fe_ffn_block(f, p + "norm2", p + "feedforward", N * (int)Sc, s));
+  }
+  f->xs = xs_keep;
+  fe_add_pe_kernel<<<(int)((nx + 255) / 256), 256, 0, s>>>(f->xs.f(), FW(f, R + "target_positional_encoding.pe"), nx, Tc, d, 1);
+  for (int i = 0; i < f->cfg.dec_layers; ++i) {
+    const std::string p = R + "transformer_decoder." + std::to_string(i) + ".";
+    CHK(fe_attn_block(f, p + "norm1", p + "self_attn.self_attn", N, Tc, nullptr, 0, s));
+    CHK(fe_attn_block(f, p + "norm2", p + "cross_attn.cross_attn", N, Tc, f->cond.f(), (int)Sc, s));
+    CHK(fe_ffn_block(f, p + "norm3", p + "feedforward", N * Tc, s));
+  }
+  // project_output (model/diffusion.py:60,76) straight into lip[b][t0 + t][:]
+  const int Lp = f->lo_pad;   // rows of lipf are Lp wide, the first Lo columns are the regressor's output
+  GemmP po = gemm_base(f->xs.p, d, f->po_w.p, d, f->po_b.f(), f->lipf.f() + (size_t)t0 * Lp, Lp, N * Tc, Lp, d);
+  po.rows_per_seq = Tc;
+  po.out_seq_pad = T - Tc;
+  CHK(launch_gemm(c, po, s));
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+// FiLMTransformer.encode_lip (model/diffusion.py:295-313): lip regressor over 120-frame chunks of channel 0, nearest-exact
+// interpolation of the [T, lip_out] result to the n_tokens audio tokens, concatenation behind cond_in
+extern "C" int a2p_frontend_encode_lip(a2p_frontend_ctx* f, const float* audio, int32_t batch, int64_t samples, const float* cond_in,
+                                       int32_t n_tokens, int32_t cond_dim, float* out, void* stream) {
+  ARG(f && audio && cond_in && out, "null argument");
+  ARG(f->finalized && f->cfg.lip, "front end without a lip regressor (or not finalized)");
+  const int spf = f->cfg.samples_per_frame, d = f->cfg.d_model, Lo = f->cfg.lip_out, chunk = f->cfg.chunk_frames;
+  ARG(samples % spf == 0, "%lld samples are not a whole number of %d-sample frames", (long long)samples, spf);
+  const int T = (int)(samples / spf), B = batch;
+  ARG(B >= 1 && B <= f->cfg.max_batch && T >= 1 && T <= f->cfg.max_frames, "batch %d / frames %d beyond the configured capacity", B, T);
+  hipStream_t s = (hipStream_t)stream;
+  CHK(fe_reserve(f, (size_t)chunk * spf));
+  if (f->cap_seq < B) {
+    const size_t rows = (size_t)B * 1024 + 128, Sld = 1024;
+    CHK(buf_alloc_tmp(f->cond, rows * d * 4)); CHK(buf_alloc_tmp(f->xs, rows * d * 4)); CHK(buf_alloc_tmp(f->xn, rows * d * 4));
+    CHK(buf_alloc_tmp(f->qk, (rows + (size_t)B * Sld + 64) * d * 4)); CHK(buf_alloc_tmp(f->vt, (size_t)B * d * Sld * 4));
+    CHK(buf_alloc_tmp(f->ao, rows * d * 4)); CHK(buf_alloc_tmp(f->hff, rows * f->cfg.ff_size * 4));
+    CHK(buf_alloc_tmp(f->lipf, (size_t)B * f->cfg.max_frames * rup(Lo, 4) * 4));
+    f->cap_seq = B;
+  }
+  for (int t0 = 0; t0 < T; t0 += chunk) CHK(fe_lip_chunks(f, audio, samples, B, T, t0, std::min(chunk, T - t0), s));
+  const int64_t total = (int64_t)B * n_tokens * (cond_dim + Lo);
+  fe_concat_kernel<<<(int)((total + 255) / 256), 256, 0, s>>>(cond_in, f->lipf.f(), out, B, n_tokens, T, cond_dim, Lo, f->lo_pad);
+  HIPCHK(hipGetLastError());
+  return 0;
+}

@@ -215,6 +215,7 @@ static int gemm_dispatch(KernelTimer& kt, const GemmP& p, hipStream_t s) {
   else if (p.epi == EPI_STORE && p.act == ACT_NONE && p.out_f32) A2P_GEMM(EPI_STORE, ACT_NONE, true);
   else if (p.epi == EPI_STORE && p.act == ACT_NONE) A2P_GEMM(EPI_STORE, ACT_NONE, false);
   else if (p.epi == EPI_STORE && p.act == ACT_GELU && !p.out_f32) A2P_GEMM(EPI_STORE, ACT_GELU, false);
+  else if (p.epi == EPI_STORE && p.act == ACT_RELU && !p.out_f32) A2P_GEMM(EPI_STORE, ACT_RELU, false);   // audio front end
   else {
     set_err("gemm: no kernel instance for epi=%d act=%d out_f32=%d", p.epi, p.act, p.out_f32);
     return A2P_ERR_ARG;
@@ -275,7 +276,10 @@ static int launch_ln_rope(a2p_ctx* c, bool as_f32, const float* x, int64_t ldx, 
 static int launch_attn(a2p_ctx* c, const AttnP& p, int nseq, int kind, hipStream_t s) {
   dim3 grid((p.Tq + 127) / 128, c->H, nseq);
   KernelTimer kt(c, kind);
-  if (c->DH == 64) {
+  if (c->DH == 128) {  // lip regressor of the audio front end (4 heads x 128), fp32 only
+    ARG(!c->bf16, "head_dim 128 is instantiated for fp32 only");
+    A2P_LAUNCH(kt, (attn_kernel<float, 128>), grid, 256, s, p);
+  } else if (c->DH == 64) {
     if (c->bf16) A2P_LAUNCH(kt, (attn_kernel<bf16_t, 64>), grid, 256, s, p);
     else A2P_LAUNCH(kt, (attn_kernel<float, 64>), grid, 256, s, p);
   } else {
@@ -659,3 +663,4 @@ extern "C" int a2p_finalize_weights(a2p_ctx* c, void* stream) {
 
 #include "a2p_lib_run.h"
 #include "a2p_guide.h"
+#include "a2p_frontend.h"

@@ -45,6 +45,7 @@ __device__ __forceinline__ float act_ct(float x) {
   else if constexpr (ACT == ACT_MISH) return act_mish(x);
   else if constexpr (ACT == ACT_SILU) return act_silu(x);
   else if constexpr (ACT == ACT_LRELU) return act_lrelu02(x);
+  else if constexpr (ACT == ACT_RELU) return x > 0.0f ? x : 0.0f;
   else return x;
 }
 

@@ -16,10 +16,12 @@ decoder layer, the unconditional branch -- is hoisted into `a2p_prepare_cond`
 and cached per `y` (the reference recomputes it in every step and CFG pass,
 model/diffusion.py:355-381).
 
-The audio front end (vq-wav2vec conv stack + lip regressor,
-model/diffusion.py:285-313) is outside this path (weights
-unavailable offline): pass its output as `y["cond_embed"]`, or give the module an
-`audio_frontend` callable that maps `y["audio"]` to it.
+The audio front end (vq-wav2vec conv stack + lip regressor, model/diffusion.py:285-313)
+is part of the hoisted work: with `audio_frontend="native"` the module owns `audio_model`
+/ `lip_model` like the reference does and takes the reference's `y["audio"]`
+(model/audio_frontend.py, csrc/a2p_frontend.h; once per clip instead of twice per step).
+`y["cond_embed"]` (the front end's output) is accepted too and takes precedence; any
+other callable `audio_frontend(audio) -> cond_embed` works as well.
 """
 from __future__ import annotations
 
@@ -111,7 +113,7 @@ class FiLMTransformer(nn.Module):
     def __init__(self, args, nfeats: int, latent_dim: int = 512, ff_size: int = 1024, num_layers: int = 4,
                  num_heads: int = 4, dropout: float = 0.1, cond_feature_dim: int = 4800,
                  activation: Callable = F.gelu, use_rotary: bool = True, cond_mode: str = "audio",
-                 split_type: str = "train", device: str = "cuda", audio_frontend: Optional[Callable] = None,
+                 split_type: str = "train", device: str = "cuda", audio_frontend=None, audio_resample: str = "sinc",
                  precision: str = "fp32", max_batch: int = 32, **kwargs) -> None:
         super().__init__()
         if not use_rotary:
@@ -128,7 +130,7 @@ class FiLMTransformer(nn.Module):
         self.split_type = split_type
         self.device = device
         self.seq_len = args.max_seq_length
-        self.audio_frontend = audio_frontend
+        self.audio_frontend = audio_frontend          # None | callable(audio) -> cond_embed | "native" (set up below)
         self.precision = precision
         self.max_batch = max_batch
         d = latent_dim
@@ -179,6 +181,20 @@ class FiLMTransformer(nn.Module):
         self.final_layer = nn.Linear(d, nfeats)
         self.final_layer.apply(init_weight)
 
+        if audio_frontend == "native":
+            # the reference's own front end on the GPU: vq-wav2vec conv features of both channels and, for the
+            # face model, the lip regressor -- the modules own the parameters under the reference's keys (`audio_model.*`,
+            # `lip_model.*`), the arithmetic is csrc/a2p_frontend.h; `y["audio"]` is then all the caller passes
+            from .audio_frontend import Audio2LipRegressionTransformer, NativeAudioFrontend, Wav2VecModel
+            self.audio_model = Wav2VecModel()
+            if self.data_format == "face":
+                self.lip_model = Audio2LipRegressionTransformer()
+            for m in (self.audio_model, getattr(self, "lip_model", None)):
+                if m is not None:
+                    for q in m.parameters():
+                        q.requires_grad = False
+            self.audio_frontend = NativeAudioFrontend(self, resample=audio_resample, max_batch=max_batch, max_frames=self.seq_len)
+
         self._ctx: Optional[C.c_void_p] = None
         self._ctx_lib = None
         self._param_list = None
@@ -198,7 +214,7 @@ class FiLMTransformer(nn.Module):
     def _hot_state(self) -> Dict[str, torch.Tensor]:
         # the guide transformer / tokenizer sub-modules (setup_guide_predictor) own their native contexts
         return {k: v for k, v in self.state_dict().items()
-                if not (k.endswith("rotary.freqs") or k.startswith("transformer.") or k.startswith("tokenizer."))}
+                if not (k.endswith("rotary.freqs") or k.startswith(("transformer.", "tokenizer.", "audio_model.", "lip_model.")))}
 
     def setup_guide_predictor(self, transformer: nn.Module, tokenizer: nn.Module, resume_trans: str = "<in-memory>") -> None:
         """model/diffusion.py:244-271 with the modules passed in (the reference builds them from `args.json` + checkpoint files
@@ -242,7 +258,7 @@ class FiLMTransformer(nn.Module):
         # small configurations host-bound).  In-place updates (load_state_dict, optimisers) bump `_version`;
         # storage re-seating goes through `_apply` above.
         if self._param_list is None:
-            skip = {id(t) for n in ("transformer", "tokenizer") if isinstance(getattr(self, n, None), nn.Module)
+            skip = {id(t) for n in ("transformer", "tokenizer", "audio_model", "lip_model") if isinstance(getattr(self, n, None), nn.Module)
                     for t in list(getattr(self, n).parameters()) + list(getattr(self, n).buffers())}
             self._param_list = [t for t in list(self.parameters()) + list(self.buffers()) if id(t) not in skip]
         return (len(self._param_list), sum(p._version for p in self._param_list))

@@ -14,11 +14,14 @@ def load_model(model, state_dict):
     """Non-strict load with the reference's checks (utils/model_util.py:30-38): no unexpected keys
     (the out-of-scope audio/lip front-end tensors of a reference checkpoint are skipped), and only
     `transformer.` / `tokenizer.` keys may be missing."""
-    state_dict = {k: v for k, v in state_dict.items() if not k.startswith(_IGNORED_PREFIXES)}
+    own = set(model.state_dict().keys())
+    # front-end tensors: loaded when the model was built with audio_frontend="native" (it then owns audio_model / lip_model);
+    # tensors of those sub-models that are not on the path (aggregator, quantiser, GroupNorm ...) are skipped either way
+    state_dict = {k: v for k, v in state_dict.items() if not k.startswith(_IGNORED_PREFIXES) or k in own}
     missing_keys, unexpected_keys = model.load_state_dict(state_dict, strict=False)
     assert len(unexpected_keys) == 0, unexpected_keys
-    assert all(k.startswith("transformer.") or k.startswith("tokenizer.") or k.endswith("rotary.freqs")
-               for k in missing_keys), missing_keys
+    assert all(k.startswith(("transformer.", "tokenizer.")) or k.endswith("rotary.freqs") or
+               (k.startswith(_IGNORED_PREFIXES) and k.endswith(".pe")) for k in missing_keys), missing_keys
 
 
 def create_model_and_diffusion(args, split_type, **model_overrides):

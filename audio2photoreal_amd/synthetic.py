@@ -94,6 +94,33 @@ def synthetic_tokenizer_state_dict(spec: TokenizerSpec, seed: int = 10) -> Dict[
     return {name: _init_like_reference(seed, name, shape, "vq.") for name, shape in tokenizer_param_shapes(spec).items()}
 
 
+def synthetic_frontend_state_dict(seed: int = 10, lip: bool = True) -> Dict[str, torch.Tensor]:
+    """Parameters of the audio front end under the reference's keys (`audio_model.*`, `lip_model.*`; model/audio_frontend.py).
+    Conv weights get He gain (bias-free conv + ReLU stacks: keeps the 8-layer activations O(1) on N(0,1) audio); the positional
+    tables `pe` are the reference's closed form (transformer_modules.py:284-291), not random."""
+    from .model.audio_frontend import Audio2LipRegressionTransformer, Wav2VecModel
+    mods = {"audio_model.": Wav2VecModel()}
+    if lip:
+        mods["lip_model."] = Audio2LipRegressionTransformer()
+    sd: Dict[str, torch.Tensor] = {}
+    for prefix, m in mods.items():
+        for name, ref in m.state_dict().items():
+            key, shape = prefix + name, tuple(ref.shape)
+            if name.endswith(".pe"):
+                sd[key] = ref.clone()
+            elif "conv_layers" in name:
+                fan_in = shape[1] * shape[2]
+                sd[key] = synthetic_tensor(seed, key, shape, float(np.sqrt(2.0 / fan_in)))
+            else:
+                sd[key] = _init_like_reference(seed, name, shape, prefix)
+    return sd
+
+
+def synthetic_audio(seed: int, batch: int, frames: int) -> torch.Tensor:
+    """z-normalised 48 kHz stereo like data_loaders/data.py:237 hands over: N(0, 1) [batch, frames * 1600, 2]."""
+    return synthetic_tensor(seed, "audio", (batch, frames * 1600, 2))
+
+
 def synthetic_inputs(spec: DenoiserSpec, batch: int, frames: int, seed: int = 10,
                      steps_of_noise: int = 0) -> Dict[str, torch.Tensor]:
     """x_T, conditioning features (fed past the hoisted audio front end,

@@ -232,6 +232,41 @@ int a2p_vq_decode(const int64_t* q, int32_t batch, int32_t T, int32_t depth, int
                   int32_t vertices, const float* const* codebooks, const float* const* conv_w, const float* const* conv_b,
                   float* out, void* stream);
 
+/* ---- audio front end ------------------------------------------------------------------
+ * What FiLMTransformer.forward computes from y["audio"] before anything else, in every step and pass (model/diffusion.py:
+ * 354-358): encode_audio (:285-293, both stereo channels through the vq-wav2vec conv feature extractor of model/utils.py:18-26,
+ * after torchaudio Resample(48000, 16000)) and, for the face model, encode_lip (:295-313: Audio2LipRegressionTransformer :37-79 =
+ * Wav2VecEncoder (model/modules/audio_encoder.py:24-46) + RegressionTransformer (model/modules/transformer_modules.py:560-627)
+ * + Linear, over 120-frame chunks; nearest-exact interpolation to the token count; concatenation).  Here it is one call per
+ * clip.  fp32.  Parameter names are the reference's state_dict keys; the conv feature extractors take
+ * `audio_model.feature_extractor.conv_layers.{i}.0.weight` / `lip_model.audio_encoder.wav2vec_model.feature_extractor.
+ * conv_layers.{i}.0.weight` ([512, Cin, k], bias-free conv + ReLU, (k, stride) = (10,5) (8,4) (4,2) (4,2) (4,2) (1,1) (1,1) (1,1));
+ * other `audio_model.*` / `lip_model.*` tensors of a checkpoint are accepted and ignored (a2p_frontend_set_weight returns 1). */
+typedef struct a2p_frontend_ctx a2p_frontend_ctx;
+typedef struct a2p_frontend_config {
+  int32_t conv_dim;          /* 512 */
+  int32_t resample;          /* 0: x[::3]; 1: torchaudio Resample(48000, 16000) windowed sinc (hann, width 6, rolloff 0.99) */
+  int32_t lip;               /* 1: the lip regressor is present (face model) */
+  int32_t d_model, num_heads, ff_size, enc_layers, dec_layers; /* RegressionTransformer: 512, 4, 1024, 2, 4 */
+  int32_t lip_out;           /* n_vertices * 3 = 1014 */
+  int32_t lip_pad;           /* zeros prepended at 16 kHz by Wav2VecEncoder (320) */
+  int32_t chunk_frames;      /* 120 (model/diffusion.py:303) */
+  int32_t samples_per_frame; /* 1600 at 48 kHz */
+  int32_t max_batch, max_frames;
+  int32_t reserved[2];
+} a2p_frontend_config;
+int a2p_frontend_create(const a2p_frontend_config* cfg, a2p_frontend_ctx** out);
+int a2p_frontend_destroy(a2p_frontend_ctx* ctx);
+int a2p_frontend_set_weight(a2p_frontend_ctx* ctx, const char* name, const float* dev_ptr, int64_t numel, void* stream);
+int a2p_frontend_finalize(a2p_frontend_ctx* ctx, void* stream);
+/* encode_audio: audio fp32 [batch, samples, 2] (48 kHz stereo) -> out fp32 [batch, n_tokens, 2 * conv_dim]; fails if the conv
+ * geometry does not give exactly n_tokens. */
+int a2p_frontend_encode_audio(a2p_frontend_ctx* ctx, const float* audio, int32_t batch, int64_t samples, float* out,
+                              int32_t n_tokens, void* stream);
+/* encode_lip: out [batch, n_tokens, cond_dim + lip_out] = cat(cond_in [batch, n_tokens, cond_dim], interpolate(lip(audio[..., 0]))). */
+int a2p_frontend_encode_lip(a2p_frontend_ctx* ctx, const float* audio, int32_t batch, int64_t samples, const float* cond_in,
+                            int32_t n_tokens, int32_t cond_dim, float* out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

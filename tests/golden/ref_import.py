@@ -84,6 +84,10 @@ def import_reference():
         # conditioning producer outside the hot path
         self.lip_model = nn.Identity()
 
+    # the reference's own front end, kept reachable for tests/golden/make_golden_frontend.py
+    if not hasattr(md.FiLMTransformer, "_ref_encode_audio"):
+        md.FiLMTransformer._ref_encode_audio = md.FiLMTransformer.encode_audio
+        md.FiLMTransformer._ref_encode_lip = md.FiLMTransformer.encode_lip
     md.FiLMTransformer.setup_lip_models = _setup_lip_models
 
     # decoder-only conditioning: feed precomputed features

@@ -1,0 +1,100 @@
+"""GPU: the native audio front end (csrc/a2p_frontend.h through the C ABI) against the fixtures the REFERENCE produced and
+against the oracle; `FiLMTransformer` taking the reference's y["audio"]."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from audio2photoreal_amd.model.cfg_sampler import ClassifierFreeSampleModel
+from audio2photoreal_amd.model_util import create_model_and_diffusion, default_args, load_model
+from audio2photoreal_amd.spec import face_spec, pose_spec
+from audio2photoreal_amd.synthetic import synthetic_audio, synthetic_frontend_state_dict, synthetic_state_dict, synthetic_tensor
+from conftest import ROOT, record, rel_l2, rel_max
+
+pytestmark = pytest.mark.gpu
+SEED, B, FRAMES = 10, 2, 240
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "GPU tests need the MI355X"
+    return torch.device("cuda:0")
+
+
+def build(fmt, dev, resample, precision="fp32", layers=1):
+    spec = (face_spec if fmt == "face" else pose_spec)(num_layers=layers)
+    model, diffusion = create_model_and_diffusion(default_args(fmt, layers=layers, timestep_respacing="ddim10"), "test",
+                                                  precision=precision, max_batch=B, audio_frontend="native", audio_resample=resample)
+    load_model(model, {**synthetic_state_dict(spec, SEED), **synthetic_frontend_state_dict(SEED, lip=fmt == "face")})
+    return spec, model.to(dev).eval(), diffusion
+
+
+def test_front_end_vs_reference_golden(dev):
+    """encode_audio + encode_lip on the GPU == the reference's own methods (stub resampler / conv geometry), fp32 <= 1e-3."""
+    gold = np.load(os.path.join(ROOT, "tests", "golden", "golden_frontend_v1.npz"))
+    _, model, _ = build("face", dev, "decimate")
+    audio = synthetic_audio(SEED, B, FRAMES).to(dev)
+    fe = model.audio_frontend
+    emb = fe.encode_audio(audio)
+    full = fe(audio)
+    assert tuple(full.shape) == tuple(gold["shape"])
+    e = {"emb": rel_l2(emb[:, ::16].cpu(), gold["emb_rows16"]), "emb_max": rel_max(emb[:, ::16].cpu(), gold["emb_rows16"]),
+         "full": rel_l2(full[:, ::16].cpu(), gold["full_rows16"]), "full_max": rel_max(full[:, ::16].cpu(), gold["full_rows16"]),
+         "norm": abs(float(full.norm()) / float(gold["full_norm"]) - 1)}
+    record("frontend/golden", **e)
+    assert max(e.values()) < 1e-3, e
+
+
+def test_front_end_sinc_and_600_frames_vs_oracle(dev):
+    """The product default (windowed-sinc resampler) and the bench shape (600 frames = 5 lip chunks, 1998 tokens) vs the oracle."""
+    from oracle import frontend_oracle as FO
+    _, model, _ = build("face", dev, "sinc")
+    sd = synthetic_frontend_state_dict(SEED, lip=True)
+    audio = synthetic_audio(SEED, 1, 600)
+    torch.set_num_threads(min(os.cpu_count() or 1, 32))
+    with torch.no_grad():
+        want = FO.encode_lip(audio, FO.encode_audio(audio, sd, FO.resample_sinc), sd, FO.resample_sinc)
+    got = model.audio_frontend(audio.to(dev)).cpu()
+    assert got.shape == (1, 1998, 2038)
+    e = {"rel_l2": rel_l2(got, want), "max_norm": rel_max(got, want)}
+    record("frontend/sinc_T600", **e)
+    assert max(e.values()) < 1e-3, e
+    # a 150-frame clip: one full chunk + a 30-frame remainder (model/diffusion.py:303 slices [i : i + 120])
+    audio = synthetic_audio(SEED + 1, 2, 150)
+    with torch.no_grad():
+        want = FO.encode_lip(audio, FO.encode_audio(audio, sd, FO.resample_sinc), sd, FO.resample_sinc)
+    got = model.audio_frontend(audio.to(dev)).cpu()
+    assert rel_l2(got, want) < 1e-3 and rel_max(got, want) < 1e-3
+
+
+@pytest.mark.parametrize("fmt", ["face", "pose"])
+def test_denoiser_takes_the_reference_audio_contract(dev, fmt):
+    """y = {"audio": [B, T*1600, 2], ...} exactly as data_loaders/tensors.py:57-67 builds it: the forward equals the one fed with the
+    front end's own output as y["cond_embed"], and the front end runs once per clip (cache hit on the second call)."""
+    spec, model, diffusion = build(fmt, dev, "sinc")
+    T = 120
+    audio = synthetic_audio(SEED, B, T).to(dev)
+    x = synthetic_tensor(SEED, "x_T", (B, spec.nfeats, 1, T)).to(dev)
+    y = {"audio": audio, "scale": torch.full((B,), 10.0 if fmt == "face" else 2.0, device=dev)}
+    if spec.is_pose:
+        y["keyframes"] = synthetic_tensor(SEED, "keyframes", (B, 4, spec.keyframe_dim)).to(dev)
+        y["mask"] = torch.ones(B, 1, 1, T, dtype=torch.bool, device=dev)
+    cfg = ClassifierFreeSampleModel(model)
+    t = torch.tensor([500, 3], device=dev)
+    a = cfg(x, t, y).clone()
+    calls = {"n": 0}
+    orig = model.audio_frontend.encode_audio
+    model.audio_frontend.encode_audio = lambda au: (calls.__setitem__("n", calls["n"] + 1), orig(au))[1]
+    b = cfg(x, t, y)
+    assert calls["n"] == 0 and torch.equal(a, b)            # hoisted: no second front-end run for the same clip
+    model.audio_frontend.encode_audio = orig
+    y2 = {k: v for k, v in y.items() if k != "audio"}
+    if spec.is_pose:
+        y2["keyframes"] = synthetic_tensor(SEED, "keyframes", (B, 4, spec.keyframe_dim)).to(dev)
+    y2["cond_embed"] = model.audio_frontend(audio)
+    assert y2["cond_embed"].shape[-1] == spec.cond_feature_dim
+    c = cfg(x, t, y2)
+    assert torch.equal(a, c)
+    out = diffusion.ddim_sample_loop(cfg, (B, spec.nfeats, 1, T), clip_denoised=False, model_kwargs={"y": y}, noise=x)
+    assert out.shape == (B, spec.nfeats, 1, T) and bool(torch.isfinite(out).all())
