@@ -13,7 +13,7 @@ PyTorch); the arithmetic is liba2p_hip.so's `a2p_frontend_*` entry points (csrc/
 
 fairseq and torchaudio are absent offline: the conv stacks use the published layer geometry (bias-free Conv1d + ReLU), the
 resampler is torchaudio's documented windowed-sinc kernel ("sinc", default) or the 3:1 decimation of the golden generator's
-stub ("decimate").  Everything that IS in /root/reference -- the regression transformer, chunking, interpolation, concat --
+stub ("decimate").  Everything that IS in the reference tree -- the regression transformer, chunking, interpolation, concat --
 is pinned by reference-generated goldens (tests/golden/golden_frontend_v1.npz).
 """
 from __future__ import annotations
