@@ -273,8 +273,12 @@ static int launch_ln_rope(a2p_ctx* c, bool as_f32, const float* x, int64_t ldx, 
   return 0;
 }
 
-static int launch_attn(a2p_ctx* c, const AttnP& p, int nseq, int kind, hipStream_t s) {
-  dim3 grid((p.Tq + 127) / 128, c->H, nseq);
+static int launch_attn(a2p_ctx* c, const AttnP& p0, int nseq, int kind, hipStream_t s) {
+  AttnP p = p0;
+  p.nq = (p.Tq + 127) / 128; p.nheads = c->H; p.nseq = nseq;
+  static const bool no_remap = getenv("A2P_ATTN_NO_REMAP") != nullptr;   // A/B switch
+  p.xcd_remap = (!no_remap && (c->H * nseq) % 8 == 0) ? 1 : 0;
+  dim3 grid(p.nq * c->H * nseq);
   KernelTimer kt(c, kind);
   if (c->DH == 128) {  // lip regressor of the audio front end (4 heads x 128), fp32 only
     ARG(!c->bf16, "head_dim 128 is instantiated for fp32 only");

@@ -40,6 +40,11 @@ struct AttnP {
                        // they do not evict the chain kernels' weight streams from L2 / MALL
   int Tq, S_main, S_tail;
   float scale_log2e;   // log2(e) / sqrt(head_dim)
+  // Workgroup -> (query block, head, sequence).  The grid is 1-D; with xcd_remap the 8 XCDs (block b runs on XCD b % 8) each
+  // take whole (sequence, head) pairs, pair % 8 == xcd, and walk their query blocks back to back: all query blocks of a pair
+  // -- and, with 8 heads, every sequence of a head, i.e. all users of the shared unconditional K/V slot -- read their K/V
+  // through ONE L2 instead of five (T = 600: 5 query blocks per pair, each of which used to pull the pair's K/V from HBM)
+  int nq, nheads, nseq, xcd_remap;
 };
 
 // LDS tile geometry: K tile [64 keys][DH], V^T tile [DH][64 keys]
@@ -96,8 +101,21 @@ __global__ __launch_bounds__(256, 3) void attn_kernel(AttnP p) {
 
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int l15 = lane & 15, g = lane >> 4;
-  const int seq = blockIdx.z, head = blockIdx.y;
-  const int q0 = blockIdx.x * BQ + wid * (QT * 16);
+  int qb, head, seq;
+  {
+    const int b = blockIdx.x;
+    if (p.xcd_remap) {  // pairs = nheads * nseq is a multiple of 8 (checked by the host)
+      const int xcd = b & 7, j = b >> 3, pair = (j / p.nq) * 8 + xcd;
+      qb = j % p.nq;
+      head = pair % p.nheads;
+      seq = pair / p.nheads;
+    } else {
+      qb = b % p.nq;
+      head = (b / p.nq) % p.nheads;
+      seq = b / (p.nq * p.nheads);
+    }
+  }
+  const int q0 = qb * BQ + wid * (QT * 16);
   // waves of the last query block whose whole range lies past Tq (T=600: 1 of 20 waves) still take part in the tile DMA and
   // the barriers but skip the MFMA / softmax work: their issue slots go to the co-resident waves
   const bool wave_active = __builtin_amdgcn_readfirstlane(q0) < p.Tq;
