@@ -338,27 +338,41 @@ static int launch_cross_attention(a2p_ctx* c, int N, int T, const CrossKV& kv, h
 }
 
 // FiLMTransformerDecoderLayer.forward as PRE? | self attention | MID | cross attention | (MID | cross attention 2) | POST
+// shared_half: classifier-free guidance, layer 0 -- both halves of the 2B sequences start from the same x (one input
+// projection) and therefore share norm1 / Q,K,V / the self attention: those run on the first N/2 sequences only, and the MID
+// kernel of the second half reads the first half's rows (ChainP::src_rows)
 static int decoder_layer_chain(a2p_ctx* c, int l, int N, int T, const CrossKV& kv, const CrossKV* kv2, const FilmRef& fr, bool first,
-                               bool has_next, hipStream_t s, hipEvent_t film_ready = nullptr, bool fuse_final = false) {
+                               bool has_next, hipStream_t s, hipEvent_t film_ready = nullptr, bool fuse_final = false,
+                               bool shared_half = false) {
   const int d = c->d;
   const std::string pf = "seqTransDecoder.stack." + std::to_string(l) + ".";
   ChainP p;
   const char* jp = getenv("A2P_SIDE_JOIN");  // diagnostic: where the main stream joins the side stream (1 PRE, 2 self attention, default MID)
   const int join_at = jp ? atoi(jp) : 3;
   if (film_ready && join_at <= 1) HIPCHK(hipStreamWaitEvent(s, film_ready, 0));
+  const int Nsa = shared_half ? N / 2 : N;
+  // shared_half: the input projection wrote the (N/2)*T rows both halves start from into c->hff (unused by the chain path, fp32
+  // here); PRE reads them there, MID reads them there for BOTH halves and writes all N*T rows of c->x -- never in place: a
+  // second-half workgroup may start after the first-half workgroup of the same source rows has stored its result
+  float* x0 = shared_half ? c->hff.f() : nullptr;
   if (first) {
-    chain_base(c, p, N, T, ch_index(l, CH_PRE), 3 * d);
+    chain_base(c, p, Nsa, T, ch_index(l, CH_PRE), 3 * d);
     chain_set_pre(c, p, l, T);
+    if (x0) p.x = x0;
     CHK(launch_chain(c, CHAIN_PRE, p, s));
   }
   if (film_ready && join_at == 2) HIPCHK(hipStreamWaitEvent(s, film_ready, 0));
-  CHK(launch_self_attention(c, N, T, s));
+  CHK(launch_self_attention(c, Nsa, T, s));
   if (film_ready && join_at >= 3) HIPCHK(hipStreamWaitEvent(s, film_ready, 0));  // FiLM / time-token K,V of this step (side stream)
   auto mid = [&](int kind, const std::string& attn_done, int film_idx, const std::string& norm) -> int {
     chain_base(c, p, N, T, ch_index(l, kind), d);
     chain_set_out_proj(c, p, pf + attn_done, fr, film_idx);
     p.lnA_g = W32(c, pf + norm + ".weight"); p.lnA_b = W32(c, pf + norm + ".bias");
     p.q_out = reinterpret_cast<bf16_t*>(c->qk.p); p.ld_q = d;
+    if (shared_half && kind == CH_MID) {
+      p.src_rows = (N / 2) * T;
+      p.xsrc = x0;
+    }
     return launch_chain(c, CHAIN_MID, p, s);
   };
   CHK(mid(CH_MID, "self_attn", 0, "norm2"));
@@ -533,11 +547,12 @@ static int run_forward(a2p_ctx* c, const float* x_in, const int64_t* t_orig, int
   // (measured: 0.99 vs 1.10 ms per step at 480 rows, equal at 1200, chain ahead from 2400 rows on).
   const bool use_chain = chain_supported(c) && ((int64_t)N * T >= 960 || getenv("A2P_CHAIN_MT"));
   // The time path (7 latency-bound launches, ~70 us at B=8) is not needed before the first out_proj epilogue and can run on
-  // the side stream next to input projection / norm1+QKV / self attention of layer 0 (-2 % step time).  Opt-in
-  // (A2P_SIDE_STREAM=1): with the two queues active, 1-30 % of forwards on some boxes used to differ for one sample; that was
-  // traced to tpath_post_kernel consuming a load right behind its s_waitcnt (kernels_misc.h, DESIGN.md section 6
-  // "Reproducibility") and fixed there -- 0 / 1500 differing forwards since -- but 2 % is inside the box-to-box spread.
-  const bool overlap_tpath = use_chain && getenv("A2P_SIDE_STREAM") && !getenv("A2P_NO_SIDE_STREAM");
+  // the side stream next to input projection / norm1+QKV / self attention of layer 0 (-2..3 % step time).  On by default since
+  // round 2 (A2P_NO_SIDE_STREAM=1 turns it off): in round 1, with the two queues active, 1-30 % of forwards on some boxes
+  // differed for one sample; that was traced to tpath_post_kernel consuming a load right behind its s_waitcnt (kernels_misc.h,
+  // DESIGN.md "Reproducibility") and fixed there -- 0 / 1500 differing forwards in round 1, 0 / 600 + identical 60-step
+  // trajectories in both 16-bit modes in round 2 (scratch/side_stress.py).
+  const bool overlap_tpath = use_chain && !getenv("A2P_NO_SIDE_STREAM");
   if (overlap_tpath) {
     c->ev_fork = c->ev_fork_pool[c->ev_turn & 7];
     c->ev_join = c->ev_join_pool[c->ev_turn & 7];
@@ -555,11 +570,12 @@ static int run_forward(a2p_ctx* c, const float* x_in, const int64_t* t_orig, int
     dim3 grid((T + 31) / 32, (c->Cpad + 31) / 32, B);
     if (c->bf16) pack_input_kernel<bf16_t><<<grid, 256, 0, s>>>(x_in, (bf16_t*)c->inpack.p, B, c->C, T, c->Cpad);
     else pack_input_kernel<float><<<grid, 256, 0, s>>>(x_in, (float*)c->inpack.p, B, c->C, T, c->Cpad);
-    GemmP p = gemm_base(c->inpack.p, c->Cpad, c->wt.at("input_projection.weight").p, c->Cpad, W32(c, "input_projection.bias"), c->x.p, d,
-                        B * T, d, c->Cpad);
+    const bool shared_half = use_chain && N == 2 * B && !getenv("A2P_NO_SHARED_HALF");
+    GemmP p = gemm_base(c->inpack.p, c->Cpad, c->wt.at("input_projection.weight").p, c->Cpad, W32(c, "input_projection.bias"),
+                        shared_half ? c->hff.p : c->x.p, d, B * T, d, c->Cpad);
     p.out_f32 = 1;
     CHK(launch_gemm(c, p, s));
-    if (N == 2 * B) {
+    if (N == 2 * B && !shared_half) {   // chain path under guidance: layer 0 reads the one copy for both halves (decoder_layer_chain)
       const int64_t n4 = (int64_t)B * T * d / 4;
       dup_rows_kernel<<<(int)((n4 + 255) / 256), 256, 0, s>>>(reinterpret_cast<const float4*>(c->x.p),
                                                              reinterpret_cast<float4*>(c->x.f() + (size_t)B * T * d), n4);
@@ -587,7 +603,7 @@ static int run_forward(a2p_ctx* c, const float* x_in, const int64_t* t_orig, int
     fr.seq_stride = (int64_t)L * F * 2 * d;
     if (use_chain)
       CHK(decoder_layer_chain(c, l, N, T, kv, c->pose ? &kv2 : nullptr, fr, l == 0, l + 1 < L, s, (overlap_tpath && l == 0) ? c->ev_join : nullptr,
-                              /*fuse_final=*/!c->pose));
+                              /*fuse_final=*/!c->pose, /*shared_half=*/l == 0 && N == 2 * B && !getenv("A2P_NO_SHARED_HALF")));
     else CHK(decoder_layer(c, l, N, T, kv, c->pose ? &kv2 : nullptr, fr, s));
   }
   if (tune1) HIPCHK(hipEventRecord(tune1, s));

@@ -51,6 +51,11 @@ enum { CHAIN_PRE = 0, CHAIN_MID = 1, CHAIN_POST = 2 };
 
 struct ChainP {
   int M, rows_per_seq, has_next, aux_kb;
+  int src_rows;           // > 0: the residual rows and the attention-output panel of row m are READ at row m - src_rows when m >= src_rows
+                          // (layer 0 under classifier-free guidance: both halves of the batch enter with the same x and the same
+                          // self attention, so the first PRE kernel and the first self attention run on one half only)
+  const float* xsrc;      // residual rows are read from here instead of x when non-null: with src_rows the read rows of one
+                          // workgroup are the WRITTEN rows of another, so the source must be a buffer this launch does not write
   float* x;               // fp32 residual stream [M][D], updated in place
   const bf16_t* stream;   // packed weight stream of this chain
   const float* aux;       // per-tile biases of this chain, aux_kb KiB: POST [bias_1 | bias_qk' | bias_v'], MID [bias_q], PRE [bias_qk | bias_v]
@@ -366,6 +371,7 @@ __global__ __launch_bounds__(64 * NW, 1) void chain_kernel(const ChainP p) {
       const int row = r0 + lane / CPR, pos = lane % CPR;
       int m = m0 + row;
       m = m < p.M ? m : p.M - 1;
+      m = (p.src_rows > 0 && m >= p.src_rows) ? m - p.src_rows : m;
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(p.ain + (int64_t)m * p.ld_ain + ((pos ^ (row & 15)) << 3)),
                                        (__attribute__((address_space(3))) void*)(panelA + r0 * D), 16, 0, CHAIN_NT ? 2 : 0);
     }
@@ -375,7 +381,8 @@ __global__ __launch_bounds__(64 * NW, 1) void chain_kernel(const ChainP p) {
   for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
     for (int ns = 0; ns < NSUB; ++ns) {
-      xrow[mt][ns] = chain_ld4(p.x + (int64_t)row_m[mt] * D + col_of(ns / NJ, ns % NJ));
+      const int ms = (p.src_rows > 0 && row_m[mt] >= p.src_rows) ? row_m[mt] - p.src_rows : row_m[mt];
+      xrow[mt][ns] = chain_ld4((p.xsrc ? p.xsrc : p.x) + (int64_t)ms * D + col_of(ns / NJ, ns % NJ));
     }
 #pragma unroll
   for (int i = 0; i < NS - 1; ++i) issue_stage();

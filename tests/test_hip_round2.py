@@ -190,3 +190,31 @@ def test_chain_workgroup_shapes_are_bit_identical_pose(dev, B, T, monkeypatch):
     record(f"pose_nw/B{B}_T{T}", max_abs_diff=d)
     assert torch.equal(outs["4"], outs["8"]), f"max |diff| = {d:.3e}"
     model.release()
+
+
+# ----------------------------------------------------------------------------- layer-0 work shared by the two guidance halves
+@pytest.mark.parametrize("fmt,B,T", [("face", 4, 240), ("face", 8, 600), ("pose", 16, 600)])
+def test_layer0_shared_half_is_bit_identical_to_the_duplicated_path(dev, fmt, B, T, monkeypatch):
+    """Under classifier-free guidance both halves of the 2B sequences enter layer 0 with the same x, so norm1 / Q,K,V / the
+    first self attention run once (csrc/a2p_lib_run.h `shared_half`).  Same bits as running them twice -- including grids of
+    several rounds, where a second-half workgroup starts after the first-half one has stored its rows (the source rows live in
+    a separate buffer for exactly that reason)."""
+    spec, sd, model, _ = build(fmt, "bf16", dev, max_batch=B)
+    cfg = ClassifierFreeSampleModel(model)
+    inp = synthetic_inputs(spec, B, T, SEED)
+    y = {"cond_embed": inp["cond_embed"].to(dev), "scale": torch.full((B,), 10.0 if fmt == "face" else 2.0, device=dev)}
+    if spec.is_pose:
+        y["keyframes"], y["mask"] = inp["keyframes"].to(dev), inp["mask"].to(dev)
+    x = inp["x_T"].to(dev)
+    t = torch.tensor(([901, 417, 33, 0] * 4)[:B], device=dev)
+    outs = {}
+    for nw in ("4", "8"):
+        monkeypatch.setenv("A2P_CHAIN_NW", nw)
+        monkeypatch.delenv("A2P_NO_SHARED_HALF", raising=False)
+        shared = cfg(x, t, y).clone()
+        monkeypatch.setenv("A2P_NO_SHARED_HALF", "1")
+        dup = cfg(x, t, y).clone()
+        assert torch.equal(shared, dup), f"NW={nw}: max |diff| = {float((shared - dup).abs().max()):.3e}"
+        outs[nw] = shared
+    assert torch.equal(outs["4"], outs["8"])
+    model.release()
