@@ -1,8 +1,8 @@
 # rocprofv3 evidence for profiles/: kernel stats + HBM traffic counters of the default bench command (run under gpurun)
 R=$GRAFT_REPO_ROOT
-TAG=${1:-r01_v3}
+TAG=${1:-r02}
 cd /tmp && export TMPDIR=/tmp
-B="python $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-kernel-timing"
+B="python $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-kernel-timing --no-legs --repeats 1"
 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_$TAG -o p -- $B > $R/gpurun_out/prof_$TAG.log 2>&1
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $R/gpurun_out/pmcf_$TAG -o p -- $B > $R/gpurun_out/pmcf_$TAG.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $R/gpurun_out/pmcw_$TAG -o p -- $B > $R/gpurun_out/pmcw_$TAG.log 2>&1
