@@ -225,7 +225,7 @@ static int chain_pick_nw(a2p_ctx* c, int64_t rows, hipEvent_t* e0, hipEvent_t* e
   if (const char* f = getenv("A2P_CHAIN_NW")) return atoi(f) == 8 ? 8 : 4;
   if (const char* m = getenv("A2P_CHAIN_MT")) {  // a forced panel height the 8-wave kernels do not have
     const int mt = atoi(m);
-    if (mt > (c->d == 512 ? 3 : 4)) return 4;
+    if (mt > 4) return 4;
   }
   auto& t = c->ch_tune[rows];
   if (t.choice) return t.choice;
@@ -260,15 +260,18 @@ static int launch_chain(a2p_ctx* c, int mode, const ChainP& p, hipStream_t s) {
   int mt = env_mt ? atoi(env_mt) : 0;
   // panel heights instantiated per width (LDS: the [16*MT][d] bf16 panel + hidden chunk + >= 3 ring slots must fit 160 KiB)
   static const int kMt512[] = {4, 3, 2}, kMt256[] = {6, 5, 4, 3, 2};
-  static const int kMt512w8[] = {3, 2}, kMt256w8[] = {4, 3, 2};  // 8 waves: 256 registers per wave bound the panel height
+  static const int kMt512w8[] = {4, 3, 2}, kMt256w8[] = {4, 3, 2};  // 8 waves: 256 registers per wave bound the panel height
   const bool w8 = c->ch_nw == 8;
   const int* cands = c->d == 512 ? (w8 ? kMt512w8 : kMt512) : (w8 ? kMt256w8 : kMt256);
-  const int ncand = c->d == 512 ? (w8 ? 2 : 3) : (w8 ? 3 : 5);
+  const int ncand = c->d == 512 ? 3 : (w8 ? 3 : 5);
   bool ok = false;
   for (int i = 0; i < ncand; ++i) ok = ok || cands[i] == mt;
-  if (!ok) {  // fewest rounds over the 256 CUs, then the cheaper (shorter) panel: every panel streams all weights once
+  if (!ok) {  // fewest rounds over the 256 CUs, then the cheaper (shorter) panel: every panel streams all weights once.
+    // d = 512: the 64-row panels are left to A2P_CHAIN_MT -- their POST kernels spill (20 B / 340 B of scratch per lane with
+    // 4 / 8 waves) and measure slower at every size tried (B=32: 133 vs 141 steps/s with 4 waves, 143 vs 148 with 8)
     int best = 1 << 30;
     for (int i = 0; i < ncand; ++i) {
+      if (c->d == 512 && cands[i] == 4) continue;
       const int blocks = (p.M + 16 * cands[i] - 1) / (16 * cands[i]);
       const int cost = ((blocks + 255) / 256) * (16 + 4 * cands[i]);
       if (cost < best) { best = cost; mt = cands[i]; }
@@ -286,7 +289,8 @@ static int launch_chain(a2p_ctx* c, int mode, const ChainP& p, hipStream_t s) {
   if (w8) {
     if (c->d == 512) {
       if (mt == 2) A2P_CHAIN_W(512, 2, 8);
-      else A2P_CHAIN_W(512, 3, 8);
+      else if (mt == 3) A2P_CHAIN_W(512, 3, 8);
+      else A2P_CHAIN_W(512, 4, 8);
     } else {
       if (mt == 2) A2P_CHAIN_W(256, 2, 8);
       else if (mt == 3) A2P_CHAIN_W(256, 3, 8);
