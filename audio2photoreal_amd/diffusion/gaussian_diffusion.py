@@ -153,6 +153,12 @@ class GaussianDiffusion:
         one_m = self._tab("sqrt_one_minus_alphas_cumprod", t, x_start)
         return mean, one_m * one_m, 2.0 * th.log(one_m)
 
+    @staticmethod
+    def _call(fn_name, on, *args):
+        """One C-ABI launch on `on`'s device and torch's current stream there (launches go to the CURRENT device)."""
+        with _lib.on_device_of(on):
+            _lib.check(getattr(_lib.load(), fn_name)(*args, _lib.current_stream(on.device)), fn_name)
+
     def q_sample(self, x_start, t, noise=None):
         """x_t = sqrt(abar_t) x_0 + sqrt(1 - abar_t) noise   (reference :215-233)."""
         x_start = self._prep(x_start)
@@ -163,9 +169,8 @@ class GaussianDiffusion:
         out = th.empty_like(x_start)
         B = x_start.shape[0]
         t64 = t.to(th.int64).contiguous()
-        _lib.check(_lib.load().a2p_q_sample(_lib.ptr(x_start), _lib.ptr(t64), _lib.ptr(self._tables(x_start.device)),
-                                            self.num_timesteps, _lib.ptr(noise), B, x_start.numel() // B, _lib.ptr(out),
-                                            _lib.current_stream()), "a2p_q_sample")
+        self._call("a2p_q_sample", x_start, _lib.ptr(x_start), _lib.ptr(t64), _lib.ptr(self._tables(x_start.device)),
+                                            self.num_timesteps, _lib.ptr(noise), B, x_start.numel() // B, _lib.ptr(out))
         return out
 
     def q_posterior_mean_variance(self, x_start, x_t, t):
@@ -176,9 +181,9 @@ class GaussianDiffusion:
         as_btc = self._prep(x_start).squeeze(2).permute(0, 2, 1).contiguous()
         x0, mean = th.empty_like(x_t), th.empty_like(x_t)
         t64 = t.to(th.int64).contiguous()
-        _lib.check(_lib.load().a2p_p_mean_variance(_lib.ptr(as_btc), _lib.ptr(x_t), _lib.ptr(t64),
+        self._call("a2p_p_mean_variance", as_btc, _lib.ptr(as_btc), _lib.ptr(x_t), _lib.ptr(t64),
                                                    _lib.ptr(self._tables(x_t.device)), self.num_timesteps, B, C, T, 0,
-                                                   _lib.ptr(x0), _lib.ptr(mean), _lib.current_stream()), "a2p_p_mean_variance")
+                                                   _lib.ptr(x0), _lib.ptr(mean))
         return mean, self._tab("posterior_variance", t, x_t), self._tab("posterior_log_variance_clipped", t, x_t)
 
     # ------------------------------------------------------------------ p(.)
@@ -198,10 +203,9 @@ class GaussianDiffusion:
         assert model_output.shape == (B, T, C), f"{tuple(model_output.shape)} != {(B, T, C)}"
         pred, mean = th.empty_like(x), th.empty_like(x)
         t64 = t.to(th.int64).contiguous()
-        _lib.check(_lib.load().a2p_p_mean_variance(_lib.ptr(model_output), _lib.ptr(x), _lib.ptr(t64),
+        self._call("a2p_p_mean_variance", model_output, _lib.ptr(model_output), _lib.ptr(x), _lib.ptr(t64),
                                                    _lib.ptr(self._tables(x.device)), self.num_timesteps, B, C, T,
-                                                   int(bool(clip_denoised)), _lib.ptr(pred), _lib.ptr(mean),
-                                                   _lib.current_stream()), "a2p_p_mean_variance")
+                                                   int(bool(clip_denoised)), _lib.ptr(pred), _lib.ptr(mean))
         return {"mean": mean, "variance": self._tab("posterior_variance", t, x),
                 "log_variance": self._tab("posterior_log_variance_clipped", t, x), "pred_xstart": pred}
 
@@ -246,10 +250,9 @@ class GaussianDiffusion:
         sample = th.empty_like(out["mean"])
         B = x.shape[0]
         t64, nz = t.to(th.int64).contiguous(), self._prep(noise)
-        _lib.check(_lib.load().a2p_p_sample_update(_lib.ptr(out["mean"]), _lib.ptr(t64),
+        self._call("a2p_p_sample_update", out["mean"], _lib.ptr(out["mean"]), _lib.ptr(t64),
                                                    _lib.ptr(self._tables(x.device)), self.num_timesteps,
-                                                   _lib.ptr(nz), B, x.numel() // B, _lib.ptr(sample),
-                                                   _lib.current_stream()), "a2p_p_sample_update")
+                                                   _lib.ptr(nz), B, x.numel() // B, _lib.ptr(sample))
         return {"sample": sample, "pred_xstart": out["pred_xstart"]}
 
     def ddim_sample(self, model, x, t, clip_denoised=True, denoised_fn=None, cond_fn=None, model_kwargs=None, eta=0.0,
@@ -266,10 +269,10 @@ class GaussianDiffusion:
         sample = th.empty_like(x)
         B = x.shape[0]
         t64, nz = t.to(th.int64).contiguous(), (None if noise is None else self._prep(noise))
-        _lib.check(_lib.load().a2p_ddim_update(_lib.ptr(out["pred_xstart"]), _lib.ptr(x), _lib.ptr(t64),
+        self._call("a2p_ddim_update", out["pred_xstart"], _lib.ptr(out["pred_xstart"]), _lib.ptr(x), _lib.ptr(t64),
                                                _lib.ptr(self._tables(x.device)), self.num_timesteps,
                                                _lib.ptr(nz), float(eta), B,
-                                               x.numel() // B, _lib.ptr(sample), _lib.current_stream()), "a2p_ddim_update")
+                                               x.numel() // B, _lib.ptr(sample))
         return {"sample": sample, "pred_xstart": out["pred_xstart"]}
 
     # ------------------------------------------------------------------ loops
@@ -356,8 +359,7 @@ class GaussianDiffusion:
     def _elementwise(self, fn_name, x, *args):
         """Launch one of the [B, per_sample] sampler kernels on x's stream; returns the fp32 output tensor."""
         out = th.empty_like(x)
-        _lib.check(getattr(_lib.load(), fn_name)(*args, x.shape[0], x.numel() // x.shape[0], _lib.ptr(out),
-                                                 _lib.current_stream()), fn_name)
+        self._call(fn_name, x, *args, x.shape[0], x.numel() // x.shape[0], _lib.ptr(out))
         return out
 
     def ddim_reverse_sample(self, model, x, t, clip_denoised=True, denoised_fn=None, model_kwargs=None, eta=0.0):
