@@ -87,6 +87,18 @@ __device__ __forceinline__ void attn_glds16(const bf16_t* gsrc, bf16_t* lds_wave
                                    (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, AUX);
 }
 
+// Cross-row (lane ^ 16, lane ^ 32) max-reduction of a per-lane value without the LDS crossbar: gfx950's
+// v_permlane32_swap / v_permlane16_swap exchange whole 32- / 16-lane halves between two registers in the VALU, where
+// __shfl_xor goes through ds_bpermute_b32 (an LDS round trip of ~100 cycles, four of them serialised per 64-key tile).
+__device__ __forceinline__ float attn_rowgroup_max(float v) {
+  const unsigned u = __float_as_uint(v);
+  const auto a = __builtin_amdgcn_permlane32_swap(u, u, false, false);   // a[0] = {lo, lo}, a[1] = {hi, hi}
+  const float m = fmaxf(__uint_as_float(a[0]), __uint_as_float(a[1]));
+  const unsigned w = __float_as_uint(m);
+  const auto b = __builtin_amdgcn_permlane16_swap(w, w, false, false);   // rows {0,0,2,2} and {1,1,3,3}
+  return fmaxf(__uint_as_float(b[0]), __uint_as_float(b[1]));
+}
+
 // ABL: ablation switches for scratch/attn_bench.hip only (the library instantiates ABL = 0):
 //   1 = no exp, 2 = no running-max reduction, 4 = no staging / barriers after tile 0, 8 = no PV MFMAs, 16 = no QK^T MFMAs
 template <typename T, int DH, int ABL = 0>
@@ -149,21 +161,20 @@ __global__ __launch_bounds__(256, 3) void attn_kernel(AttnP p) {
   }
 
   // ---- staging ------------------------------------------------------------------------------
-  [[maybe_unused]] int64_t ksrc[2], vsrc[2];  // bf16: per-lane source offsets of this wave's DMA pieces
+  // bf16: per-lane source offset of this wave's FIRST K / V^T DMA piece.  Piece j of a wave lies 4*KRPI key rows (K) or 32 V^T
+  // rows further on and has the same swizzle (kswz / vswz are periodic in 32 rows), so the rest of the address is wave-uniform
+  [[maybe_unused]] int64_t ksrc0 = 0, vsrc0 = 0;
   if constexpr (L::DMA) {
     constexpr int CPR = DH / 8;          // 16-byte chunks per K row
     constexpr int KRPI = 64 / CPR;       // K rows per wave-instruction
-    constexpr int KPW = CPR / 4;         // K instructions per wave (4 waves)
-    constexpr int VPW = DH / 32;         // V^T instructions per wave (8 rows each)
-#pragma unroll
-    for (int j = 0; j < KPW; ++j) {
-      const int row = (j * 4 + wid) * KRPI + lane / CPR, pos = lane % CPR;
-      ksrc[j] = (int64_t)row * p.ldk + ((pos ^ L::kswz(row)) << 3);
+    static_assert((4 * KRPI) % 32 == 0, "K pieces of one wave must share their swizzle");
+    {
+      const int row = wid * KRPI + lane / CPR, pos = lane % CPR;
+      ksrc0 = (int64_t)row * p.ldk + ((pos ^ L::kswz(row)) << 3);
     }
-#pragma unroll
-    for (int j = 0; j < VPW; ++j) {
-      const int row = (j * 4 + wid) * 8 + (lane >> 3), pos = lane & 7;
-      vsrc[j] = (int64_t)row * p.ldvt + ((pos ^ L::vswz(row)) << 3);
+    {
+      const int row = wid * 8 + (lane >> 3), pos = lane & 7;
+      vsrc0 = (int64_t)row * p.ldvt + ((pos ^ L::vswz(row)) << 3);
     }
   }
   auto stage_dma = [&](int tile, int buf) {
@@ -175,14 +186,14 @@ __global__ __launch_bounds__(256, 3) void attn_kernel(AttnP p) {
       const bf16_t* Vt = reinterpret_cast<const bf16_t*>(Vb) + tile * KV;
       if (kv_nt) {  // block-uniform
 #pragma unroll
-        for (int j = 0; j < KPW; ++j) attn_glds16<2>(Kt + ksrc[j], Ks + (j * 4 + wid) * KRPI * DH);
+        for (int j = 0; j < KPW; ++j) attn_glds16<2>(Kt + (int64_t)(j * 4 * KRPI) * p.ldk + ksrc0, Ks + (j * 4 + wid) * KRPI * DH);
 #pragma unroll
-        for (int j = 0; j < VPW; ++j) attn_glds16<2>(Vt + vsrc[j], Vs + (j * 4 + wid) * 8 * KV);
+        for (int j = 0; j < VPW; ++j) attn_glds16<2>(Vt + (int64_t)(j * 32) * p.ldvt + vsrc0, Vs + (j * 4 + wid) * 8 * KV);
       } else {
 #pragma unroll
-        for (int j = 0; j < KPW; ++j) attn_glds16<0>(Kt + ksrc[j], Ks + (j * 4 + wid) * KRPI * DH);
+        for (int j = 0; j < KPW; ++j) attn_glds16<0>(Kt + (int64_t)(j * 4 * KRPI) * p.ldk + ksrc0, Ks + (j * 4 + wid) * KRPI * DH);
 #pragma unroll
-        for (int j = 0; j < VPW; ++j) attn_glds16<0>(Vt + vsrc[j], Vs + (j * 4 + wid) * 8 * KV);
+        for (int j = 0; j < VPW; ++j) attn_glds16<0>(Vt + (int64_t)(j * 32) * p.ldvt + vsrc0, Vs + (j * 4 + wid) * 8 * KV);
       }
     }
   };
@@ -208,9 +219,10 @@ __global__ __launch_bounds__(256, 3) void attn_kernel(AttnP p) {
   // One 64-key tile.  BUF (LDS ring slot) and MASKED (tile reaches past the last key) are compile-time so the
   // fragment addresses fold into immediates and the -inf masking costs nothing on full tiles (this loop is
   // instruction-issue bound: ~250 VALU + 32 MFMA per tile per wave before, 3 waves per SIMD).
-  auto tile_body = [&](int tile, auto buf_c, auto masked_c) __attribute__((always_inline)) {
+  auto tile_body = [&](int tile, auto buf_c, auto masked_c, auto active_c) __attribute__((always_inline)) {
     constexpr int BUF = decltype(buf_c)::value;
     constexpr bool MASKED = decltype(masked_c)::value;
+    constexpr bool ACTIVE = decltype(active_c)::value;
     const int kv0 = tile * KV;
     constexpr int buf = L::DMA ? BUF : 0;
     T* Ks = smem + buf * (L::KSZ + L::VSZ);
@@ -240,7 +252,7 @@ __global__ __launch_bounds__(256, 3) void attn_kernel(AttnP p) {
       __syncthreads();
     }
 
-    if (!wave_active) return;
+    if constexpr (!ACTIVE) return;
     // ---- S^T = K Q^T for 4 key tiles x QT query tiles ----
     f32x4 s[4][QT];
 #pragma unroll
@@ -259,10 +271,19 @@ __global__ __launch_bounds__(256, 3) void attn_kernel(AttnP p) {
         }
       }
     }
+    // 16-bit path: all V^T fragments of the tile are requested NOW, behind the QK^T MFMAs, so that their LDS latency passes
+    // under the softmax arithmetic (hipcc otherwise sinks each ds_read_b128 directly in front of its MFMA with an
+    // s_waitcnt lgkmcnt(0) between them: 8 exposed LDS round trips per tile and wave)
+    [[maybe_unused]] bf16x8 vfr[2][DVT];
+    auto load_vfr = [&](int c) __attribute__((always_inline)) {
+#pragma unroll
+      for (int dv = 0; dv < DVT; ++dv)
+        vfr[c][dv] = *reinterpret_cast<const bf16x8*>(&Vs[L::vidx(dv * 16 + l15, c * 32 + g * 8)]);
+    };
+    if constexpr (sizeof(T) == 2) load_vfr(0);   // the second half follows the softmax (register budget: 3 waves per SIMD)
     // ---- online softmax (log2 domain); lane owns query l15, keys kt*16 + g*4 + r ----
     // VALU diet (this loop is VALU-bound, not MFMA-bound): masking only on the last tile, the
-    // 1/sqrt(dh)*log2(e) scale folded into the exp2 argument (one fma per score), and the O rescale
-    // skipped (wave-uniform branch) unless some running max actually moved.
+    // 1/sqrt(dh)*log2(e) scale folded into the exp2 argument (one fma per score).
     if constexpr (MASKED) {
 #pragma unroll
       for (int kt = 0; kt < 4; ++kt)
@@ -281,12 +302,10 @@ __global__ __launch_bounds__(256, 3) void attn_kernel(AttnP p) {
         for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
           for (int r = 0; r < 4; ++r) mx = fmaxf(mx, s[kt][qt][r]);
-        mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        mx = attn_rowgroup_max(mx);
       }
       const float mnew = fmaxf(mrun[qt], mx * p.scale_log2e);
       const float alpha = __builtin_amdgcn_exp2f(mrun[qt] - mnew);
-      const bool moved = mnew > mrun[qt];
       mrun[qt] = mnew;
       // two scores per VALU instruction where the ISA has a packed form (v_pk_fma_f32 / v_pk_add_f32): this loop is
       // instruction-issue bound (profiles/r01_attn_ablation.txt), the exp2 itself has no packed form
@@ -308,15 +327,16 @@ __global__ __launch_bounds__(256, 3) void attn_kernel(AttnP p) {
         }
       const float ps = ps2[0] + ps2[1];
       lsum[qt] = lsum[qt] * alpha + ps;
-      if (__any(moved)) {
+      // O rescale, unconditionally: alpha is exactly 1.0f when the running max did not move.  (Skipping it under a wave-uniform
+      // branch cost more than it saved: hipcc copied all 32 accumulator registers on both paths, ~40 v_mov_b64 per tile.)
 #pragma unroll
-        for (int dv = 0; dv < DVT; ++dv)
+      for (int dv = 0; dv < DVT; ++dv)
 #pragma unroll
-          for (int r = 0; r < 4; ++r) o[qt][dv][r] *= alpha;
-      }
+        for (int r = 0; r < 4; ++r) o[qt][dv][r] *= alpha;
     }
     // ---- O^T += V^T P^T ----
     if constexpr (sizeof(T) == 2) {
+      load_vfr(1);
 #pragma unroll
       for (int c = 0; c < 2; ++c) {  // 32-key chunk: k-slot e of lane group g -> key c*32 + g*8 + e (see AttnLds::krow)
         bf16x8 pf[QT];
@@ -330,7 +350,7 @@ __global__ __launch_bounds__(256, 3) void attn_kernel(AttnP p) {
         }
 #pragma unroll
         for (int dv = 0; dv < DVT; ++dv) {
-          const bf16x8 vf = *reinterpret_cast<const bf16x8*>(&Vs[L::vidx(dv * 16 + l15, c * 32 + g * 8)]);
+          const bf16x8 vf = vfr[c][dv];
 #pragma unroll
           for (int qt = 0; qt < QT; ++qt) {
             if constexpr (!(ABL & 8)) o[qt][dv] = P::mfma(vf, pf[qt], o[qt][dv]);
@@ -354,14 +374,20 @@ __global__ __launch_bounds__(256, 3) void attn_kernel(AttnP p) {
   };
   using std::integral_constant;
   if constexpr (L::DMA) stage_dma(0, 0);
-  for (int tile = 0; tile < ntiles; tile += 2) {
-    const bool last0 = tile + 1 >= ntiles;
-    if (last0 && ntiles * KV > S_total) tile_body(tile, integral_constant<int, 0>{}, integral_constant<bool, true>{});
-    else tile_body(tile, integral_constant<int, 0>{}, integral_constant<bool, false>{});
-    if (last0) break;
-    if (tile + 2 >= ntiles && ntiles * KV > S_total) tile_body(tile + 1, integral_constant<int, 1>{}, integral_constant<bool, true>{});
-    else tile_body(tile + 1, integral_constant<int, 1>{}, integral_constant<bool, false>{});
-  }
+  // the wave_active test is hoisted out of the tile loop (two loop nests): inside it, the skipped-compute path made every
+  // accumulator a phi of "updated" and "untouched" and hipcc paid ~20 v_mov_b64 per tile for it
+  auto tile_loop = [&](auto active_c) __attribute__((always_inline)) {
+    for (int tile = 0; tile < ntiles; tile += 2) {
+      const bool last0 = tile + 1 >= ntiles;
+      if (last0 && ntiles * KV > S_total) tile_body(tile, integral_constant<int, 0>{}, integral_constant<bool, true>{}, active_c);
+      else tile_body(tile, integral_constant<int, 0>{}, integral_constant<bool, false>{}, active_c);
+      if (last0) break;
+      if (tile + 2 >= ntiles && ntiles * KV > S_total) tile_body(tile + 1, integral_constant<int, 1>{}, integral_constant<bool, true>{}, active_c);
+      else tile_body(tile + 1, integral_constant<int, 1>{}, integral_constant<bool, false>{}, active_c);
+    }
+  };
+  if (wave_active) tile_loop(integral_constant<bool, true>{});
+  else tile_loop(integral_constant<bool, false>{});
 
   // ---- normalise and store: lane owns query l15, rows dv*16 + g*4 + {0..3} ----
 #pragma unroll

@@ -51,6 +51,7 @@ enum { CHAIN_PRE = 0, CHAIN_MID = 1, CHAIN_POST = 2 };
 
 struct ChainP {
   int M, rows_per_seq, has_next, aux_kb;
+  int n_tall;             // chain_kernel_mix: number of leading workgroups that take the taller panel
   int src_rows;           // > 0: the residual rows and the attention-output panel of row m are READ at row m - src_rows when m >= src_rows
                           // (layer 0 under classifier-free guidance: both halves of the batch enter with the same x and the same
                           // self attention, so the first PRE kernel and the first self attention run on one half only)
@@ -164,8 +165,18 @@ __device__ __forceinline__ void chain_bar() { asm volatile("s_waitcnt lgkmcnt(0)
 // tile's 128 columns (half the accumulators, half the weight slice, its own DMA ring): a wave's LDS-DMA pieces and
 // fragment reads cost it 40-60 issue cycles each that its own MFMAs do not hide (measured additive),
 // so the second wave on the SIMD is what overlaps them.
-template <int D, int MT, int MODE, int ABL = 0, int NW = 4>
-__global__ __launch_bounds__(64 * NW, 1) void chain_kernel(const ChainP p) {
+// LDS footprint (bf16 elements) of one workgroup: [panelA BM x D][panelH BM x 128][LayerNorm partials][aux][weight ring]
+template <int D, int MT>
+struct ChainLds {
+  static constexpr int BM = 16 * MT, AUX_F = 2560;
+  static constexpr int FIXED = BM * D + BM * 128 + 32 * BM + 2 * AUX_F;
+  static constexpr int NS = (160 * 1024 / 2 - FIXED) / CHAIN_STAGE_ELEMS > 6 ? 6 : (160 * 1024 / 2 - FIXED) / CHAIN_STAGE_ELEMS;
+  static constexpr int ELEMS = FIXED + NS * CHAIN_STAGE_ELEMS;
+};
+
+// The chain of one row panel: rows [m0, m0 + 16*MT) of the launch, LDS at `smem` (ChainLds<D, MT>::ELEMS elements).
+template <int D, int MT, int MODE, int ABL, int NW>
+__device__ __forceinline__ void chain_body(const ChainP& p, bf16_t* const smem, const int m0) {
   constexpr int CW = 128 / NW;   // columns of a 128-column tile owned by one wave
   constexpr int NJ = CW / 16;    // 16-column sub-tiles per wave per tile
   constexpr int PCS = CW / 8;    // 1 KiB LDS-DMA pieces per wave per stage
@@ -177,11 +188,10 @@ __global__ __launch_bounds__(64 * NW, 1) void chain_kernel(const ChainP p) {
   constexpr int FT = 8;          // ff_size / 128
   constexpr int HLD = 128;       // hidden chunk row stride
   constexpr int AUX_F = 2560;    // floats of per-tile biases (10 KiB)
-  constexpr int FIXED = BM * D + BM * HLD + 32 * BM + 2 * AUX_F;  // bf16 elements before the ring
-  constexpr int NS = (160 * 1024 / 2 - FIXED) / CHAIN_STAGE_ELEMS > 6 ? 6 : (160 * 1024 / 2 - FIXED) / CHAIN_STAGE_ELEMS;
+  constexpr int NS = ChainLds<D, MT>::NS;
+  static_assert(ChainLds<D, MT>::AUX_F == AUX_F && ChainLds<D, MT>::BM == BM && HLD == 128, "ChainLds out of step");
   static_assert(NS >= 3, "panel too tall for a 3-deep weight ring");
   constexpr int WSLICE = CHAIN_STAGE_ELEMS / NW;  // elements per wave per stage
-  __shared__ __attribute__((aligned(16))) bf16_t smem[FIXED + NS * CHAIN_STAGE_ELEMS];
   bf16_t* const panelA = smem;
   bf16_t* const panelH = panelA + BM * D;
   float* const red = reinterpret_cast<float*>(panelH + BM * HLD);  // [2][8][BM]: LayerNorm partial sums per 16-column group
@@ -191,7 +201,6 @@ __global__ __launch_bounds__(64 * NW, 1) void chain_kernel(const ChainP p) {
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int l15 = lane & 15, g = lane >> 4;
   const int W4 = NW == 4 ? wid : (wid >> 1), J0 = NW == 4 ? 0 : (wid & 1);  // 32-column group and first 16-column sub-tile of this wave
-  const int m0 = blockIdx.x * BM;
   auto stamp = [&](int i) __attribute__((always_inline)) {
     if constexpr (ABL & 64) {
       if (tid == 0 && (blockIdx.x == 0 || blockIdx.x == 101))
@@ -565,12 +574,35 @@ __global__ __launch_bounds__(64 * NW, 1) void chain_kernel(const ChainP p) {
   };
   // D-deep GEMM over `ntiles` output tiles with a per-tile bf16 store: out[m][n] (row-major, 4 columns per lane) or the
   // transposed V^T layout out[seq][n][t] (operands swapped: 4 consecutive frames t per lane, one 8-byte store each)
-  auto gemm_store = [&](int ntiles, const float* bias_lds, bf16_t* out, int64_t ldo, bool transposed) __attribute__((always_inline)) {
+  // `fin`: this is the kernel's last GEMM.  Before the stores of its last tile the weight DMA is drained (the ring runs up to
+  // NS-1 stages past the end of the stream and must have landed before the LDS is released), so that the kernel can end with
+  // its final stores -- the last tile's and the residual rows' -- still in flight instead of waiting for their acknowledgement.
+  auto gemm_store = [&](int ntiles, const float* bias_lds, bf16_t* out, int64_t ldo, bool transposed, bool fin = false) __attribute__((always_inline)) {
+    // V^T through LDS (frame count a multiple of 8): the accumulators hold 4 consecutive frames of one column per lane, i.e. an
+    // 8-byte store per lane with 64 different 8-byte segments per instruction -- measured 150 issue cycles per instruction
+    // against 45-60 for 16-byte stores (scratch/issue_probe "V^T pattern": +1.6 us per tile).  Each wave therefore transposes ITS
+    // [CW columns][BM frames] block through a private slice of the (idle) hidden-chunk buffer and writes 16-byte pieces = 8
+    // consecutive frames of one column, 2*MT adjacent pieces per column.  Same bytes, a quarter of the store instructions' cost.
+    constexpr int VP = (CW * BM / 8 + 63) / 64;   // 16-byte pieces per lane
+    const bool vt_staged = transposed && (p.rows_per_seq & 7) == 0;
+    bf16_t* const stg = panelH + wid * (CW * BM);
+    int64_t voff[VP];
+    int vcol[VP];
+    if (vt_staged) {
+#pragma unroll
+      for (int i = 0; i < VP; ++i) {
+        const int q = lane + 64 * i, c = q / (BM / 8), m = m0 + (q % (BM / 8)) * 8;
+        vcol[i] = W4 * 32 + ((c & 15) >> 2) * 8 + (J0 + (c >> 4)) * 4 + (c & 3);
+        const int sq = m / p.rows_per_seq;
+        voff[i] = (q < CW * BM / 8 && m < p.M) ? (int64_t)sq * p.vt_seq_stride + (m - sq * p.rows_per_seq) : -1;
+      }
+    }
     for (int t = 0; t < ntiles; ++t) {
       f32x4 acc[MT][NJ];
       if (!transposed) init_bias(acc, bias_lds + t * 128);
       else init_bias_t(acc, bias_lds + t * 128);
       gemm_tile(acc, panelA, D, KS, transposed);
+      if (fin && t == ntiles - 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       if (!transposed) {  // 8 (4 waves) / 4 (8 waves) contiguous columns per lane: one 16- / 8-byte store per row
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
@@ -588,6 +620,27 @@ __global__ __launch_bounds__(64 * NW, 1) void chain_kernel(const ChainP p) {
           } else {
             chain_st_bf4(dst, bf16x4{(bf16_t)v[0], (bf16_t)v[1], (bf16_t)v[2], (bf16_t)v[3]});
           }
+        }
+      } else if (vt_staged) {
+        // inline-asm LDS accesses: a compiler-visible one would be ordered behind every pending LDS-DMA slice (vmcnt(0))
+#pragma unroll
+        for (int j = 0; j < NJ; ++j)
+#pragma unroll
+          for (int mt = 0; mt < MT; ++mt) {
+            const f32x4 v = acc[mt][j];
+            const bf16x4 o = {(bf16_t)v[0], (bf16_t)v[1], (bf16_t)v[2], (bf16_t)v[3]};
+            asm volatile("ds_write_b64 %0, %1" ::"v"((uint32_t)(uintptr_t)(__attribute__((address_space(3))) bf16_t*)(stg + (j * 16 + l15) * BM + mt * 16 + g * 4)), "v"(o) : "memory");
+          }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int i = 0; i < VP; ++i) {
+          bf16x8 v;
+          asm volatile("ds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"((uint32_t)(uintptr_t)(__attribute__((address_space(3))) bf16_t*)(stg + (lane + 64 * i) * 8)) : "memory");
+          if constexpr (ABL & 1) {
+            asm volatile("" ::"v"(v));
+            continue;
+          }
+          if (voff[i] >= 0) chain_st_bf8(out + voff[i] + (int64_t)(t * 128 + vcol[i]) * ldo, v);
         }
       } else {
 #pragma unroll
@@ -622,7 +675,7 @@ __global__ __launch_bounds__(64 * NW, 1) void chain_kernel(const ChainP p) {
     }
   };
   // norm1 -> rotary -> [Q|K] ; norm1 -> V^T          (aux: bias_qk at aq, bias_v right after)
-  auto pre_work = [&](const float* aq) __attribute__((always_inline)) {
+  auto pre_work = [&](const float* aq) __attribute__((always_inline)) {   // always the kernel's last GEMMs
     ln_stats();
     ln_write(p.lnB_g, p.lnB_b, std::true_type{});
     stamp(9);
@@ -630,13 +683,15 @@ __global__ __launch_bounds__(64 * NW, 1) void chain_kernel(const ChainP p) {
     chain_bar();  // every wave is done reading the rotated panel
     stamp(10);
     ln_write(p.lnB_g, p.lnB_b, std::false_type{});
-    gemm_store(NT, aq + 2 * D, p.vt_out, p.ld_vt, true);
+    gemm_store(NT, aq + 2 * D, p.vt_out, p.ld_vt, true, true);
     stamp(11);
   };
 
   // ================================================================================================
+  bool dma_drained = false;   // the path already waited for the run-ahead weight slices (gemm_store `fin`)
   if constexpr (MODE == CHAIN_PRE) {
     pre_work(aux);
+    dma_drained = true;
   } else {
     // out_proj of the attention that produced `ain`; FiLM + residual into the register rows once all tiles are done
     {
@@ -661,9 +716,12 @@ __global__ __launch_bounds__(64 * NW, 1) void chain_kernel(const ChainP p) {
     ln_stats();
     stamp(4);
     if constexpr (MODE == CHAIN_MID) {
-      store_x();
+      // the residual rows are written LAST: loads return in issue order behind stores, so the rotary-table loads of ln_write
+      // (and every weight slice after them) issued behind 96 KB of row stores waited for their write acknowledgement
       ln_write(p.lnA_g, p.lnA_b, std::true_type{});
-      gemm_store(NT, aux, p.q_out, p.ld_q, false);
+      gemm_store(NT, aux, p.q_out, p.ld_q, false, true);
+      store_x();
+      dma_drained = true;
     } else {
       ln_write(p.lnA_g, p.lnA_b, std::false_type{});
       stamp(5);
@@ -730,17 +788,38 @@ __global__ __launch_bounds__(64 * NW, 1) void chain_kernel(const ChainP p) {
           }
         }
       } else {
-        store_x();
         stamp(8);
         if (p.has_next) pre_work(aux + FT * 128);
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        store_x();   // last, see MODE_MID
+        dma_drained = true;
       }
     }
   }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the run-ahead DMA slices must land before the LDS is released
+  if (!dma_drained) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the run-ahead DMA slices must land before the LDS is released
   if (p.clk && tid == 0 && blockIdx.x < 8) {
     p.clk[blockIdx.x * 4 + 2] = __builtin_readcyclecounter();
     p.clk[blockIdx.x * 4 + 3] = wall_clock64();
   }
   stamp(12);
+}
+
+template <int D, int MT, int MODE, int ABL = 0, int NW = 4>
+__global__ __launch_bounds__(64 * NW, 1) void chain_kernel(const ChainP p) {
+  __shared__ __attribute__((aligned(16))) bf16_t smem[ChainLds<D, MT>::ELEMS];
+  chain_body<D, MT, MODE, ABL, NW>(p, smem, blockIdx.x * (16 * MT));
+}
+
+// Two panel heights in ONE launch: workgroups [0, p.n_tall) take 16*MTA rows each, the rest 16*MTB (MTA > MTB).  A forward of
+// more rows than 256 x 16*MTB runs in rounds over the 256 CUs (one workgroup per CU: the LDS) and the last round is mostly
+// empty -- B=32, d=512: 800 panels of 48 rows = 3.125 rounds, i.e. FOUR rounds with 224 CUs idle in the last one.  With 96
+// panels of 64 rows dispatched first and 672 of 48 rows behind them every CU gets exactly three panels (160 or 144 rows).
+// Every row's result is independent of the panel height (tests/test_hip_round2.py), so the mix is invisible in the output.
+template <int D, int MTA, int MTB, int MODE, int NW>
+__global__ __launch_bounds__(64 * NW, 1) void chain_kernel_mix(const ChainP p) {
+  __shared__ __attribute__((aligned(16))) bf16_t smem[ChainLds<D, MTB>::ELEMS > ChainLds<D, MTA>::ELEMS ? ChainLds<D, MTB>::ELEMS : ChainLds<D, MTA>::ELEMS];
+  const int b = blockIdx.x;   // wave-uniform
+  if (b < p.n_tall) chain_body<D, MTA, MODE, 0, NW>(p, smem, b * (16 * MTA));
+  else chain_body<D, MTB, MODE, 0, NW>(p, smem, p.n_tall * (16 * MTA) + (b - p.n_tall) * (16 * MTB));
 }
 #pragma clang fp contract(fast)

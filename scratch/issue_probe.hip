@@ -12,11 +12,13 @@ typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
 
-enum { M_MFMA = 1, M_DMA = 2, M_GLOAD = 4, M_DSREAD = 8 };
+enum { M_MFMA = 1, M_DMA = 2, M_GLOAD = 4, M_DSREAD = 8, M_STORE = 16, M_STORE_BULK = 32, M_STORE_NT = 64, M_KMAJOR = 128 };
+// M_KMAJOR: the A fragments are read once per k-step for a group of 4 output tiles (every 4th stage), the W fragments every stage
+// M_STORE: 3 x 1 KiB global stores per wave every 8 stages (one output tile of gemm_store); M_STORE_BULK: 12 stores every 32 stages
 constexpr int STAGES = 256;
 
-template <int MODE, int NW>
-__global__ __launch_bounds__(64 * NW, 1) void probe(const char* __restrict__ src, unsigned long long* out, float* sink) {
+template <int MODE, int NW, int PAT = 0>
+__global__ __launch_bounds__(64 * NW, 1) void probe(const char* __restrict__ src, unsigned long long* out, float* sink, char* stbuf) {
   constexpr int PCS = 16 / NW;            // 1 KiB pieces per wave per 16 KiB stage (4 waves: 4, 8 waves: 2)
   constexpr int NMFMA = 48 / NW;          // MT = 3: 48 MFMA 16x16x32 per stage per workgroup
   constexpr int NDS = NW == 4 ? 5 : 4;    // fragment reads per k-chunk: MT A + NJ W
@@ -65,7 +67,40 @@ __global__ __launch_bounds__(64 * NW, 1) void probe(const char* __restrict__ src
       _Pragma("unroll") for (int i = 0; i < PCS; ++i)
         asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(g[i]) : "v"(gp + i * 1024));
     }
-    if constexpr (MODE & M_DSREAD) {
+    if constexpr (MODE & (M_STORE | M_STORE_BULK)) {
+      constexpr int EVERY = (MODE & M_STORE_BULK) ? 32 : 8, NST = (MODE & M_STORE_BULK) ? 12 : 3;
+      if (s % EVERY == EVERY - 1) {
+        // each wave owns a [48 rows x 2 KiB pitch] window per tile; PAT selects which bytes of it one instruction writes
+        char* base = stbuf + ((size_t)blockIdx.x * NW + wid) * (size_t)(STAGES / 8) * (48 * 2048) + (size_t)(s / 8) * (48 * 2048);
+        const int l15 = lane & 15, g = lane >> 4;
+        _Pragma("unroll") for (int i = 0; i < NST; ++i) {
+          if constexpr (PAT == 0) {        // fully coalesced: 1 KiB contiguous per instruction
+            *reinterpret_cast<f32x4*>(base + i * 1024 + lane * 16) = acc[i % 6];
+          } else if constexpr (PAT == 1) { // the QK store today: 16 rows x 64 B (row pitch 2 KiB), lanes of one row 16 apart
+            *reinterpret_cast<f32x4*>(base + (size_t)(i * 16 + l15) * 2048 + g * 16) = acc[i % 6];
+          } else if constexpr (PAT == 2) { // the V^T store today: 8 B per lane, 16 columns x 32 B (pitch 1280 B), twice as many instructions
+            typedef __attribute__((ext_vector_type(2))) float f32x2;
+            *reinterpret_cast<f32x2*>(base + (size_t)(i * 32 + l15) * 1280 + g * 8) = f32x2{acc[i % 6][0], acc[i % 6][1]};
+            *reinterpret_cast<f32x2*>(base + (size_t)(i * 32 + 16 + l15) * 1280 + g * 8) = f32x2{acc[i % 6][2], acc[i % 6][3]};
+          } else if constexpr (PAT == 3) { // 4 rows x 256 B per instruction, adjacent lanes contiguous
+            *reinterpret_cast<f32x4*>(base + (size_t)(i * 4 + g) * 2048 + l15 * 16) = acc[i % 6];
+          } else if constexpr (PAT == 4) { // 16 rows x 64 B, but the 4 lanes of a row ADJACENT
+            *reinterpret_cast<f32x4*>(base + (size_t)(i * 16 + (lane >> 2)) * 2048 + (lane & 3) * 16) = acc[i % 6];
+          }
+        }
+      }
+    }
+    if constexpr ((MODE & M_DSREAD) && (MODE & M_KMAJOR)) {
+      constexpr int NWR = NW == 4 ? 4 : 2;   // W fragment reads per stage: 2 k-chunks x NJ
+      _Pragma("unroll") for (int i = 0; i < NWR; ++i)
+        nw[i] = *reinterpret_cast<const bf16x8*>(slot + ((lane * 16 + i * 512) & (PCS * 1024 - 1)));
+      if ((s & 3) == 3) {                    // next stage starts a new k-step: 2 k-chunks x MT A fragments
+        _Pragma("unroll") for (int i = 0; i < 5; ++i)
+          na[i] = *reinterpret_cast<const bf16x8*>(lds + FR + ((lane * 16 + i * 1024 + s * 64) & (32 * 1024 - 1)));
+        asm volatile("" : "+v"(nw[4]));
+        nw[4] = *reinterpret_cast<const bf16x8*>(lds + FR + ((lane * 16 + 5 * 1024 + s * 64) & (32 * 1024 - 1)));
+      }
+    } else if constexpr (MODE & M_DSREAD) {
       _Pragma("unroll") for (int i = 0; i < NDS; ++i) {   // 2 k-chunks x NDS reads: conflict-free lane-linear 16 B reads
         na[i] = *reinterpret_cast<const bf16x8*>(lds + FR + ((lane * 16 + i * 1024 + s * 64) & (32 * 1024 - 1)));
         nw[i] = *reinterpret_cast<const bf16x8*>(slot + ((lane * 16 + i * 512) & (PCS * 1024 - 1)));
@@ -84,7 +119,7 @@ __global__ __launch_bounds__(64 * NW, 1) void probe(const char* __restrict__ src
           __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
         }
       }
-      if constexpr (MODE & M_DSREAD) {
+      if constexpr ((MODE & M_DSREAD) && !(MODE & M_KMAJOR)) {
         _Pragma("unroll") for (int i = 0; i < 2 * NDS; ++i) {
           __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
           __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
@@ -113,10 +148,11 @@ __global__ __launch_bounds__(64 * NW, 1) void probe(const char* __restrict__ src
   }
 }
 
-template <int MODE, int NW>
-void run(const char* name, const char* src, unsigned long long* dout, float* sink, int blocks) {
+static char* g_stbuf = nullptr;
+template <int MODE, int NW, int PAT = 0>
+void run(const char* name, const char* src, unsigned long long* dout, float* sink, int blocks, char* stbuf = nullptr) {
   std::vector<unsigned long long> h((size_t)blocks * NW * 2);
-  for (int it = 0; it < 3; ++it) probe<MODE, NW><<<blocks, 64 * NW>>>(src, dout, sink);
+  for (int it = 0; it < 3; ++it) probe<MODE, NW, PAT><<<blocks, 64 * NW>>>(src, dout, sink, g_stbuf);
   CK(hipDeviceSynchronize());
   CK(hipMemcpy(h.data(), dout, h.size() * 8, hipMemcpyDeviceToHost));
   double cyc = 0, rt = 0;
@@ -138,12 +174,22 @@ void all(const char* src, unsigned long long* dout, float* sink, int blocks) {
   run<M_MFMA | M_DMA | M_DSREAD, NW>("mfma + dma + ds_read (the kernel)", src, dout, sink, blocks);
   run<M_MFMA | M_GLOAD | M_DSREAD, NW>("mfma + gload + ds_read", src, dout, sink, blocks);
   run<M_DMA | M_DSREAD, NW>("dma + ds_read", src, dout, sink, blocks);
+  run<M_MFMA | M_DMA | M_DSREAD | M_KMAJOR, NW>("kernel, A frags once per 4 tiles", src, dout, sink, blocks);
+  run<M_MFMA | M_DSREAD | M_KMAJOR, NW>("mfma + ds_read, A once per 4", src, dout, sink, blocks);
+  run<M_MFMA | M_DMA | M_DSREAD | M_STORE, NW, 0>("kernel + store/8 coalesced", src, dout, sink, blocks);
+  run<M_MFMA | M_DMA | M_DSREAD | M_STORE, NW, 1>("kernel + store/8 QK pattern", src, dout, sink, blocks);
+  run<M_MFMA | M_DMA | M_DSREAD | M_STORE, NW, 2>("kernel + store/8 V^T pattern", src, dout, sink, blocks);
+  run<M_MFMA | M_DMA | M_DSREAD | M_STORE, NW, 3>("kernel + store/8 4 rows x 256 B", src, dout, sink, blocks);
+  run<M_MFMA | M_DMA | M_DSREAD | M_STORE, NW, 4>("kernel + store/8 16 x 64 B adj", src, dout, sink, blocks);
+  run<M_DMA | M_STORE, NW, 0>("dma + store/8 coalesced", src, dout, sink, blocks);
+  run<M_DMA | M_STORE, NW, 1>("dma + store/8 QK pattern", src, dout, sink, blocks);
+  run<M_DMA | M_STORE, NW, 2>("dma + store/8 V^T pattern", src, dout, sink, blocks);
 }
 
 int main() {
   char* src; unsigned long long* dout; float* sink;
   CK(hipMalloc(&src, (size_t)4 << 20)); CK(hipMemset(src, 1, (size_t)4 << 20));
-  CK(hipMalloc(&dout, 256 * 8 * 2 * 8)); CK(hipMalloc(&sink, 64));
+  CK(hipMalloc(&dout, 256 * 8 * 2 * 8)); CK(hipMalloc(&sink, 64)); CK(hipMalloc(&g_stbuf, (size_t)200 * 8 * (STAGES / 8) * (48 * 2048) + (1 << 20)));
   for (int blocks : {1, 200}) {
     printf("blocks=%d (1 = one CU alone, 200 = the B=8 grid)\n", blocks);
     all<4>(src, dout, sink, blocks);

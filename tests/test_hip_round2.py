@@ -218,3 +218,30 @@ def test_layer0_shared_half_is_bit_identical_to_the_duplicated_path(dev, fmt, B,
         outs[nw] = shared
     assert torch.equal(outs["4"], outs["8"])
     model.release()
+
+
+# ----------------------------------------------------------------------------- two panel heights in one chain launch
+@pytest.mark.parametrize("B,T", [(11, 600), (32, 600), (13, 592)])
+def test_mixed_panel_heights_are_bit_identical_to_the_uniform_launch(dev, B, T, monkeypatch):
+    """Forwards of more than 256 48-row panels (face, d=512) launch the chain kernels with 64-row panels for the first workgroups
+    so that the grid fills whole rounds of the 256 CUs (csrc/kernels_chain.h `chain_kernel_mix`, a2p_lib_run.h `launch_chain`).
+    Same bits as the uniform 48-row launch for both workgroup shapes, ragged tails included."""
+    spec, sd, model, _ = build("face", "bf16", dev, max_batch=B)
+    cfg = ClassifierFreeSampleModel(model)
+    inp = synthetic_inputs(spec, B, T, SEED)
+    y = {"cond_embed": inp["cond_embed"].to(dev), "scale": torch.full((B,), 10.0, device=dev)}
+    x = inp["x_T"].to(dev)
+    t = torch.tensor(([901, 417, 33, 0] * 8)[:B], device=dev)
+    assert 2 * B * T > 256 * 48 and (2 * B * T + 47) // 48 % 256 != 0, "shape does not reach the mixed launch"
+    outs = {}
+    for nw in ("4", "8"):
+        monkeypatch.setenv("A2P_CHAIN_NW", nw)
+        monkeypatch.delenv("A2P_CHAIN_NO_MIX", raising=False)
+        mixed = cfg(x, t, y).clone()
+        monkeypatch.setenv("A2P_CHAIN_NO_MIX", "1")
+        uniform = cfg(x, t, y).clone()
+        assert torch.isfinite(mixed).all()
+        assert torch.equal(mixed, uniform), f"NW={nw}: max |diff| = {float((mixed - uniform).abs().max()):.3e}"
+        outs[nw] = mixed
+    assert torch.equal(outs["4"], outs["8"])
+    model.release()
