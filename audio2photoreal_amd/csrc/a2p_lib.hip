@@ -137,7 +137,8 @@ struct a2p_ctx {
   std::map<std::string, Buf> w;   // fp32 parameters by reference state_dict key
   std::map<std::string, Buf> wt;  // compute-dtype copies [N, Kpad]
   bool finalized = false, prepared = false;
-  Buf rope_cs, time_freq, film_w, film_b, tct_w, tct_b;
+  int rope_npos = 0;
+  Buf rope_cs, rope_cst, time_freq, film_w, film_b, tct_w, tct_b;
   Buf cak_w32, cak_b, cav_w32, cav_b, cak_wt, cav_wt;
   Buf ca2k_wt, ca2v_wt, ca2k_b, ca2v_b;
   Buf conv_wt[7];
@@ -461,7 +462,7 @@ extern "C" int a2p_ctx_destroy(a2p_ctx* c) {
   hipDeviceSynchronize();
   for (auto& kv : c->w) buf_free(kv.second);
   for (auto& kv : c->wt) buf_free(kv.second);
-  Buf* all[] = {&c->rope_cs, &c->time_freq, &c->film_w, &c->film_b, &c->tct_w, &c->tct_b, &c->cak_w32, &c->cak_b, &c->cav_w32,
+  Buf* all[] = {&c->rope_cs, &c->rope_cst, &c->time_freq, &c->film_w, &c->film_b, &c->tct_w, &c->tct_b, &c->cak_w32, &c->cak_b, &c->cav_w32,
                 &c->cav_b, &c->cak_wt, &c->cav_wt, &c->ca2k_wt, &c->ca2v_wt, &c->ca2k_b, &c->ca2v_b, &c->hidden, &c->kc, &c->vtc,
                 &c->k2c, &c->vt2c, &c->slot_cond, &c->slot_unc, &c->slot_cfg, &c->x, &c->xn, &c->xr, &c->qk, &c->vt, &c->ao,
                 &c->hff, &c->inpack, &c->mo, &c->cb[0], &c->cb[1], &c->cb[2], &c->cb[3], &c->emb, &c->th, &c->tct, &c->tvec,
@@ -555,6 +556,9 @@ extern "C" int a2p_finalize_weights(a2p_ctx* c, void* stream) {
     const int npos = c->Sld > c->Tld ? c->Sld : c->Tld;
     CHK(buf_alloc(c->rope_cs, (size_t)npos * (d / 2) * 8));
     rope_table_kernel<<<(npos * (d / 2) + 255) / 256, 256, 0, s>>>(tmp.f(), (float2*)c->rope_cs.p, npos, d / 2);
+    CHK(buf_alloc(c->rope_cst, (size_t)npos * (d / 2) * 8));   // chain-kernel layout [d/4][npos] x 16 bytes
+    rope_table_t_kernel<<<(npos * (d / 4) + 255) / 256, 256, 0, s>>>((const float2*)c->rope_cs.p, (float4*)c->rope_cst.p, npos, d / 2);
+    c->rope_npos = npos;
     HIPCHK(hipStreamSynchronize(s));
     buf_free(tmp);
     // SinusoidalPosEmb frequencies (model/utils.py:73-75): exp(arange(half) * -(ln 1e4 / (half-1))), fp32

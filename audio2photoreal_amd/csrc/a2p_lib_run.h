@@ -184,7 +184,7 @@ static int chain_build_streams(a2p_ctx* c, hipStream_t s) {
 
 static void chain_base(a2p_ctx* c, ChainP& p, int N, int T, int idx, int aux_floats) {
   memset(&p, 0, sizeof(p));
-  p.M = N * T; p.rows_per_seq = T; p.x = c->x.f(); p.cs = reinterpret_cast<const float2*>(c->rope_cs.p);
+  p.M = N * T; p.rows_per_seq = T; p.x = c->x.f(); p.cst = reinterpret_cast<const f32x4*>(c->rope_cst.p); p.cs_npos = c->rope_npos;
   p.ain = reinterpret_cast<const bf16_t*>(c->ao.p); p.ld_ain = c->d;
   p.stream = reinterpret_cast<const bf16_t*>(c->ch_stream[(size_t)(c->ch_nw == 8) * c->L * 4 + idx].p);
   p.aux = c->ch_aux[idx].f(); p.aux_kb = (aux_floats + 255) / 256;
@@ -377,6 +377,7 @@ static int decoder_layer_chain(a2p_ctx* c, int l, int N, int T, const CrossKV& k
   const int join_at = jp ? atoi(jp) : 3;
   if (film_ready && join_at <= 1) HIPCHK(hipStreamWaitEvent(s, film_ready, 0));
   const int Nsa = shared_half ? N / 2 : N;
+  const bool tiled = !getenv("A2P_CHAIN_X_ROWMAJOR");   // A/B switch: keep the residual stream row-major between chain kernels
   // shared_half: the input projection wrote the (N/2)*T rows both halves start from into c->hff (unused by the chain path, fp32
   // here); PRE reads them there, MID reads them there for BOTH halves and writes all N*T rows of c->x -- never in place: a
   // second-half workgroup may start after the first-half workgroup of the same source rows has stored its result
@@ -399,6 +400,10 @@ static int decoder_layer_chain(a2p_ctx* c, int l, int N, int T, const CrossKV& k
       p.src_rows = (N / 2) * T;
       p.xsrc = x0;
     }
+    // residual layout (ChainP::x_in_tiled): row-major as the input projection (or the caller) left it for the first kernel that
+    // touches the rows, tiled between chain kernels
+    p.x_in_tiled = !(first && kind == CH_MID) && tiled;
+    p.x_out_tiled = tiled;
     return launch_chain(c, CHAIN_MID, p, s);
   };
   CHK(mid(CH_MID, "self_attn", 0, "norm2"));
@@ -413,6 +418,8 @@ static int decoder_layer_chain(a2p_ctx* c, int l, int N, int T, const CrossKV& k
   p.bias_2 = W32(c, pf + "linear2.bias");
   if (fr.base) p.film_f = fr.base + (int64_t)2 * 2 * d;
   p.has_next = has_next ? 1 : 0;
+  p.x_in_tiled = tiled;
+  p.x_out_tiled = tiled && has_next;   // the last layer's rows go back to the caller / the pose tail row-major
   if (has_next) chain_set_pre(c, p, l + 1, T);
   if (!has_next && fuse_final) {  // model output rows straight from the last POST kernel (c->x is NOT updated)
     p.has_next = 2; p.fin_out = c->mo.f(); p.ld_fin = c->C; p.fin_n = c->C;

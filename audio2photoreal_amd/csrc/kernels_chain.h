@@ -58,6 +58,12 @@ struct ChainP {
   const float* xsrc;      // residual rows are read from here instead of x when non-null: with src_rows the read rows of one
                           // workgroup are the WRITTEN rows of another, so the source must be a buffer this launch does not write
   float* x;               // fp32 residual stream [M][D], updated in place
+  // Layout of the residual rows between chain kernels (x_in_tiled: as read, x_out_tiled: as written): per block of 16 rows the
+  // D/16 "chunks" (tile t, 32-column group W4, 4-column half jj) of 1 KiB each, chunk = [g = 0..3][row & 15][4 floats] -- i.e.
+  // exactly one load / store instruction of a wave (lane = g*16 + row): 1 KiB contiguous instead of 64 16-byte segments 2 KiB
+  // apart.  A 16-row block occupies the same bytes in both layouts and a workgroup owns whole blocks, so the buffer can change
+  // layout in place; the first kernel of a forward reads row-major (input projection), the last one writes row-major.
+  int x_in_tiled, x_out_tiled;
   const bf16_t* stream;   // packed weight stream of this chain
   const float* aux;       // per-tile biases of this chain, aux_kb KiB: POST [bias_1 | bias_qk' | bias_v'], MID [bias_q], PRE [bias_qk | bias_v]
   // MID / POST: attention output panel
@@ -84,7 +90,8 @@ struct ChainP {
   int64_t ld_qk;
   bf16_t* vt_out;
   int64_t vt_seq_stride, ld_vt;
-  const float2* cs;  // rotary table [pos][D/2]
+  const f32x4* cst;  // rotary table in the panel layout [D/4][cs_npos]: (cos, sin) x 2 of 4 consecutive columns (rope_table_t_kernel)
+  int cs_npos;
   // has_next == 2 (last decoder layer): final_layer (model/diffusion.py:397) instead of the next layer's PRE work;
   // fp32 rows out[m][0..fin_n), bias in aux after bias_1; the residual stream itself is not written back
   float* fin_out;
@@ -364,6 +371,10 @@ __device__ __forceinline__ void chain_body(const ChainP& p, bf16_t* const smem, 
   // the two halves of a lane are adjacent (col_of(t, 1) == col_of(t, 0) + 4)
   auto col_of = [&](int t, int j) __attribute__((always_inline)) { return t * 128 + W4 * 32 + g * 8 + (J0 + j) * 4; };
 
+  // float offset of this lane's 4 columns of sub-tile (t, j) of row m in the tiled residual layout (ChainP::x_in_tiled)
+  auto x_tiled_off = [&](int m, int t, int j) __attribute__((always_inline)) {
+    return ((int64_t)(m >> 4) * (D / 16) + (t * 8 + W4 * 2 + J0 + j)) * 256 + (g * 16 + (m & 15)) * 4;
+  };
   // ---- kernel start: panel + aux DMA, residual rows, stream prefetch ----------------------------------------
   f32x4 xrow[MT][NSUB];
   int row_m[MT], row_seq[MT];
@@ -391,7 +402,7 @@ __device__ __forceinline__ void chain_body(const ChainP& p, bf16_t* const smem, 
 #pragma unroll
     for (int ns = 0; ns < NSUB; ++ns) {
       const int ms = (p.src_rows > 0 && row_m[mt] >= p.src_rows) ? row_m[mt] - p.src_rows : row_m[mt];
-      xrow[mt][ns] = chain_ld4((p.xsrc ? p.xsrc : p.x) + (int64_t)ms * D + col_of(ns / NJ, ns % NJ));
+      xrow[mt][ns] = chain_ld4((p.xsrc ? p.xsrc : p.x) + (p.x_in_tiled ? x_tiled_off(ms, ns / NJ, ns % NJ) : (int64_t)ms * D + col_of(ns / NJ, ns % NJ)));
     }
 #pragma unroll
   for (int i = 0; i < NS - 1; ++i) issue_stage();
@@ -518,7 +529,7 @@ __device__ __forceinline__ void chain_body(const ChainP& p, bf16_t* const smem, 
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
           const int pos = row_m[mt] - row_seq[mt] * p.rows_per_seq;
-          cs[mt][ns] = *reinterpret_cast<const f32x4*>(p.cs + (int64_t)pos * (D / 2) + (n >> 1));  // (cos,sin) x 2
+          cs[mt][ns] = p.cst[(int64_t)(n >> 2) * p.cs_npos + pos];  // (cos,sin) x 2; the 16 rows of a lane group are 256 contiguous bytes
         }
       }
     }
@@ -569,7 +580,7 @@ __device__ __forceinline__ void chain_body(const ChainP& p, bf16_t* const smem, 
       if (m0 + mt * 16 + l15 >= p.M) continue;
 #pragma unroll
       for (int ns = 0; ns < NSUB; ++ns)
-        chain_st4(p.x + (int64_t)row_m[mt] * D + col_of(ns / NJ, ns % NJ), xrow[mt][ns]);
+        chain_st4(p.x + (p.x_out_tiled ? x_tiled_off(row_m[mt], ns / NJ, ns % NJ) : (int64_t)row_m[mt] * D + col_of(ns / NJ, ns % NJ)), xrow[mt][ns]);
     }
   };
   // D-deep GEMM over `ntiles` output tiles with a per-tile bf16 store: out[m][n] (row-major, 4 columns per lane) or the

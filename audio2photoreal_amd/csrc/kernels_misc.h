@@ -15,6 +15,17 @@ __global__ void rope_table_kernel(const float* __restrict__ freqs, float2* __res
   cs[i] = make_float2(cosf(ang), sinf(ang));
 }
 
+// The same table for the chain kernels, which read it one row-panel at a time: [d/4][npos] entries of 16 bytes = (cos, sin) of
+// the two pairs of 4 consecutive columns, positions contiguous.  A chain lane owns (row = lane & 15, 4 columns), so one load
+// instruction then touches 4 x 256 contiguous bytes instead of 64 separate 16-byte segments of the [pos][d/2] layout.
+__global__ void rope_table_t_kernel(const float2* __restrict__ cs, float4* __restrict__ cst, int npos, int half) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= npos * (half / 2)) return;
+  const int q = i / npos, pos = i - q * npos;
+  const float2 a = cs[(size_t)pos * half + 2 * q], b = cs[(size_t)pos * half + 2 * q + 1];
+  cst[i] = make_float4(a.x, a.y, b.x, b.y);
+}
+
 // ---------------------------------------------------------------------------------------------
 // LayerNorm (eps 1e-5, biased variance) over d = 64*NPL, optionally followed by the full-width
 // interleaved-pair rotation (rotary_embedding_torch.py:46-66).  One wave per row, fp32 statistics.

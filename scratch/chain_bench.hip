@@ -89,7 +89,7 @@ int main(int argc, char** argv) {
     p.M = M; p.rows_per_seq = 600; p.aux_kb = 10; p.x = x; p.stream = stream; p.aux = aux; p.ain = ain; p.ld_ain = D;
     p.bias_o = vec; p.film_o = film; p.film_seq_stride = 4 * D; p.film_shift_off = D; p.lnA_g = vec + 512; p.lnA_b = vec + 1024;
     p.q_out = qk; p.ld_q = D; p.bias_2 = vec + 1536; p.film_f = film + 2 * D; p.lnB_g = vec + 2048; p.lnB_b = vec + 2560;
-    p.qk_out = qk; p.ld_qk = 2 * D; p.vt_out = vt; p.vt_seq_stride = (int64_t)D * 640; p.ld_vt = 640; p.cs = cs;
+    p.qk_out = qk; p.ld_qk = 2 * D; p.vt_out = vt; p.vt_seq_stride = (int64_t)D * 640; p.ld_vt = 640; p.cst = reinterpret_cast<const f32x4*>(cs); p.cs_npos = 640;
     CK(hipMalloc(&g_tbuf, (size_t)512 << 20)); CK(hipMalloc(&g_tout, 64)); CK(hipMemset(g_tbuf, 1, (size_t)512 << 20));
     for (int th : {1, 0}) {
       g_cycle = 16; g_thrash = th;

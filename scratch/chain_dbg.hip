@@ -59,7 +59,7 @@ int main() {
   p.M = M; p.rows_per_seq = T; p.aux_kb = 4; p.x = x; p.aux = aux; p.ain = ain; p.ld_ain = D; p.has_next = 0;
   p.bias_o = vec; p.film_o = film; p.film_seq_stride = 4 * D; p.film_shift_off = D; p.lnA_g = vec + 512; p.lnA_b = vec + 1024;
   p.q_out = qk; p.ld_q = D; p.bias_2 = vec + 1536; p.film_f = film + 2 * D; p.lnB_g = vec + 2048; p.lnB_b = vec + 2560;
-  p.qk_out = qk; p.ld_qk = 2 * D; p.vt_out = vt; p.vt_seq_stride = (int64_t)D * 448; p.ld_vt = 448; p.cs = cs;
+  p.qk_out = qk; p.ld_qk = 2 * D; p.vt_out = vt; p.vt_seq_stride = (int64_t)D * 448; p.ld_vt = 448; p.cst = reinterpret_cast<const f32x4*>(cs); p.cs_npos = 448;
   const size_t xb = hx.size() * 4;
   for (int rep = 0; rep < 3; ++rep) {
     printf("rep %d\n", rep);
