@@ -282,7 +282,9 @@ static int launch_chain(a2p_ctx* c, int mode, const ChainP& p, hipStream_t s) {
   // d = 512, more than one round of 48-row panels with a mostly empty last round: 64-row panels for the first n_tall
   // workgroups so that the forward fits one round less (chain_kernel_mix; B=32: 96 x 64 + 672 x 48 rows = 3 full rounds
   // instead of 3.125 -> 4).  A2P_CHAIN_NO_MIX=1 keeps the uniform launch for A/B runs.
-  if (c->d == 512 && mt == 3 && !env_mt && grid > 256 && grid % 256 != 0 && !getenv("A2P_CHAIN_NO_MIX")) {
+  // Only for the 8-wave shape: 64-row panels of 512-register waves live half in AGPRs and run 1.6-1.9x the 48-row time
+  // (scratch/chain_bench, POST: 143 vs 89 us), with 8 waves 1.26-1.37x (102 vs 75 us) for 1.33x the rows.
+  if (w8 && c->d == 512 && mt == 3 && !env_mt && grid > 256 && grid % 256 != 0 && !getenv("A2P_CHAIN_NO_MIX")) {
     const int W = 256 * ((grid + 255) / 256 - 1);
     const int n_tall = (p.M - 48 * W + 15) / 16;
     if (n_tall > 0 && n_tall <= W) {
@@ -294,8 +296,7 @@ static int launch_chain(a2p_ctx* c, int mode, const ChainP& p, hipStream_t s) {
     else if (mode == CHAIN_MID) A2P_LAUNCH(kt, (chain_kernel_mix<512, 4, 3, CHAIN_MID, NW>), W, 64 * NW, s, q);         \
     else A2P_LAUNCH(kt, (chain_kernel_mix<512, 4, 3, CHAIN_POST, NW>), W, 64 * NW, s, q);                               \
   } while (0)
-      if (w8) A2P_CHAIN_MIX(8);
-      else A2P_CHAIN_MIX(4);
+      A2P_CHAIN_MIX(8);
 #undef A2P_CHAIN_MIX
       HIPCHK(hipGetLastError());
       return 0;

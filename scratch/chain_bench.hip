@@ -96,6 +96,7 @@ int main(int argc, char** argv) {
       printf("M=%d weight streams cycled=16, MALL/L2 thrash between launches=%d\n", M, th);
       all<3, 4>(p);
       all<3, 8>(p);
+      if (getenv("CB_MT4")) { all<4, 4>(p); all<4, 8>(p); }
 
     }
   }

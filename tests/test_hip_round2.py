@@ -234,7 +234,7 @@ def test_mixed_panel_heights_are_bit_identical_to_the_uniform_launch(dev, B, T, 
     t = torch.tensor(([901, 417, 33, 0] * 8)[:B], device=dev)
     assert 2 * B * T > 256 * 48 and (2 * B * T + 47) // 48 % 256 != 0, "shape does not reach the mixed launch"
     outs = {}
-    for nw in ("4", "8"):
+    for nw in ("4", "8"):   # the mixed launch exists for the 8-wave shape; the 4-wave runs are the uniform reference
         monkeypatch.setenv("A2P_CHAIN_NW", nw)
         monkeypatch.delenv("A2P_CHAIN_NO_MIX", raising=False)
         mixed = cfg(x, t, y).clone()
