@@ -106,9 +106,11 @@ enum { CH_PRE = 0, CH_MID = 1, CH_MID2 = 2, CH_POST = 3 };
 static int ch_index(int layer, int kind) { return layer * 4 + kind; }
 
 // stages of one GEMM: 128-row tiles of W[nrows, ldw] (tile-major), K/64 k-steps each
-static void pk_gemm(std::vector<ChainPackDesc>& v, const void* W, int ldw, int nrows, int K) {
+// omap: the GEMM's tiles are stored straight to HBM by chain_body::gemm_store (Q|K, V, Q projections): paired column map for
+// the 8-wave slices (chain_pack_kernel)
+static void pk_gemm(std::vector<ChainPackDesc>& v, const void* W, int ldw, int nrows, int K, int omap = 0) {
   for (int t = 0; t < (nrows + 127) / 128; ++t)
-    for (int ks = 0; ks < K / 64; ++ks) v.push_back({reinterpret_cast<const bf16_t*>(W), ldw, t * 128, ks * 64, nrows});
+    for (int ks = 0; ks < K / 64; ++ks) v.push_back({reinterpret_cast<const bf16_t*>(W), ldw, t * 128, ks * 64, nrows, omap});
 }
 
 static int chain_pack(a2p_ctx* c, int idx, const std::vector<ChainPackDesc>& descs, const std::vector<std::pair<const float*, int>>& aux,
@@ -145,8 +147,8 @@ static int chain_build_streams(a2p_ctx* c, hipStream_t s) {
   auto pf = [&](int l) { return "seqTransDecoder.stack." + std::to_string(l) + "."; };
   auto add_pre = [&](std::vector<ChainPackDesc>& v, int l) {  // [Q|K] then V of layer l's self attention
     const Buf& inw = c->wt.at(pf(l) + "self_attn.in_proj_weight");
-    pk_gemm(v, inw.p, d, 2 * d, d);
-    pk_gemm(v, c->offT(inw, (int64_t)2 * d * d), d, d, d);
+    pk_gemm(v, inw.p, d, 2 * d, d, 1);
+    pk_gemm(v, c->offT(inw, (int64_t)2 * d * d), d, d, d, 1);
   };
   for (int l = 0; l < L; ++l) {
     std::vector<ChainPackDesc> v;
@@ -155,7 +157,7 @@ static int chain_build_streams(a2p_ctx* c, hipStream_t s) {
     auto mid = [&](int kind, const std::string& done, const std::string& next) -> int {
       std::vector<ChainPackDesc> m;
       pk_gemm(m, c->wt.at(pf(l) + done + ".out_proj.weight").p, d, d, d);
-      pk_gemm(m, c->wt.at(pf(l) + next + ".in_proj_weight").p, d, d, d);  // rows [0, d): the query projection
+      pk_gemm(m, c->wt.at(pf(l) + next + ".in_proj_weight").p, d, d, d, 1);  // rows [0, d): the query projection
       return chain_pack(c, ch_index(l, kind), m, {{W32(c, pf(l) + next + ".in_proj_bias"), d}}, s);
     };
     CHK(mid(CH_MID, "self_attn", "multihead_attn"));
@@ -165,9 +167,9 @@ static int chain_build_streams(a2p_ctx* c, hipStream_t s) {
     const Buf& w1 = c->wt.at(pf(l) + "linear1.weight");
     const Buf& w2 = c->wt.at(pf(l) + "linear2.weight");
     for (int h = 0; h < ff / 128; ++h) {
-      for (int ks = 0; ks < d / 64; ++ks) q.push_back({reinterpret_cast<const bf16_t*>(w1.p), d, h * 128, ks * 64, ff});
+      for (int ks = 0; ks < d / 64; ++ks) q.push_back({reinterpret_cast<const bf16_t*>(w1.p), d, h * 128, ks * 64, ff, 0});
       for (int t = 0; t < d / 128; ++t)
-        for (int ks = 0; ks < 2; ++ks) q.push_back({reinterpret_cast<const bf16_t*>(w2.p), ff, t * 128, h * 128 + ks * 64, d});
+        for (int ks = 0; ks < 2; ++ks) q.push_back({reinterpret_cast<const bf16_t*>(w2.p), ff, t * 128, h * 128 + ks * 64, d, 0});
     }
     std::vector<std::pair<const float*, int>> aux = {{W32(c, pf(l) + "linear1.bias"), ff}};
     if (l + 1 < L) {

@@ -106,6 +106,8 @@ struct ChainP {
 struct ChainPackDesc {
   const bf16_t* W;
   int ldw, row0, k0, nrows;  // rows >= nrows are zero-filled
+  int omap;                  // 1: stage of a GEMM whose output tiles go straight to HBM (chain_body::gemm_store): the 8-wave slices use
+                             // the PAIRED column map below (the 4-wave slices are the same for both values)
 };
 
 __global__ __launch_bounds__(256) void chain_pack_kernel(const ChainPackDesc* __restrict__ descs, bf16_t* __restrict__ dst, int nw) {
@@ -119,7 +121,14 @@ __global__ __launch_bounds__(256) void chain_pack_kernel(const ChainPackDesc* __
     // lane: 16-byte bf16 stores / LDS writes, 32 contiguous bytes of the fp32 residual).  4 waves: W4 = w, J = r >> 4;
     // 8 waves: W4 = w >> 1, J = w & 1 -- the same column sets per (W4, J), which keeps the two shapes bit-identical.
     const int w4 = nw == 4 ? w : (w >> 1), J = nw == 4 ? (r >> 4) : (w & 1), i = r & 15;
-    const int row = d.row0 + w4 * 32 + (i >> 2) * 8 + J * 4 + (i & 3), chunk = pos ^ ((r >> 1) & 7);
+    // Paired output map (8 waves, omap): a wave owns 16 columns of a tile = 32 bytes of an output row, and stores of less than
+    // 64 contiguous bytes per row cost ~9 cycles per touched line against ~3.5 (scratch/issue_probe: 743 vs 392 cycles per stage).
+    // So the wave's columns of tiles 2k and 2k+1 are made ADJACENT: column = 256*k + 64*W4 + 32*J + 16*(tile & 1) + i, and the
+    // pair of tiles is written together, 64 contiguous bytes per row (chain_body::gemm_store).
+    const int tile = d.row0 >> 7;
+    const int row = (nw == 8 && d.omap) ? (tile >> 1) * 256 + w4 * 64 + J * 32 + (tile & 1) * 16 + i
+                                        : d.row0 + w4 * 32 + (i >> 2) * 8 + J * 4 + (i & 3);
+    const int chunk = pos ^ ((r >> 1) & 7);
     uint4 v = make_uint4(0, 0, 0, 0);
     if (row < d.nrows) v = *reinterpret_cast<const uint4*>(d.W + (int64_t)row * d.ldw + d.k0 + chunk * 8);
     out[q] = v;
@@ -350,6 +359,23 @@ __device__ __forceinline__ void chain_body(const ChainP& p, bf16_t* const smem, 
     for (int j = 0; j < NJ; ++j)
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt) acc[mt][j] = b[j];
+  };
+  // 8 waves, GEMMs that store their tiles (gemm_store): first of the 16 columns this wave owns of output tile t under the paired
+  // column map of chain_pack_kernel -- tiles 2k and 2k+1 are adjacent halves of one 64-byte run per row
+  auto obase = [&](int t) __attribute__((always_inline)) { return (t >> 1) * 256 + W4 * 64 + J0 * 32 + (t & 1) * 16; };
+  auto init_bias_o = [&](f32x4(&acc)[MT][NJ], const float* bias_lds, int t) __attribute__((always_inline)) {
+    f32x4 b;
+    asm volatile("ds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=&v"(b) : "v"(lds_off(bias_lds + obase(t) + g * 4)) : "memory");
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) acc[mt][0] = b;
+  };
+  auto init_bias_ot = [&](f32x4(&acc)[MT][NJ], const float* bias_lds, int t) __attribute__((always_inline)) {
+    float b;
+    asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=&v"(b) : "v"(lds_off(bias_lds + obase(t) + l15)) : "memory");
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) acc[mt][0] = f32x4{b, b, b, b};
   };
   // same for the swapped (D = C) orientation: one bias value per lane column n = j*16 + l15
   auto init_bias_t = [&](f32x4(&acc)[MT][NJ], const float* bias_lds) __attribute__((always_inline)) {
@@ -603,18 +629,58 @@ __device__ __forceinline__ void chain_body(const ChainP& p, bf16_t* const smem, 
 #pragma unroll
       for (int i = 0; i < VP; ++i) {
         const int q = lane + 64 * i, c = q / (BM / 8), m = m0 + (q % (BM / 8)) * 8;
-        vcol[i] = W4 * 32 + ((c & 15) >> 2) * 8 + (J0 + (c >> 4)) * 4 + (c & 3);
+        vcol[i] = NW == 8 ? c : W4 * 32 + ((c & 15) >> 2) * 8 + (J0 + (c >> 4)) * 4 + (c & 3);   // 8 waves: + obase(t), paired map
         const int sq = m / p.rows_per_seq;
         voff[i] = (q < CW * BM / 8 && m < p.M) ? (int64_t)sq * p.vt_seq_stride + (m - sq * p.rows_per_seq) : -1;
       }
     }
+    [[maybe_unused]] bf16x4 held[MT];   // 8 waves: the even tile of a pair, kept until its neighbour is done
     for (int t = 0; t < ntiles; ++t) {
       f32x4 acc[MT][NJ];
-      if (!transposed) init_bias(acc, bias_lds + t * 128);
-      else init_bias_t(acc, bias_lds + t * 128);
+      if constexpr (NW == 8) {
+        if (!transposed) init_bias_o(acc, bias_lds, t);
+        else init_bias_ot(acc, bias_lds, t);
+      } else {
+        if (!transposed) init_bias(acc, bias_lds + t * 128);
+        else init_bias_t(acc, bias_lds + t * 128);
+      }
       gemm_tile(acc, panelA, D, KS, transposed);
       if (fin && t == ntiles - 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      if (!transposed) {  // 8 (4 waves) / 4 (8 waves) contiguous columns per lane: one 16- / 8-byte store per row
+      if constexpr (NW == 8) {
+        if (!transposed) {
+          // Tiles 2k | 2k+1 of this wave are the two 32-byte halves of one 64-byte run per row (paired map).  The pair goes
+          // through the wave's slice of the idle hidden-chunk buffer, one 16-row tile at a time ([16 rows][32 columns] = 1 KiB),
+          // and leaves as 16-byte pieces: lane q writes piece q & 3 of row q >> 2, i.e. 16 rows x 64 contiguous bytes per store.
+          if ((t & 1) == 0) {
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+              const f32x4 v = acc[mt][0];
+              held[mt] = bf16x4{(bf16_t)v[0], (bf16_t)v[1], (bf16_t)v[2], (bf16_t)v[3]};
+            }
+          } else {
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+              const f32x4 v = acc[mt][0];
+              const bf16x4 o = {(bf16_t)v[0], (bf16_t)v[1], (bf16_t)v[2], (bf16_t)v[3]};
+              const uint32_t wa = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) bf16_t*)(stg + l15 * 32 + g * 4);
+              asm volatile("ds_write_b64 %0, %1\n\tds_write_b64 %0, %2 offset:32" ::"v"(wa), "v"(held[mt]), "v"(o) : "memory");
+              bf16x8 w;
+              asm volatile("s_waitcnt lgkmcnt(0)\n\tds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)"
+                           : "=v"(w)
+                           : "v"((uint32_t)(uintptr_t)(__attribute__((address_space(3))) bf16_t*)(stg + lane * 8))
+                           : "memory");
+              if constexpr (ABL & 1) {
+                asm volatile("" ::"v"(w));
+                continue;
+              }
+              const int m = m0 + mt * 16 + (lane >> 2);
+              if (m < p.M) chain_st_bf8(out + (int64_t)m * ldo + obase(t - 1) + (lane & 3) * 8, w);
+            }
+          }
+          continue;
+        }
+      }
+      if (!transposed) {  // 4 waves: 8 contiguous columns per lane, one 16-byte store per row
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
           if constexpr (ABL & 1) {
@@ -651,7 +717,7 @@ __device__ __forceinline__ void chain_body(const ChainP& p, bf16_t* const smem, 
             asm volatile("" ::"v"(v));
             continue;
           }
-          if (voff[i] >= 0) chain_st_bf8(out + voff[i] + (int64_t)(t * 128 + vcol[i]) * ldo, v);
+          if (voff[i] >= 0) chain_st_bf8(out + voff[i] + (int64_t)(NW == 8 ? obase(t) + vcol[i] : t * 128 + vcol[i]) * ldo, v);
         }
       } else {
 #pragma unroll
@@ -668,7 +734,7 @@ __device__ __forceinline__ void chain_body(const ChainP& p, bf16_t* const smem, 
             // then share a sequence and the address is aligned), else row by row (T = 30 k frames, k odd)
             const int m = m0 + mt * 16 + g * 4;
             if (m >= p.M) continue;
-            const int sq = m / p.rows_per_seq, n = t * 128 + W4 * 32 + (l15 >> 2) * 8 + (J0 + j) * 4 + (l15 & 3);
+            const int sq = m / p.rows_per_seq, n = NW == 8 ? obase(t) + l15 : t * 128 + W4 * 32 + (l15 >> 2) * 8 + (J0 + j) * 4 + (l15 & 3);
             if ((p.rows_per_seq & 3) == 0) {
               chain_st_bf4(out + (int64_t)sq * p.vt_seq_stride + (int64_t)n * ldo + (m - sq * p.rows_per_seq), o);
             } else {

@@ -84,6 +84,12 @@ __global__ __launch_bounds__(64 * NW, 1) void probe(const char* __restrict__ src
             *reinterpret_cast<f32x2*>(base + (size_t)(i * 32 + 16 + l15) * 1280 + g * 8) = f32x2{acc[i % 6][2], acc[i % 6][3]};
           } else if constexpr (PAT == 3) { // 4 rows x 256 B per instruction, adjacent lanes contiguous
             *reinterpret_cast<f32x4*>(base + (size_t)(i * 4 + g) * 2048 + l15 * 16) = acc[i % 6];
+          } else if constexpr (PAT == 5) { // the 8-wave Q/K store today: 8 B per lane, 16 rows x 4 pieces 16 B apart
+            typedef __attribute__((ext_vector_type(2))) float f32x2;
+            *reinterpret_cast<f32x2*>(base + (size_t)(i * 16 + l15) * 2048 + g * 16 + (wid & 1) * 8) = f32x2{acc[i % 6][0], acc[i % 6][1]};
+          } else if constexpr (PAT == 6) { // the same 48 x 32 B block of a wave as 16-byte pieces (2 per row), 1.5 instructions
+            if (i < 2 && (i == 0 || lane < 32))
+              *reinterpret_cast<f32x4*>(base + (size_t)(i * 32 + (lane >> 1)) * 2048 + (wid & 1) * 32 + (lane & 1) * 16) = acc[i % 6];
           } else if constexpr (PAT == 4) { // 16 rows x 64 B, but the 4 lanes of a row ADJACENT
             *reinterpret_cast<f32x4*>(base + (size_t)(i * 16 + (lane >> 2)) * 2048 + (lane & 3) * 16) = acc[i % 6];
           }
@@ -181,6 +187,8 @@ void all(const char* src, unsigned long long* dout, float* sink, int blocks) {
   run<M_MFMA | M_DMA | M_DSREAD | M_STORE, NW, 2>("kernel + store/8 V^T pattern", src, dout, sink, blocks);
   run<M_MFMA | M_DMA | M_DSREAD | M_STORE, NW, 3>("kernel + store/8 4 rows x 256 B", src, dout, sink, blocks);
   run<M_MFMA | M_DMA | M_DSREAD | M_STORE, NW, 4>("kernel + store/8 16 x 64 B adj", src, dout, sink, blocks);
+  run<M_MFMA | M_DMA | M_DSREAD | M_STORE, NW, 5>("kernel + store/8 8-wave QK 8 B", src, dout, sink, blocks);
+  run<M_MFMA | M_DMA | M_DSREAD | M_STORE, NW, 6>("kernel + store/8 8-wave QK staged", src, dout, sink, blocks);
   run<M_DMA | M_STORE, NW, 0>("dma + store/8 coalesced", src, dout, sink, blocks);
   run<M_DMA | M_STORE, NW, 1>("dma + store/8 QK pattern", src, dout, sink, blocks);
   run<M_DMA | M_STORE, NW, 2>("dma + store/8 V^T pattern", src, dout, sink, blocks);
