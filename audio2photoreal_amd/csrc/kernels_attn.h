@@ -390,22 +390,51 @@ __global__ __launch_bounds__(256, 3) void attn_kernel(AttnP p) {
   else tile_loop(integral_constant<bool, false>{});
 
   // ---- normalise and store: lane owns query l15, rows dv*16 + g*4 + {0..3} ----
+  if constexpr (sizeof(T) == 2) {
+    // 16-bit: a lane holds 4 consecutive head-dim values (8 bytes) of one query, so a direct store writes 16 rows x 32 bytes
+    // per instruction -- rows of less than 64 contiguous bytes are the slow store regime (scratch/issue_probe: ~9 cycles per
+    // touched line against ~3.5).  The wave's [32 queries][DH] block is transposed through its slice of the (now idle) K/V ring
+    // instead and leaves as 16-byte pieces, DH/8 adjacent lanes per query: whole 128-byte rows per store at DH = 64.
+    constexpr int SP = DH + 8;                      // padded row (elements): 2-way instead of 16-way bank conflicts on the writes
+    constexpr int PPR = DH / 8;                     // 16-byte pieces per query row
+    constexpr int NPC = QT * 16 * PPR / 64;         // pieces per lane
+    static_assert(4 * QT * 16 * SP <= L::NBUF * (L::KSZ + L::VSZ), "staging does not fit the K/V ring");
+    __syncthreads();                                // every wave is done reading the last tile
+    T* stw = smem + wid * (QT * 16 * SP);
 #pragma unroll
-  for (int qt = 0; qt < QT; ++qt) {
-    float l = lsum[qt];
-    l += __shfl_xor(l, 16, 64);
-    l += __shfl_xor(l, 32, 64);
-    const float inv = 1.0f / l;
-    const int q = q0 + qt * 16 + l15;
-    if (q >= p.Tq) continue;
-    T* Op = reinterpret_cast<T*>(p.O) + (int64_t)seq * p.o_seq_stride + (int64_t)q * p.ldo + head * DH;
+    for (int qt = 0; qt < QT; ++qt) {
+      float l = lsum[qt];
+      l += __shfl_xor(l, 16, 64);
+      l += __shfl_xor(l, 32, 64);
+      const float inv = 1.0f / l;
 #pragma unroll
-    for (int dv = 0; dv < DVT; ++dv) {
-      const f32x4 v = o[qt][dv];
-      if constexpr (sizeof(T) == 2) {
-        bf16x4 ov = {(bf16_t)(v[0] * inv), (bf16_t)(v[1] * inv), (bf16_t)(v[2] * inv), (bf16_t)(v[3] * inv)};
-        *reinterpret_cast<bf16x4*>(Op + dv * 16 + g * 4) = ov;
-      } else {
+      for (int dv = 0; dv < DVT; ++dv) {
+        const f32x4 v = o[qt][dv];
+        *reinterpret_cast<bf16x4*>(stw + (qt * 16 + l15) * SP + dv * 16 + g * 4) =
+            bf16x4{(bf16_t)(v[0] * inv), (bf16_t)(v[1] * inv), (bf16_t)(v[2] * inv), (bf16_t)(v[3] * inv)};
+      }
+    }
+    T* Ob = reinterpret_cast<T*>(p.O) + (int64_t)seq * p.o_seq_stride + head * DH;
+#pragma unroll
+    for (int i = 0; i < NPC; ++i) {
+      const int pc = lane + 64 * i, row = pc / PPR, part = pc % PPR;
+      const bf16x8 v = *reinterpret_cast<const bf16x8*>(stw + row * SP + part * 8);
+      const int q = q0 + row;
+      if (q < p.Tq) *reinterpret_cast<bf16x8*>(Ob + (int64_t)q * p.ldo + part * 8) = v;
+    }
+  } else {
+#pragma unroll
+    for (int qt = 0; qt < QT; ++qt) {
+      float l = lsum[qt];
+      l += __shfl_xor(l, 16, 64);
+      l += __shfl_xor(l, 32, 64);
+      const float inv = 1.0f / l;
+      const int q = q0 + qt * 16 + l15;
+      if (q >= p.Tq) continue;
+      T* Op = reinterpret_cast<T*>(p.O) + (int64_t)seq * p.o_seq_stride + (int64_t)q * p.ldo + head * DH;
+#pragma unroll
+      for (int dv = 0; dv < DVT; ++dv) {
+        const f32x4 v = o[qt][dv];
         *reinterpret_cast<float4*>(Op + dv * 16 + g * 4) = make_float4(v[0] * inv, v[1] * inv, v[2] * inv, v[3] * inv);
       }
     }
