@@ -331,6 +331,57 @@ __device__ __forceinline__ void chain_body(const ChainP& p, bf16_t* const smem, 
       }
     }
   };
+  // linear2 partial of one hidden chunk: facc[t] += H[:, 0:128] * W2[t-th 128 rows, chunk]^T for all NT output tiles, as ONE
+  // pipelined pass over 2*NT stream stages in k-major order (stage = ks*NT + t; the host packs them so): the chunk's A fragments
+  // are read once per k-step for all NT tiles instead of once per tile (8 waves are LDS-read bound: every wave reads every panel
+  // row), and the NT two-stage GEMMs do not each pay their own pipeline ramp.  Per tile the k-order is unchanged: same bits.
+  auto ffn2_kmajor = [&](f32x4(&facc)[NT][MT][NJ]) __attribute__((always_inline)) {
+    bf16x8 a[2][2][MT], w[2][2][NJ];   // [buffer][k-chunk][...]
+    auto load_a = [&](int buf, int ks) __attribute__((always_inline)) {
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+          a[buf][kk][mt] = *reinterpret_cast<const bf16x8*>(panelH + (mt * 16 + l15) * HLD + (((ks * 8 + kk * 4 + g) ^ l15) << 3));
+    };
+    auto load_w = [&](int buf, const bf16_t* wb) __attribute__((always_inline)) {
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+          const int wrow = j * 16 + l15;
+          w[buf][kk][j] = *reinterpret_cast<const bf16x8*>(wb + wrow * 64 + (((kk * 4 + g) ^ ((wrow >> 1) & 7)) << 3));
+        }
+    };
+    load_a(0, 0);
+    load_w(0, stage_begin());
+#pragma unroll
+    for (int s = 0; s < 2 * NT; ++s) {
+      const int ks = s / NT, t = s % NT;
+      if (s + 1 < 2 * NT) {
+        load_w((s + 1) & 1, stage_begin());
+        if ((s + 1) % NT == 0) load_a(1, 1);
+      }
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+          for (int j = 0; j < NJ; ++j) facc[t][mt][j] = A2P_MFMA16(w[s & 1][kk][j], a[ks][kk][mt], facc[t][mt][j]);
+      if (s + 1 < 2 * NT) {
+#pragma unroll
+        for (int i = 0; i < PCS; ++i) {
+          __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < 2 * NJ + ((s + 1) % NT == 0 ? 2 * MT : 0); ++i) {
+          __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        }
+      }
+    }
+  };
   auto zero = [&](f32x4(&acc)[MT][NJ]) __attribute__((always_inline)) {
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt)
@@ -828,8 +879,7 @@ __device__ __forceinline__ void chain_body(const ChainP& p, bf16_t* const smem, 
           }
         }
         if (!(ABL & 8)) chain_bar();  // the hidden chunk is complete
-#pragma unroll
-        for (int t = 0; t < NT; ++t) gemm_tile(facc[t], panelH, HLD, 2);
+        ffn2_kmajor(facc);
       }
       stamp(6);
       if constexpr (!(ABL & 1024)) {
