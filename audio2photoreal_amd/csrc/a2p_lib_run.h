@@ -108,9 +108,17 @@ static int ch_index(int layer, int kind) { return layer * 4 + kind; }
 // stages of one GEMM: 128-row tiles of W[nrows, ldw] (tile-major), K/64 k-steps each
 // omap: the GEMM's tiles are stored straight to HBM by chain_body::gemm_store (Q|K, V, Q projections): paired column map for
 // the 8-wave slices (chain_pack_kernel)
-static void pk_gemm(std::vector<ChainPackDesc>& v, const void* W, int ldw, int nrows, int K, int omap = 0) {
-  for (int t = 0; t < (nrows + 127) / 128; ++t)
-    for (int ks = 0; ks < K / 64; ++ks) v.push_back({reinterpret_cast<const bf16_t*>(W), ldw, t * 128, ks * 64, nrows, omap});
+// group > 0: the tiles are consumed in groups of `group` tiles, k-major inside a group (chain_body::gemm_group)
+static void pk_gemm(std::vector<ChainPackDesc>& v, const void* W, int ldw, int nrows, int K, int omap = 0, int group = 0) {
+  const int nt = (nrows + 127) / 128;
+  if (group <= 0) {
+    for (int t = 0; t < nt; ++t)
+      for (int ks = 0; ks < K / 64; ++ks) v.push_back({reinterpret_cast<const bf16_t*>(W), ldw, t * 128, ks * 64, nrows, omap});
+    return;
+  }
+  for (int t0 = 0; t0 < nt; t0 += group)
+    for (int ks = 0; ks < K / 64; ++ks)
+      for (int t = t0; t < t0 + group && t < nt; ++t) v.push_back({reinterpret_cast<const bf16_t*>(W), ldw, t * 128, ks * 64, nrows, omap});
 }
 
 static int chain_pack(a2p_ctx* c, int idx, const std::vector<ChainPackDesc>& descs, const std::vector<std::pair<const float*, int>>& aux,
@@ -156,14 +164,14 @@ static int chain_build_streams(a2p_ctx* c, hipStream_t s) {
     CHK(chain_pack(c, ch_index(l, CH_PRE), v, {{W32(c, pf(l) + "self_attn.in_proj_bias"), 3 * d}}, s));
     auto mid = [&](int kind, const std::string& done, const std::string& next) -> int {
       std::vector<ChainPackDesc> m;
-      pk_gemm(m, c->wt.at(pf(l) + done + ".out_proj.weight").p, d, d, d);
+      pk_gemm(m, c->wt.at(pf(l) + done + ".out_proj.weight").p, d, d, d, 0, d / 128);
       pk_gemm(m, c->wt.at(pf(l) + next + ".in_proj_weight").p, d, d, d, 1);  // rows [0, d): the query projection
       return chain_pack(c, ch_index(l, kind), m, {{W32(c, pf(l) + next + ".in_proj_bias"), d}}, s);
     };
     CHK(mid(CH_MID, "self_attn", "multihead_attn"));
     if (c->pose) CHK(mid(CH_MID2, "multihead_attn", "multihead_attn2"));
     std::vector<ChainPackDesc> q;
-    pk_gemm(q, c->wt.at(pf(l) + (c->pose ? "multihead_attn2" : "multihead_attn") + ".out_proj.weight").p, d, d, d);
+    pk_gemm(q, c->wt.at(pf(l) + (c->pose ? "multihead_attn2" : "multihead_attn") + ".out_proj.weight").p, d, d, d, 0, d / 128);
     const Buf& w1 = c->wt.at(pf(l) + "linear1.weight");
     const Buf& w2 = c->wt.at(pf(l) + "linear2.weight");
     for (int h = 0; h < ff / 128; ++h) {

@@ -331,18 +331,19 @@ __device__ __forceinline__ void chain_body(const ChainP& p, bf16_t* const smem, 
       }
     }
   };
-  // linear2 partial of one hidden chunk: facc[t] += H[:, 0:128] * W2[t-th 128 rows, chunk]^T for all NT output tiles, as ONE
-  // pipelined pass over 2*NT stream stages in k-major order (stage = ks*NT + t; the host packs them so): the chunk's A fragments
-  // are read once per k-step for all NT tiles instead of once per tile (8 waves are LDS-read bound: every wave reads every panel
-  // row), and the NT two-stage GEMMs do not each pay their own pipeline ramp.  Per tile the k-order is unchanged: same bits.
-  auto ffn2_kmajor = [&](f32x4(&facc)[NT][MT][NJ]) __attribute__((always_inline)) {
+  // acc[t] += P[:, 0:64*NKS] * (stream stages)^T for all NT tiles of a group, as ONE pipelined pass over NKS*NT stream stages in
+  // k-major order (stage = ks*NT + t; the host packs them so): the A fragments of a k-step are read once for all NT tiles instead of
+  // once per tile (8 waves are LDS-read bound: every wave reads every panel row), and the group pays one pipeline ramp instead of
+  // NT.  Per tile the k-order is unchanged: same bits as the tile-major form.
+  auto gemm_group = [&](f32x4(&acc)[NT][MT][NJ], const bf16_t* P, int pld, auto nks_c, bool swap = false) __attribute__((always_inline)) {
+    constexpr int NKS = decltype(nks_c)::value, NST = NKS * NT;
     bf16x8 a[2][2][MT], w[2][2][NJ];   // [buffer][k-chunk][...]
     auto load_a = [&](int buf, int ks) __attribute__((always_inline)) {
 #pragma unroll
       for (int kk = 0; kk < 2; ++kk)
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt)
-          a[buf][kk][mt] = *reinterpret_cast<const bf16x8*>(panelH + (mt * 16 + l15) * HLD + (((ks * 8 + kk * 4 + g) ^ l15) << 3));
+          a[buf][kk][mt] = *reinterpret_cast<const bf16x8*>(P + (mt * 16 + l15) * pld + (((ks * 8 + kk * 4 + g) ^ l15) << 3));
     };
     auto load_w = [&](int buf, const bf16_t* wb) __attribute__((always_inline)) {
 #pragma unroll
@@ -356,26 +357,30 @@ __device__ __forceinline__ void chain_body(const ChainP& p, bf16_t* const smem, 
     load_a(0, 0);
     load_w(0, stage_begin());
 #pragma unroll
-    for (int s = 0; s < 2 * NT; ++s) {
+    for (int s = 0; s < NST; ++s) {
       const int ks = s / NT, t = s % NT;
-      if (s + 1 < 2 * NT) {
+      const bool new_k = (s + 1) % NT == 0;   // the next stage starts a k-step
+      if (s + 1 < NST) {
         load_w((s + 1) & 1, stage_begin());
-        if ((s + 1) % NT == 0) load_a(1, 1);
+        if (new_k) load_a((ks + 1) & 1, ks + 1);
       }
 #pragma unroll
       for (int kk = 0; kk < 2; ++kk)
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-          for (int j = 0; j < NJ; ++j) facc[t][mt][j] = A2P_MFMA16(w[s & 1][kk][j], a[ks][kk][mt], facc[t][mt][j]);
-      if (s + 1 < 2 * NT) {
+          for (int j = 0; j < NJ; ++j) {
+            if (swap) acc[t][mt][j] = A2P_MFMA16(a[ks & 1][kk][mt], w[s & 1][kk][j], acc[t][mt][j]);
+            else acc[t][mt][j] = A2P_MFMA16(w[s & 1][kk][j], a[ks & 1][kk][mt], acc[t][mt][j]);
+          }
+      if (s + 1 < NST) {
 #pragma unroll
         for (int i = 0; i < PCS; ++i) {
           __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
           __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
         }
 #pragma unroll
-        for (int i = 0; i < 2 * NJ + ((s + 1) % NT == 0 ? 2 * MT : 0); ++i) {
+        for (int i = 0; i < 2 * NJ + (new_k ? 2 * MT : 0); ++i) {
           __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
           __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
         }
@@ -825,10 +830,8 @@ __device__ __forceinline__ void chain_body(const ChainP& p, bf16_t* const smem, 
     {
       f32x4 oacc[NT][MT][NJ];
 #pragma unroll
-      for (int t = 0; t < NT; ++t) {
-        zero(oacc[t]);
-        gemm_tile(oacc[t], panelA, D, KS);
-      }
+      for (int t = 0; t < NT; ++t) zero(oacc[t]);
+      gemm_group(oacc, panelA, D, std::integral_constant<int, KS>{});
       stamp(2);
       if constexpr (!(ABL & 512)) {
 #pragma unroll
@@ -879,7 +882,7 @@ __device__ __forceinline__ void chain_body(const ChainP& p, bf16_t* const smem, 
           }
         }
         if (!(ABL & 8)) chain_bar();  // the hidden chunk is complete
-        ffn2_kmajor(facc);
+        gemm_group(facc, panelH, HLD, std::integral_constant<int, 2>{});
       }
       stamp(6);
       if constexpr (!(ABL & 1024)) {
