@@ -15,8 +15,8 @@ The ONE JSON line rank 0 prints carries, next to the contract fields:
   cpu_baseline  the oracle (CPU port of the reference algorithm) timed on this box's host cores, bounded sample
   parity        all three modes (fp16 = benchmarked, bf16, fp32 = parity mode) against that same oracle run at the bench shape
                 (face, T=600, S=2000), plus the drift of the full 1000-step chain of both 16-bit modes vs GPU-fp32 under identical noise
-  legs          the same workload with bf16 operands ("bf16"), and the other two north-star shapes on this GPU: face B=32
-                ("b32") and the body model B=16 with keyframes ("body")
+  legs          the same workload with bf16 operands ("bf16"), and the other north-star shapes on this GPU: face B=32
+                ("b32"), the body model B=16 with keyframes ("body") and the reference's CPU-runnable config 0 shape ("cfg0")
 
 Multi-GPU = sample parallel: rank r denoises the global samples shard_bounds(N*B, N, r) with its own
 replica, no per-step communication (weak scaling); one all_gather (sample_parallel.gather_samples; RCCL over xGMI) of the
@@ -486,6 +486,10 @@ def main():
             body = Case("pose", 16, T, a.precision, dev, list(range(16)), respacing="ddim100", sampler="ddim")
             legs["body"] = leg_record(body, a.steps, a.warmup, a.repeats)
             legs["body"]["note"] = "BASELINE configs[2]: body diffusion, keyframe conditioning + CFG scale 2, batch 16, 600 frames, ddim100 step"
+            cfg0 = Case("face", 1, 240, a.precision, dev, [0], respacing="ddim10", sampler="ddim")
+            legs["cfg0"] = leg_record(cfg0, 50, 5, a.repeats)
+            legs["cfg0"]["note"] = ("BASELINE configs[0] shape: face, batch 1, 240 frames, ddim10 step.  480 rows: below the chain kernels' "
+                                    "break-even, ~110 dependent launches of 4-12 us back to back (no gaps): launch-count bound, not compute bound")
 
     if rank == 0:
         value = world * a.steps / dt
