@@ -276,7 +276,11 @@ static int launch_ln_rope(a2p_ctx* c, bool as_f32, const float* x, int64_t ldx, 
 
 static int launch_attn(a2p_ctx* c, const AttnP& p0, int nseq, int kind, hipStream_t s) {
   AttnP p = p0;
-  p.nq = (p.Tq + 127) / 128; p.nheads = c->H; p.nseq = nseq;
+  // A2P_ATTN_WAVES=2 (16-bit modes): 2-wave workgroups of 64 queries -- a perfectly even 5 workgroups per CU at B=8, but every K/V
+  // tile then feeds half as many queries: measured 97 vs 70 us for the cross attention (experiment switch, kernels_attn.h NWV)
+  static const bool two = getenv("A2P_ATTN_WAVES") && atoi(getenv("A2P_ATTN_WAVES")) == 2;
+  const int nwv = (c->bf16 && two) ? 2 : 4;
+  p.nq = (p.Tq + 32 * nwv - 1) / (32 * nwv); p.nheads = c->H; p.nseq = nseq;
   static const bool no_remap = getenv("A2P_ATTN_NO_REMAP") != nullptr;   // A/B switch
   p.xcd_remap = (!no_remap && (c->H * nseq) % 8 == 0) ? 1 : 0;
   dim3 grid(p.nq * c->H * nseq);
@@ -285,10 +289,12 @@ static int launch_attn(a2p_ctx* c, const AttnP& p0, int nseq, int kind, hipStrea
     ARG(!c->bf16, "head_dim 128 is instantiated for fp32 only");
     A2P_LAUNCH(kt, (attn_kernel<float, 128>), grid, 256, s, p);
   } else if (c->DH == 64) {
-    if (c->bf16) A2P_LAUNCH(kt, (attn_kernel<bf16_t, 64>), grid, 256, s, p);
+    if (c->bf16 && nwv == 2) A2P_LAUNCH(kt, (attn_kernel<bf16_t, 64, 0, 2>), grid, 128, s, p);
+    else if (c->bf16) A2P_LAUNCH(kt, (attn_kernel<bf16_t, 64>), grid, 256, s, p);
     else A2P_LAUNCH(kt, (attn_kernel<float, 64>), grid, 256, s, p);
   } else {
-    if (c->bf16) A2P_LAUNCH(kt, (attn_kernel<bf16_t, 32>), grid, 256, s, p);
+    if (c->bf16 && nwv == 2) A2P_LAUNCH(kt, (attn_kernel<bf16_t, 32, 0, 2>), grid, 128, s, p);
+    else if (c->bf16) A2P_LAUNCH(kt, (attn_kernel<bf16_t, 32>), grid, 256, s, p);
     else A2P_LAUNCH(kt, (attn_kernel<float, 32>), grid, 256, s, p);
   }
   HIPCHK(hipGetLastError());

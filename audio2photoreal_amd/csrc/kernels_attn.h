@@ -66,11 +66,11 @@ struct AttnLds {
   }
   // 16-byte chunk swizzle of the K tile: the 16 rows {8j + 4b + r} read by one ds_read_b128 group must hit 16 distinct
   // 16-byte bank slots (slot = (row * row_bytes + pos * 16) mod 256)
-  __device__ static __forceinline__ int kswz(int row) {
+  __device__ static constexpr __forceinline__ int kswz(int row) {
     if constexpr (DH == 64) return (((row >> 3) & 3) << 1) | ((row >> 1) & 1);
     else return (row >> 3) & 3;
   }
-  __device__ static __forceinline__ int vswz(int row) { return (row >> 1) & 7; }
+  __device__ static constexpr __forceinline__ int vswz(int row) { return (row >> 1) & 7; }
   __device__ static __forceinline__ int kidx(int row, int c) {
     if constexpr (DMA) return row * LSK + ((((c >> 3) ^ kswz(row)) << 3) | (c & 7));
     else return row * LSK + c;
@@ -101,11 +101,15 @@ __device__ __forceinline__ float attn_rowgroup_max(float v) {
 
 // ABL: ablation switches for scratch/attn_bench.hip only (the library instantiates ABL = 0):
 //   1 = no exp, 2 = no running-max reduction, 4 = no staging / barriers after tile 0, 8 = no PV MFMAs, 16 = no QK^T MFMAs
-template <typename T, int DH, int ABL = 0>
-__global__ __launch_bounds__(256, 3) void attn_kernel(AttnP p) {
+// NWV: waves per workgroup (each wave owns QT*16 = 32 queries); 4 in production.  NWV = 2 was tried for its even grid (T = 600: 10
+// query blocks per (sequence, head), B=8: 1280 workgroups = exactly 5 per CU instead of 2 or 3) and lost clearly -- cross attention
+// 97 vs 70 us: every K/V tile then feeds 64 instead of 128 queries and the tile DMA / LDS traffic per query doubles.
+template <typename T, int DH, int ABL = 0, int NWV = 4>
+__global__ __launch_bounds__(64 * NWV, 3) void attn_kernel(AttnP p) {
   using P = Prec<T>;
   using L = AttnLds<T, DH>;
-  constexpr int QT = 2, BQ = 4 * QT * 16, KV = 64;
+  constexpr int QT = 2, BQ = NWV * QT * 16, KV = 64, NTHR = 64 * NWV;
+  static_assert(NWV == 4 || sizeof(T) == 2, "the register-staged fp32 path is written for 4 waves");
   constexpr int KC = DH / P::KCH;   // k-chunks over head_dim (QK^T)
   constexpr int DVT = DH / 16;      // 16-row tiles of O^T
   constexpr int VEC = 16 / sizeof(T);
@@ -161,39 +165,45 @@ __global__ __launch_bounds__(256, 3) void attn_kernel(AttnP p) {
   }
 
   // ---- staging ------------------------------------------------------------------------------
-  // bf16: per-lane source offset of this wave's FIRST K / V^T DMA piece.  Piece j of a wave lies 4*KRPI key rows (K) or 32 V^T
-  // rows further on and has the same swizzle (kswz / vswz are periodic in 32 rows), so the rest of the address is wave-uniform
-  [[maybe_unused]] int64_t ksrc0 = 0, vsrc0 = 0;
+  // bf16: source offsets of this wave's DMA pieces.  K piece pi = j*NWV + wid covers KRPI key rows, V^T piece pi covers 8 head-dim
+  // rows.  The swizzle of a row is the XOR of a part that depends on the piece and a part that depends on the lane's row inside the
+  // piece (kswz / vswz take disjoint bits from the two), so one per-lane offset + one per-lane swizzle serve all pieces: the piece
+  // part is wave-uniform (scalar) arithmetic at issue time, not a register per piece.
+  constexpr int CPR_ = DH / 8, KRPI_ = 64 / CPR_;
+  constexpr int KPW = L::DMA ? CPR_ / NWV : 1, VPW = L::DMA ? DH / 8 / NWV : 1;
+  const int widu = __builtin_amdgcn_readfirstlane(wid);
+  [[maybe_unused]] int kbase = 0, ksw = 0, vbase = 0, vsw = 0;
   if constexpr (L::DMA) {
-    constexpr int CPR = DH / 8;          // 16-byte chunks per K row
-    constexpr int KRPI = 64 / CPR;       // K rows per wave-instruction
-    static_assert((4 * KRPI) % 32 == 0, "K pieces of one wave must share their swizzle");
-    {
-      const int row = wid * KRPI + lane / CPR, pos = lane % CPR;
-      ksrc0 = (int64_t)row * p.ldk + ((pos ^ L::kswz(row)) << 3);
-    }
-    {
-      const int row = wid * 8 + (lane >> 3), pos = lane & 7;
-      vsrc0 = (int64_t)row * p.ldvt + ((pos ^ L::vswz(row)) << 3);
-    }
+    const int kr0 = lane / CPR_, vr0 = lane >> 3;
+    kbase = kr0 * (int)p.ldk;
+    ksw = ((lane % CPR_) ^ L::kswz(kr0)) << 3;
+    vbase = vr0 * (int)p.ldvt;
+    vsw = ((lane & 7) ^ L::vswz(vr0)) << 3;
   }
+  auto kpiece = [&](int j) __attribute__((always_inline)) {   // element offset of K piece j of this wave inside a tile
+    const int pi = j * NWV + widu;
+    return (int64_t)(pi * KRPI_) * p.ldk + (kbase + (ksw ^ (L::kswz(pi * KRPI_) << 3)));
+  };
+  auto vpiece = [&](int j) __attribute__((always_inline)) {
+    const int pi = j * NWV + widu;
+    return (int64_t)(pi * 8) * p.ldvt + (vbase + (vsw ^ (L::vswz(pi * 8) << 3)));
+  };
   auto stage_dma = [&](int tile, int buf) {
     if constexpr (L::DMA) {
-      constexpr int CPR = DH / 8, KRPI = 64 / CPR, KPW = CPR / 4, VPW = DH / 32;
       bf16_t* Ks = reinterpret_cast<bf16_t*>(smem) + buf * (L::KSZ + L::VSZ);
       bf16_t* Vs = Ks + L::KSZ;
       const bf16_t* Kt = reinterpret_cast<const bf16_t*>(Kb) + (int64_t)tile * KV * p.ldk;
       const bf16_t* Vt = reinterpret_cast<const bf16_t*>(Vb) + tile * KV;
       if (kv_nt) {  // block-uniform
 #pragma unroll
-        for (int j = 0; j < KPW; ++j) attn_glds16<2>(Kt + (int64_t)(j * 4 * KRPI) * p.ldk + ksrc0, Ks + (j * 4 + wid) * KRPI * DH);
+        for (int j = 0; j < KPW; ++j) attn_glds16<2>(Kt + kpiece(j), Ks + (j * NWV + widu) * KRPI_ * DH);
 #pragma unroll
-        for (int j = 0; j < VPW; ++j) attn_glds16<2>(Vt + (int64_t)(j * 32) * p.ldvt + vsrc0, Vs + (j * 4 + wid) * 8 * KV);
+        for (int j = 0; j < VPW; ++j) attn_glds16<2>(Vt + vpiece(j), Vs + (j * NWV + widu) * 8 * KV);
       } else {
 #pragma unroll
-        for (int j = 0; j < KPW; ++j) attn_glds16<0>(Kt + (int64_t)(j * 4 * KRPI) * p.ldk + ksrc0, Ks + (j * 4 + wid) * KRPI * DH);
+        for (int j = 0; j < KPW; ++j) attn_glds16<0>(Kt + kpiece(j), Ks + (j * NWV + widu) * KRPI_ * DH);
 #pragma unroll
-        for (int j = 0; j < VPW; ++j) attn_glds16<0>(Vt + (int64_t)(j * 32) * p.ldvt + vsrc0, Vs + (j * 4 + wid) * 8 * KV);
+        for (int j = 0; j < VPW; ++j) attn_glds16<0>(Vt + vpiece(j), Vs + (j * NWV + widu) * 8 * KV);
       }
     }
   };
@@ -238,7 +248,7 @@ __global__ __launch_bounds__(256, 3) void attn_kernel(AttnP p) {
     if (p.S_tail > 0 && kv0 + KV > p.S_main) {  // block-uniform: patch the time-token rows into the tile
       if constexpr (!L::DMA) __syncthreads();
       const int sample = seq % p.tail_mod;
-      for (int e = tid; e < p.S_tail * DH; e += 256) {
+      for (int e = tid; e < p.S_tail * DH; e += NTHR) {
         const int j = e / DH, c = e % DH;
         const int kl = p.S_main + j - kv0;
         if (kl >= 0 && kl < KV) {
@@ -398,7 +408,7 @@ __global__ __launch_bounds__(256, 3) void attn_kernel(AttnP p) {
     constexpr int SP = DH + 8;                      // padded row (elements): 2-way instead of 16-way bank conflicts on the writes
     constexpr int PPR = DH / 8;                     // 16-byte pieces per query row
     constexpr int NPC = QT * 16 * PPR / 64;         // pieces per lane
-    static_assert(4 * QT * 16 * SP <= L::NBUF * (L::KSZ + L::VSZ), "staging does not fit the K/V ring");
+    static_assert(NWV * QT * 16 * SP <= L::NBUF * (L::KSZ + L::VSZ), "staging does not fit the K/V ring");
     __syncthreads();                                // every wave is done reading the last tile
     T* stw = smem + wid * (QT * 16 * SP);
 #pragma unroll

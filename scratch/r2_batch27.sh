@@ -1,0 +1,12 @@
+R=$GRAFT_REPO_ROOT; cd $R
+timeout 900 python -m pytest tests -m gpu -q -x 2>&1 | tail -3
+j='import json,sys
+d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(sys.argv[1], d["value"], d["ms_per_step"], {k:(v["launches_per_step"], v["avg_launch_us"]) for k,v in d["kernels"].items()})'
+for rep in 1 2; do
+timeout 300 python bench.py --no-cpu-baseline --no-legs --no-parity 2>/dev/null | python -c "$j" "B8 2-wave"
+A2P_ATTN_WAVES=4 timeout 300 python bench.py --no-cpu-baseline --no-legs --no-parity 2>/dev/null | python -c "$j" "B8 4-wave"
+done
+timeout 300 python bench.py --no-cpu-baseline --no-legs --no-parity --batch 32 --steps 10 2>/dev/null | python -c "$j" "B32 2-wave"
+A2P_ATTN_WAVES=4 timeout 300 python bench.py --no-cpu-baseline --no-legs --no-parity --batch 32 --steps 10 2>/dev/null | python -c "$j" "B32 4-wave"
+timeout 300 python bench.py --no-cpu-baseline --no-legs --no-parity --model pose --batch 16 2>/dev/null | python -c "$j" "pose 2-wave"
+A2P_ATTN_WAVES=4 timeout 300 python bench.py --no-cpu-baseline --no-legs --no-parity --model pose --batch 16 2>/dev/null | python -c "$j" "pose 4-wave"
