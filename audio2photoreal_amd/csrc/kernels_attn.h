@@ -100,7 +100,8 @@ __device__ __forceinline__ float attn_rowgroup_max(float v) {
 }
 
 // ABL: ablation switches for scratch/attn_bench.hip only (the library instantiates ABL = 0):
-//   1 = no exp, 2 = no running-max reduction, 4 = no staging / barriers after tile 0, 8 = no PV MFMAs, 16 = no QK^T MFMAs
+//   1 = no exp, 2 = no running-max reduction, 4 = no staging / barriers after tile 0, 8 = no PV MFMAs, 16 = no QK^T MFMAs,
+//   32 = per-tile barrier without the DMA wait, 64 = per-tile DMA wait without the barrier (timing only: results are wrong)
 // NWV: waves per workgroup (each wave owns QT*16 = 32 queries); 4 in production.  NWV = 2 was tried for its even grid (T = 600: 10
 // query blocks per (sequence, head), B=8: 1280 workgroups = exactly 5 per CU instead of 2 or 3) and lost clearly -- cross attention
 // 97 vs 70 us: every K/V tile then feeds 64 instead of 128 queries and the tile DMA / LDS traffic per query doubles.
@@ -238,7 +239,16 @@ __global__ __launch_bounds__(64 * NWV, 3) void attn_kernel(AttnP p) {
     T* Ks = smem + buf * (L::KSZ + L::VSZ);
     T* Vs = Ks + L::KSZ;
     if (!(ABL & 4) || tile == 0) {
-      __syncthreads();  // bf16: tile landed (vmcnt(0)) and the other buffer is free; fp32: previous tile consumed
+      // bf16: tile landed (vmcnt(0)) and the other buffer is free; fp32: previous tile consumed
+      if constexpr ((ABL & 32) != 0) {          // ablation: barrier, but no wait for the tile DMA
+        if (tile == 0) __syncthreads();
+        else asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+      } else if constexpr ((ABL & 64) != 0) {   // ablation: wait for this wave's DMA pieces, but no barrier
+        if (tile == 0) __syncthreads();
+        else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+      } else {
+        __syncthreads();
+      }
       if constexpr (L::DMA) {
         if (tile + 1 < ntiles) stage_dma(tile + 1, buf ^ 1);
       } else {
