@@ -56,7 +56,7 @@ class A2PGuideConfig(C.Structure):
 class A2PFrontendConfig(C.Structure):
     _fields_ = [(n, C.c_int32) for n in (
         "conv_dim", "resample", "lip", "d_model", "num_heads", "ff_size", "enc_layers", "dec_layers", "lip_out", "lip_pad",
-        "chunk_frames", "samples_per_frame", "max_batch", "max_frames")] + [("reserved", C.c_int32 * 2)]
+        "chunk_frames", "samples_per_frame", "max_batch", "max_frames", "conv_16bit")] + [("reserved", C.c_int32 * 1)]
 
 
 class A2PError(RuntimeError):

@@ -4,7 +4,8 @@
 // (model/modules/transformer_modules.py:560-627), setup_lip_regressor (model/utils.py:18-26).
 //
 // The reference runs all of this in EVERY denoising step and in both guidance passes; here it runs once per clip
-// (FiLMTransformer.prepare).  fp32 throughout (exact-fp32 MFMA GEMMs, the attention kernel at head_dim 128).
+// (FiLMTransformer.prepare).  fp32 throughout (exact-fp32 MFMA GEMMs, the attention kernel at head_dim 128), except that the conv
+// stacks' GEMMs (layers 1..7, 99 % of the FLOPs) can run on 16-bit operands with fp32 accumulation (cfg.conv_16bit).
 //
 // What is pinned and what is not: the lip regressor's transformer, the 120-frame chunking, the nearest-exact interpolation
 // and the concatenation are all in /root/reference and are pinned by reference-generated goldens (tests/golden/
@@ -18,6 +19,8 @@
 struct a2p_frontend_ctx {
   a2p_frontend_config cfg;
   a2p_ctx core;  // fp32 host state for the shared launchers (GEMM / attention / LayerNorm dispatch); owns no buffers
+  a2p_ctx core16;  // the same for the conv stacks in 16-bit mode (cfg.conv_16bit)
+  bool conv16 = false;
   std::map<std::string, int64_t> expect;
   std::map<std::string, Buf> w;
   bool finalized = false;
@@ -62,16 +65,38 @@ __global__ void fe_resample_kernel(const float* __restrict__ x, const float* __r
   out[n] = acc;
 }
 
-// first conv layer: Conv1d(1, Co, k, stride) + ReLU on a mono signal -> channel-last rows [T0][Co]
-__global__ __launch_bounds__(256) void fe_conv0_kernel(const float* __restrict__ x, const float* __restrict__ w, float* __restrict__ out,
+// first conv layer: Conv1d(1, Co, k <= 16, stride) + ReLU on a mono signal -> channel-last rows [T0][Co] (fp32 arithmetic, output T).
+// A thread owns one channel (its k taps in registers) and walks FE0_TB output frames whose input window sits in LDS; a frame's Co
+// outputs are contiguous, so every store instruction is one coalesced run.  (The first version -- one thread per output, taps and
+// samples re-read from global memory -- wrote 131 MB per sequence at 0.5 TB/s.)
+constexpr int FE0_TB = 64;
+template <typename T>
+__global__ __launch_bounds__(256) void fe_conv0_kernel(const float* __restrict__ x, const float* __restrict__ w, T* __restrict__ out,
                                                        int64_t T0, int Co, int k, int stride) {
+  __shared__ float win[FE0_TB * 8 + 16];   // stride <= 8
+  const int64_t t0 = (int64_t)blockIdx.x * FE0_TB;
+  const int nt = (int)(T0 - t0 < FE0_TB ? T0 - t0 : FE0_TB);
+  const int nwin = (nt - 1) * stride + k;
+  for (int i = threadIdx.x; i < nwin; i += 256) win[i] = x[t0 * stride + i];
+  __syncthreads();
+  for (int c = blockIdx.y * 256 + threadIdx.x; c < Co; c += gridDim.y * 256) {
+    float wr[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) wr[j] = j < k ? w[c * 32 + j] : 0.f;
+    for (int t = 0; t < nt; ++t) {
+      float acc = 0.f;
+#pragma unroll
+      for (int j = 0; j < 16; ++j)
+        if (j < k) acc = fmaf(wr[j], win[t * stride + j], acc);
+      out[(t0 + t) * Co + c] = from_f32<T>(acc > 0.f ? acc : 0.f);
+    }
+  }
+}
+
+// fp32 -> 16-bit copy of a repacked conv weight
+__global__ void fe_cast_kernel(const float* __restrict__ src, bf16_t* __restrict__ dst, int64_t n) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= T0 * Co) return;
-  const int64_t t = i / Co;
-  const int c = (int)(i - t * Co);
-  float acc = 0.f;
-  for (int j = 0; j < k; ++j) acc = fmaf(w[c * 32 + j], x[t * stride + j], acc);
-  out[i] = acc > 0.f ? acc : 0.f;
+  if (i < n) dst[i] = (bf16_t)src[i];
 }
 
 // Conv1d weight [Co][Ci][k] -> GEMM operand [Co][k*Ci] (tap-major: a channel-last window of k rows is one contiguous A row);
@@ -140,6 +165,9 @@ extern "C" int a2p_frontend_create(const a2p_frontend_config* cfg, a2p_frontend_
   f->cfg = *cfg;
   f->core.bf16 = false; f->core.esz = 4; f->core.d = cfg->d_model; f->core.H = cfg->num_heads; f->core.DH = cfg->d_model / cfg->num_heads;
   f->core.use_arena = false;
+  f->conv16 = cfg->conv_16bit != 0;
+  f->core16.bf16 = true; f->core16.esz = 2; f->core16.d = cfg->d_model; f->core16.H = cfg->num_heads; f->core16.DH = f->core.DH;
+  f->core16.use_arena = false;
   auto& e = f->expect;
   const int64_t C = cfg->conv_dim, d = cfg->d_model, ff = cfg->ff_size;
   for (int i = 0; i < 8; ++i)
@@ -217,6 +245,14 @@ extern "C" int a2p_frontend_finalize(a2p_frontend_ctx* f, void* stream) {
       CHK(buf_alloc_tmp(dst[i], (size_t)C * ld * 4));
       const int64_t n = (int64_t)C * ld;
       fe_repack_kernel<<<(int)((n + 255) / 256), 256, 0, s>>>(FW(f, prefix + std::to_string(i) + ".0.weight"), dst[i].f(), C, Ci, kFeK[i], ld);
+      if (f->conv16 && i > 0) {   // layers 1..7 are GEMMs on 16-bit operands; layer 0 keeps fp32 taps (VALU arithmetic)
+        Buf h;
+        CHK(buf_alloc_tmp(h, (size_t)n * 2));
+        fe_cast_kernel<<<(int)((n + 255) / 256), 256, 0, s>>>(dst[i].f(), reinterpret_cast<bf16_t*>(h.p), n);
+        HIPCHK(hipStreamSynchronize(s));
+        buf_free(dst[i]);
+        dst[i] = h;
+      }
     }
     return 0;
   };
@@ -268,7 +304,11 @@ static int fe_features(a2p_frontend_ctx* f, const float* wav48, int64_t L, int l
   int64_t n = n16 + lead;
   const int64_t T0 = (n - kFeK[0]) / kFeS[0] + 1;
   ARG(T0 >= 1, "sequence of %lld samples is shorter than the first conv kernel", (long long)L);
-  fe_conv0_kernel<<<(int)((T0 * C + 255) / 256), 256, 0, s>>>(f->pcm.f(), cw[0].f(), f->act[0].f(), T0, C, kFeK[0], kFeS[0]);
+  {
+    const dim3 g0((unsigned)((T0 + FE0_TB - 1) / FE0_TB), (unsigned)((C + 255) / 256));
+    if (f->conv16) fe_conv0_kernel<bf16_t><<<g0, 256, 0, s>>>(f->pcm.f(), cw[0].f(), reinterpret_cast<bf16_t*>(f->act[0].p), T0, C, kFeK[0], kFeS[0]);
+    else fe_conv0_kernel<float><<<g0, 256, 0, s>>>(f->pcm.f(), cw[0].f(), f->act[0].f(), T0, C, kFeK[0], kFeS[0]);
+  }
   n = T0;
   int cur = 0;
   for (int i = 1; i < 8; ++i) {
@@ -276,7 +316,8 @@ static int fe_features(a2p_frontend_ctx* f, const float* wav48, int64_t L, int l
     ARG(To >= 1, "sequence too short for conv layer %d", i);
     GemmP p = gemm_base(f->act[cur].p, (int64_t)kFeS[i] * C, cw[i].p, (int64_t)kFeK[i] * C, nullptr, f->act[cur ^ 1].p, C, (int)To, C, kFeK[i] * C);
     p.act = ACT_RELU;
-    CHK(launch_gemm(&f->core, p, s));
+    if (f->conv16 && i == 7) p.out_f32 = 1;   // the features leave the stack as fp32 in both modes
+    CHK(launch_gemm(f->conv16 ? &f->core16 : &f->core, p, s));
     n = To;
     cur ^= 1;
   }

@@ -217,6 +217,7 @@ static int gemm_dispatch(KernelTimer& kt, const GemmP& p, hipStream_t s) {
   else if (p.epi == EPI_STORE && p.act == ACT_NONE) A2P_GEMM(EPI_STORE, ACT_NONE, false);
   else if (p.epi == EPI_STORE && p.act == ACT_GELU && !p.out_f32) A2P_GEMM(EPI_STORE, ACT_GELU, false);
   else if (p.epi == EPI_STORE && p.act == ACT_RELU && !p.out_f32) A2P_GEMM(EPI_STORE, ACT_RELU, false);   // audio front end
+  else if (p.epi == EPI_STORE && p.act == ACT_RELU) A2P_GEMM(EPI_STORE, ACT_RELU, true);                   // its last conv layer in 16-bit mode
   else {
     set_err("gemm: no kernel instance for epi=%d act=%d out_f32=%d", p.epi, p.act, p.out_f32);
     return A2P_ERR_ARG;

@@ -3,7 +3,8 @@
 (:295-313) -- in every denoising step and guidance pass.  Here it runs once per clip, inside `FiLMTransformer.prepare`.
 
 The torch modules below are parameter CONTAINERS with the reference's `state_dict()` key layout (nothing is computed in
-PyTorch); the arithmetic is liba2p_hip.so's `a2p_frontend_*` entry points (csrc/a2p_frontend.h, fp32).
+PyTorch); the arithmetic is the `a2p_frontend_*` entry points of liba2p_hip*.so (csrc/a2p_frontend.h: fp32, or -- following the
+owner model's precision -- the conv stacks' GEMMs on 16-bit operands).
 
   audio_model   setup_lip_regressor()'s vq-wav2vec model (model/utils.py:18-26).  Only its conv feature extractor is on the
                 path (`audio_model.feature_extractor(a)`, model/diffusion.py:290-291); keys follow fairseq's
@@ -127,10 +128,15 @@ class NativeAudioFrontend:
     `encode_audio(audio)` = FiLMTransformer.encode_audio (also what GuideTransformer.encode_audio computes, model/guide.py:111-119);
     `__call__(audio)` = encode_audio followed by encode_lip when the owner has a lip model: the denoiser's `cond_embed`."""
 
-    def __init__(self, owner: nn.Module, resample: str = "sinc", max_batch: int = 32, max_frames: int = 600):
+    def __init__(self, owner: nn.Module, resample: str = "sinc", max_batch: int = 32, max_frames: int = 600,
+                 precision: Optional[str] = None):
+        """`precision`: "fp32" = exact-fp32 MFMA everywhere (parity mode); "fp16" / "bf16" = the conv feature extractors' GEMMs (99 % of
+        the front end's FLOPs) on 16-bit operands with fp32 accumulation; None = follow `owner.precision` at first use."""
         assert resample in ("sinc", "decimate")
+        assert precision in (None, "fp32", "fp16", "f16", "bf16")
         self.owner, self.resample, self.max_batch, self.max_frames = owner, resample, max_batch, max_frames
-        self._ctx, self._sig = None, None
+        self.precision = precision
+        self._ctx, self._sig, self._ctx_lib = None, None, None
 
     def _params(self):
         out = {}
@@ -144,16 +150,24 @@ class NativeAudioFrontend:
     def has_lip(self) -> bool:
         return isinstance(getattr(self.owner, "lip_model", None), nn.Module)
 
+    def _precision(self) -> str:
+        return self.precision or getattr(self.owner, "precision", "fp32")
+
+    def _lib(self):
+        return _lib.load(half=self._precision() in ("fp16", "f16"))
+
     def _ensure(self, device) -> None:
-        lib = _lib.load()
+        prec = self._precision()
+        lib = self._lib()
         params = self._params()
-        sig = (str(device), _lib.content_key(*params.values()))
+        sig = (str(device), prec, _lib.content_key(*params.values()))
         if self._ctx is not None and sig == self._sig:
             return
         self.release()
         cfg = _lib.A2PFrontendConfig(conv_dim=512, resample=int(self.resample == "sinc"), lip=int(self.has_lip), d_model=512, num_heads=4,
                                      ff_size=1024, enc_layers=2, dec_layers=4, lip_out=1014, lip_pad=320, chunk_frames=120,
-                                     samples_per_frame=1600, max_batch=self.max_batch, max_frames=self.max_frames)
+                                     samples_per_frame=1600, max_batch=self.max_batch, max_frames=self.max_frames,
+                                     conv_16bit=int(prec != "fp32"))
         ctx = C.c_void_p()
         with torch.cuda.device(device):
             _lib.check(lib.a2p_frontend_create(C.byref(cfg), C.byref(ctx)), "a2p_frontend_create")
@@ -164,11 +178,11 @@ class NativeAudioFrontend:
                 keep.append(t)
                 _lib.check(lib.a2p_frontend_set_weight(ctx, name.encode(), _lib.ptr(t), t.numel(), stream), f"a2p_frontend_set_weight({name})")
             _lib.check(lib.a2p_frontend_finalize(ctx, stream), "a2p_frontend_finalize")
-        self._ctx, self._sig, self._keep = ctx, sig, list(params.values())
+        self._ctx, self._sig, self._keep, self._ctx_lib = ctx, sig, list(params.values()), lib
 
     def release(self) -> None:
         if self._ctx is not None:
-            _lib.load().a2p_frontend_destroy(self._ctx)
+            self._ctx_lib.a2p_frontend_destroy(self._ctx)   # the library build that created it
             self._ctx = None
 
     def __del__(self):
@@ -194,7 +208,7 @@ class NativeAudioFrontend:
         S = self.n_tokens(L)
         out = torch.empty(B, S, 1024, device=a.device, dtype=torch.float32)
         with _lib.on_device_of(a):
-            _lib.check(_lib.load().a2p_frontend_encode_audio(self._ctx, _lib.ptr(a), B, L, _lib.ptr(out), S, _lib.current_stream(a.device)),
+            _lib.check(self._ctx_lib.a2p_frontend_encode_audio(self._ctx, _lib.ptr(a), B, L, _lib.ptr(out), S, _lib.current_stream(a.device)),
                        "a2p_frontend_encode_audio")
         return out
 
@@ -205,7 +219,7 @@ class NativeAudioFrontend:
         B, L, S, Ca = a.shape[0], a.shape[1], ce.shape[1], ce.shape[2]
         out = torch.empty(B, S, Ca + 1014, device=a.device, dtype=torch.float32)
         with _lib.on_device_of(a):
-            _lib.check(_lib.load().a2p_frontend_encode_lip(self._ctx, _lib.ptr(a), B, L, _lib.ptr(ce), S, Ca, _lib.ptr(out),
+            _lib.check(self._ctx_lib.a2p_frontend_encode_lip(self._ctx, _lib.ptr(a), B, L, _lib.ptr(ce), S, Ca, _lib.ptr(out),
                                                            _lib.current_stream(a.device)), "a2p_frontend_encode_lip")
         return out
 

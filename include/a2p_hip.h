@@ -253,7 +253,10 @@ typedef struct a2p_frontend_config {
   int32_t chunk_frames;      /* 120 (model/diffusion.py:303) */
   int32_t samples_per_frame; /* 1600 at 48 kHz */
   int32_t max_batch, max_frames;
-  int32_t reserved[2];
+  int32_t conv_16bit;        /* 1: the two conv feature extractors (99 % of the front end's FLOPs) run on 16-bit MFMA operands -- IEEE half in
+                              * liba2p_hip_f16.so, bfloat16 in liba2p_hip.so -- with fp32 accumulation; 0: exact-fp32 MFMA (parity mode).
+                              * The resampler, the first conv layer's arithmetic and the lip regressor stay fp32 either way. */
+  int32_t reserved[1];
 } a2p_frontend_config;
 int a2p_frontend_create(const a2p_frontend_config* cfg, a2p_frontend_ctx** out);
 int a2p_frontend_destroy(a2p_frontend_ctx* ctx);

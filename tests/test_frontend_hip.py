@@ -98,3 +98,29 @@ def test_denoiser_takes_the_reference_audio_contract(dev, fmt):
     assert torch.equal(a, c)
     out = diffusion.ddim_sample_loop(cfg, (B, spec.nfeats, 1, T), clip_denoised=False, model_kwargs={"y": y}, noise=x)
     assert out.shape == (B, spec.nfeats, 1, T) and bool(torch.isfinite(out).all())
+
+
+@pytest.mark.parametrize("precision,tol", [("fp16", 1.6e-3), ("bf16", 1.3e-2)])   # measured: 8.0e-4 / 6.4e-3 (audio half)
+def test_front_end_16bit_conv_stack_vs_oracle(dev, precision, tol):
+    """The throughput modes run the conv feature extractors' GEMMs (layers 1..7 of both stacks) on 16-bit operands with fp32
+    accumulation; everything else of the front end stays fp32.  Bench shape (600 frames, 1998 tokens) against the fp32 oracle;
+    the gates are 2x the errors measured on the MI355X (profiles/r02_parity_tests.json)."""
+    from oracle import frontend_oracle as FO
+    _, model, _ = build("face", dev, "sinc", precision=precision)
+    sd = synthetic_frontend_state_dict(SEED, lip=True)
+    audio = synthetic_audio(SEED, 1, 600)
+    torch.set_num_threads(min(os.cpu_count() or 1, 32))
+    with torch.no_grad():
+        want = FO.encode_lip(audio, FO.encode_audio(audio, sd, FO.resample_sinc), sd, FO.resample_sinc)
+    got = model.audio_frontend(audio.to(dev)).cpu()
+    assert got.shape == want.shape and bool(torch.isfinite(got).all())
+    e = {"rel_l2": rel_l2(got, want), "max_norm": rel_max(got, want),
+         "audio_rel_l2": rel_l2(got[..., :1024], want[..., :1024]), "lip_rel_l2": rel_l2(got[..., 1024:], want[..., 1024:])}
+    record(f"frontend/sinc_T600_{precision}", **e)
+    assert max(e.values()) < tol, e
+    # fp32 front end on a 16-bit model stays available
+    from audio2photoreal_amd.model.audio_frontend import NativeAudioFrontend
+    fe32 = NativeAudioFrontend(model, resample="sinc", max_batch=B, max_frames=600, precision="fp32")
+    got32 = fe32(audio.to(dev)).cpu()
+    assert rel_l2(got32, want) < 1e-3
+    fe32.release()
