@@ -351,23 +351,67 @@ def run_pipeline(a, dev):
         spec, cfg, diff = models["pose"]
         y = {"cond_embed": feats, "keyframes": torch.zeros(B, nk, 104, device=dev), "mask": torch.ones(B, 1, 1, T, dtype=torch.bool, device=dev),
              "scale": torch.full((B,), 2.0, device=dev)}
+        torch.manual_seed(101)                        # guide uniforms + body x_T (the overlapped run draws them in another order)
         y["keyframes"] = _replace_keyframes({"y": y}, cfg).to(dev)
         mark("guide_tokens_and_vq_decode_ms")
         body = diff.ddim_sample_loop(cfg, (B, spec.nfeats, 1, T), clip_denoised=False, model_kwargs={"y": y})
         mark("body_ddim100_ms")
         spec, cfg, diff = models["face"]
         yf = {"cond_embed": face_ce, "scale": torch.full((B,), 10.0, device=dev)}
+        torch.manual_seed(202)
         face = diff.ddim_sample_loop(cfg, (B, spec.nfeats, 1, T), clip_denoised=False, model_kwargs={"y": yf})
         mark("face_ddim100_ms")
         assert bool(torch.isfinite(body).all()) and bool(torch.isfinite(face).all())
+        st["_out"] = (body, face)
         return st
-    once()                                    # contexts, weight upload, allocator warm-up
+    def overlapped():
+        """The same work with the dependency graph it actually has: the face model needs only the audio features, the body model
+        needs the guide's keyframes.  Face runs on one HIP stream; guide (one CU per sequence, latency-bound) -> VQ decode -> body on
+        another, so the guide transformer's 54 ms pass under the face model's denoising steps."""
+        guide.invalidate_cond()
+        for _, cfg_m, _ in models.values():
+            cfg_m.model.invalidate_cond()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        feats = models["pose"][1].model.audio_frontend.encode_audio(audio)
+        face_ce = models["face"][1].model.audio_frontend.encode_lip(audio, feats)
+        main = torch.cuda.current_stream(dev)
+        s_face, s_body = torch.cuda.Stream(dev), torch.cuda.Stream(dev)
+        s_face.wait_stream(main)
+        s_body.wait_stream(main)
+        with torch.cuda.stream(s_face):           # enqueued first: nothing on this stream ever blocks the host
+            spec, cfg, diff = models["face"]
+            yf = {"cond_embed": face_ce, "scale": torch.full((B,), 10.0, device=dev)}
+            torch.manual_seed(202)
+            face = diff.ddim_sample_loop(cfg, (B, spec.nfeats, 1, T), clip_denoised=False, model_kwargs={"y": yf})
+        with torch.cuda.stream(s_body):
+            spec, cfg, diff = models["pose"]
+            y = {"cond_embed": feats, "keyframes": torch.zeros(B, nk, 104, device=dev), "mask": torch.ones(B, 1, 1, T, dtype=torch.bool, device=dev),
+                 "scale": torch.full((B,), 2.0, device=dev)}
+            torch.manual_seed(101)
+            y["keyframes"] = _replace_keyframes({"y": y}, cfg).to(dev)
+            body = diff.ddim_sample_loop(cfg, (B, spec.nfeats, 1, T), clip_denoised=False, model_kwargs={"y": y})
+        main.wait_stream(s_face)
+        main.wait_stream(s_body)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        return dt, body, face
+
+    once().pop("_out")                        # contexts, weight upload, allocator warm-up
     st = once()
+    body_seq, face_seq = st.pop("_out")
     total = sum(st.values()) / 1e3
+    _, body_ov, face_ov = overlapped()
+    same = bool(torch.equal(body_ov, body_seq)) and bool(torch.equal(face_ov, face_seq))
+    assert same, "the two-stream schedule changed the samples"
+    ov = min(overlapped()[0] for _ in range(2))
     print(json.dumps({"metric": "end-to-end sec/sample: audio front end -> guide transformer -> body ddim100 -> face ddim100, 600 frames, from raw "
                                 "48 kHz audio (BASELINE configs[4] shape, one subject, one GPU)",
-                      "value": round(total / B, 5), "unit": "s/sample", "higher_is_better": False, "n_gpus": 1, "batch": B,
-                      "dtype": a.precision, "data": "synthetic", "total_s": round(total, 4),
+                      "value": round(min(total, ov) / B, 5), "unit": "s/sample", "higher_is_better": False, "n_gpus": 1, "batch": B,
+                      "dtype": a.precision, "data": "synthetic", "total_s": round(min(total, ov), 4),
+                      "sequential_total_s": round(total, 4), "overlapped_total_s": round(ov, 4), "overlapped_equals_sequential": same,
+                      "value_note": "overlapped = face on one HIP stream, guide -> VQ -> body on another (the face model does not depend on "
+                                    "the guide); stages_ms are the per-stage times of the sequential run",
                       "stages_ms": {k: round(v, 2) for k, v in st.items()}}))
 
 
