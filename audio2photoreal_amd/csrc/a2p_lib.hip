@@ -206,10 +206,10 @@ static GemmP gemm_base(const void* A, int64_t lda, const void* W, int64_t ldw, c
   return p;
 }
 
-template <typename T, int MT>
+template <typename T, int MT, int NB = 2>
 static int gemm_dispatch(KernelTimer& kt, const GemmP& p, hipStream_t s) {
   dim3 grid((p.N + 127) / 128, (p.M + 32 * MT - 1) / (32 * MT));
-#define A2P_GEMM(EPI, ACT, F32) A2P_LAUNCH(kt, (gemm_kernel<T, MT, EPI, ACT, F32>), grid, 256, s, p)
+#define A2P_GEMM(EPI, ACT, F32) A2P_LAUNCH(kt, (gemm_kernel<T, MT, EPI, ACT, F32, NB>), grid, 256, s, p)
   if (p.epi == EPI_FILM_RES) A2P_GEMM(EPI_FILM_RES, ACT_NONE, false);
   else if (p.epi == EPI_STORE_T && p.act == ACT_NONE) A2P_GEMM(EPI_STORE_T, ACT_NONE, false);
   else if (p.epi == EPI_CONV && p.act == ACT_LRELU && !p.out_f32) A2P_GEMM(EPI_CONV, ACT_LRELU, false);
@@ -236,7 +236,12 @@ static int launch_gemm(a2p_ctx* c, const GemmP& p, hipStream_t s) {
   const bool small = c->bf16 || blocks128 < 512;
   KernelTimer kt(c, A2P_KERNEL_GEMM);
   int rc;
-  if (c->bf16) rc = small ? gemm_dispatch<bf16_t, 2>(kt, p, s) : gemm_dispatch<bf16_t, 4>(kt, p, s);
+  // 16-bit launches of at most one 64x128 workgroup per CU (config 0: 480 rows) are K/64 serial memory round trips with the
+  // 2-deep ring; they take the 4-deep one (A2P_GEMM_RING2=1 keeps the 2-deep ring for A/B runs)
+  static const bool ring2 = getenv("A2P_GEMM_RING2") != nullptr;
+  const int64_t blocks64 = (int64_t)((p.N + 127) / 128) * ((p.M + 63) / 64);
+  if (c->bf16 && small && blocks64 <= 256 && p.ntaps == 1 && !ring2) rc = gemm_dispatch<bf16_t, 2, 4>(kt, p, s);
+  else if (c->bf16) rc = small ? gemm_dispatch<bf16_t, 2>(kt, p, s) : gemm_dispatch<bf16_t, 4>(kt, p, s);
   else rc = small ? gemm_dispatch<float, 2>(kt, p, s) : gemm_dispatch<float, 4>(kt, p, s);
   CHK(rc);
   HIPCHK(hipGetLastError());

@@ -190,14 +190,18 @@ __device__ __forceinline__ void glds16(const bf16_t* gsrc, bf16_t* lds_wave_base
                                    (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
 }
 
-template <int MT>
+// NB: depth of the tile ring.  2 = the next k-tile is requested while the current one is consumed (several workgroups per CU hide
+// each other's waits: the large launches).  4 = three k-tiles in flight with a counted vmcnt wait: for launches of at most one
+// workgroup per CU -- the 480-row forwards of BASELINE configs[0] -- whose time is K/64 serial HBM/L2 round trips otherwise.
+template <int MT, int NB = 2>
 __device__ __forceinline__ void gemm_mainloop_bf16(const GemmP& p, f32x4 (&acc)[MT][4], int m0, int n0) {
   using P = Prec<bf16_t>;
   constexpr int BM = 32 * MT, BN = 128, BK = 64;
   constexpr int AI = BM / 32;  // glds instructions per wave for the A tile (8 rows each, 4 waves)
-  __shared__ __attribute__((aligned(16))) bf16_t smem[2 * (BM + BN) * BK];
+  constexpr int PCS = AI + 4;  // DMA instructions per wave per k-tile
+  __shared__ __attribute__((aligned(16))) bf16_t smem[NB * (BM + BN) * BK];
   bf16_t* const As0 = smem;
-  bf16_t* const Ws0 = smem + 2 * BM * BK;
+  bf16_t* const Ws0 = smem + NB * BM * BK;
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, l15 = lane & 15, g = lane >> 4;
   const int wm = wid >> 1, wn = wid & 1;
   const bf16_t* __restrict__ A = reinterpret_cast<const bf16_t*>(p.A);
@@ -241,11 +245,24 @@ __device__ __forceinline__ void gemm_mainloop_bf16(const GemmP& p, f32x4 (&acc)[
 #pragma unroll
   for (int j = 0; j < 4; ++j) w_row[j] = wn * 64 + j * 16 + l15;
 
-  stage(0, 0);
+#pragma unroll
+  for (int i = 0; i < NB - 1; ++i)
+    if (i < total) stage(i, i);
+  int buf = 0, nbuf = NB - 1;   // ring slots of tile `it` and of tile it + NB - 1
   for (int it = 0; it < total; ++it) {
-    const int buf = it & 1;
-    __syncthreads();  // drains vmcnt(0): tile `it` has landed; everyone finished reading buffer buf^1
-    if (it + 1 < total) stage(it + 1, buf ^ 1);
+    if constexpr (NB == 2) {
+      __syncthreads();  // drains vmcnt(0): tile `it` has landed; everyone finished reading buffer buf^1
+    } else {
+      // loads return in issue order: this wave's pieces of tile `it` are in once at most the pieces of the tiles requested after
+      // it are outstanding (exactly min(NB - 2, total - 1 - it) tiles); the barrier publishes every wave's pieces and frees the
+      // slot of tile it - 1 for the request below
+      const int rem = total - 1 - it;
+      if (rem >= 2) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(2 * PCS) : "memory");
+      else if (rem == 1) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(PCS) : "memory");
+      else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+      static_assert(NB == 2 || NB == 4, "ring depths 2 and 4");
+    }
+    if (it + NB - 1 < total) stage(it + NB - 1, nbuf);
     const bf16_t* Ab = As0 + buf * BM * BK;
     const bf16_t* Wb = Ws0 + buf * BN * BK;
 #pragma unroll
@@ -262,10 +279,12 @@ __device__ __forceinline__ void gemm_mainloop_bf16(const GemmP& p, f32x4 (&acc)[
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = P::mfma(wf[j], af[i], acc[i][j]);
     }
+    buf = buf + 1 == NB ? 0 : buf + 1;
+    nbuf = nbuf + 1 == NB ? 0 : nbuf + 1;
   }
 }
 
-template <typename T, int MT, int EPI, int ACT, bool OUTF32>
+template <typename T, int MT, int EPI, int ACT, bool OUTF32, int NB = 2>
 __global__ __launch_bounds__(256) void gemm_kernel(GemmP p) {
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
   const int m0 = blockIdx.y * (32 * MT), n0 = blockIdx.x * 128;
@@ -274,7 +293,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmP p) {
   for (int i = 0; i < MT; ++i)
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-  if constexpr (sizeof(T) == 2) gemm_mainloop_bf16<MT>(p, acc, m0, n0);
+  if constexpr (sizeof(T) == 2) gemm_mainloop_bf16<MT, NB>(p, acc, m0, n0);
   else gemm_mainloop_f32<MT>(p, acc, m0, n0);
   gemm_epilogue<T, MT, EPI, ACT, OUTF32>(p, acc, m0 + (wid >> 1) * 16 * MT, n0 + (wid & 1) * 64, lane & 15, lane >> 4);
 }
