@@ -718,12 +718,18 @@ __device__ __forceinline__ void chain_body(const ChainP& p, bf16_t* const smem, 
             for (int mt = 0; mt < MT; ++mt) {
               const f32x4 v = acc[mt][0];
               const bf16x4 o = {(bf16_t)v[0], (bf16_t)v[1], (bf16_t)v[2], (bf16_t)v[3]};
-              const uint32_t wa = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) bf16_t*)(stg + l15 * 32 + g * 4);
-              asm volatile("ds_write_b64 %0, %1\n\tds_write_b64 %0, %2 offset:32" ::"v"(wa), "v"(held[mt]), "v"(o) : "memory");
+              // [16 rows][32 columns] with the two 32-byte halves of rows 4..7 and 12..15 swapped: rows r, r+4, r+8, r+12 share
+              // their LDS banks (64-byte pitch), and un-swizzled the 16 rows of one ds_write_b64 hit the same 4 slots 4 times
+              // (scratch/lds_probe: 128 vs 32 cycles per instruction with 8 waves writing)
+              const int hsw = (l15 >> 2) & 1;
+              const uint32_t wa = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) bf16_t*)(stg + l15 * 32 + hsw * 16 + g * 4);
+              const uint32_t wb = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) bf16_t*)(stg + l15 * 32 + (hsw ^ 1) * 16 + g * 4);
+              asm volatile("ds_write_b64 %0, %2\n\tds_write_b64 %1, %3" ::"v"(wa), "v"(wb), "v"(held[mt]), "v"(o) : "memory");
               bf16x8 w;
+              const int prow = lane >> 2, pp = lane & 3;   // this lane stores piece pp (8 columns) of row prow
               asm volatile("s_waitcnt lgkmcnt(0)\n\tds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)"
                            : "=v"(w)
-                           : "v"((uint32_t)(uintptr_t)(__attribute__((address_space(3))) bf16_t*)(stg + lane * 8))
+                           : "v"((uint32_t)(uintptr_t)(__attribute__((address_space(3))) bf16_t*)(stg + prow * 32 + (((pp >> 1) ^ ((prow >> 2) & 1)) * 2 + (pp & 1)) * 8))
                            : "memory");
               if constexpr (ABL & 1) {
                 asm volatile("" ::"v"(w));
