@@ -12,7 +12,8 @@ typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
 
-enum { M_MFMA = 1, M_DMA = 2, M_GLOAD = 4, M_DSREAD = 8, M_STORE = 16, M_STORE_BULK = 32, M_STORE_NT = 64, M_KMAJOR = 128 };
+enum { M_MFMA = 1, M_DMA = 2, M_GLOAD = 4, M_DSREAD = 8, M_STORE = 16, M_STORE_BULK = 32, M_STORE_NT = 64, M_KMAJOR = 128, M_VALU9 = 256, M_VALU18 = 512 };
+// M_VALU9 / M_VALU18: 9 / 18 extra integer VALU instructions per stage (the address / ring bookkeeping the compiler emits in the real kernels)
 // M_KMAJOR: the A fragments are read once per k-step for a group of 4 output tiles (every 4th stage), the W fragments every stage
 // M_STORE: 3 x 1 KiB global stores per wave every 8 stages (one output tile of gemm_store); M_STORE_BULK: 12 stores every 32 stages
 constexpr int STAGES = 256;
@@ -38,6 +39,7 @@ __global__ __launch_bounds__(64 * NW, 1) void probe(const char* __restrict__ src
     fw[i] = fa[i];
   }
   u32x4 g[4] = {};
+  int vjunk[3] = {lane, lane + 1, lane + 2};
   __syncthreads();
   const unsigned long long t0 = __builtin_readcyclecounter();   // s_memtime
   const unsigned long long r0 = wall_clock64();                 // s_memrealtime, 100 MHz
@@ -112,6 +114,10 @@ __global__ __launch_bounds__(64 * NW, 1) void probe(const char* __restrict__ src
         nw[i] = *reinterpret_cast<const bf16x8*>(slot + ((lane * 16 + i * 512) & (PCS * 1024 - 1)));
       }
     }
+    if constexpr (MODE & (M_VALU9 | M_VALU18)) {
+      constexpr int NV = (MODE & M_VALU18) ? 18 : 9;
+      _Pragma("unroll") for (int i = 0; i < NV; ++i) asm volatile("v_add_u32 %0, %0, %1" : "+v"(vjunk[i % 3]) : "v"(lane));
+    }
     if constexpr (MODE & M_MFMA) {
       _Pragma("unroll") for (int i = 0; i < NMFMA; ++i)
         acc[i % 6] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ca[i % 5], cw[(i + 2) % 5], acc[i % 6], 0, 0, 0);
@@ -148,6 +154,7 @@ __global__ __launch_bounds__(64 * NW, 1) void probe(const char* __restrict__ src
   _Pragma("unroll")
   for (int i = 0; i < 4; ++i) v += (float)g[i][0];
   if (v == 1.2345f) sink[0] = v;
+  if (vjunk[0] + vjunk[1] + vjunk[2] == 0x7fffffff) sink[1] = 1.f;
   if (lane == 0) {
     out[(blockIdx.x * NW + wid) * 2 + 0] = t1 - t0;
     out[(blockIdx.x * NW + wid) * 2 + 1] = r1 - r0;
@@ -180,6 +187,9 @@ void all(const char* src, unsigned long long* dout, float* sink, int blocks) {
   run<M_MFMA | M_DMA | M_DSREAD, NW>("mfma + dma + ds_read (the kernel)", src, dout, sink, blocks);
   run<M_MFMA | M_GLOAD | M_DSREAD, NW>("mfma + gload + ds_read", src, dout, sink, blocks);
   run<M_DMA | M_DSREAD, NW>("dma + ds_read", src, dout, sink, blocks);
+  run<M_MFMA | M_DMA | M_DSREAD | M_VALU9, NW>("kernel + 9 VALU per stage", src, dout, sink, blocks);
+  run<M_MFMA | M_DMA | M_DSREAD | M_VALU18, NW>("kernel + 18 VALU per stage", src, dout, sink, blocks);
+  run<M_MFMA | M_VALU18, NW>("mfma + 18 VALU per stage", src, dout, sink, blocks);
   run<M_MFMA | M_DMA | M_DSREAD | M_KMAJOR, NW>("kernel, A frags once per 4 tiles", src, dout, sink, blocks);
   run<M_MFMA | M_DSREAD | M_KMAJOR, NW>("mfma + ds_read, A once per 4", src, dout, sink, blocks);
   run<M_MFMA | M_DMA | M_DSREAD | M_STORE, NW, 0>("kernel + store/8 coalesced", src, dout, sink, blocks);
