@@ -91,12 +91,16 @@ __device__ __forceinline__ void attn_glds16(const bf16_t* gsrc, bf16_t* lds_wave
 // v_permlane32_swap / v_permlane16_swap exchange whole 32- / 16-lane halves between two registers in the VALU, where
 // __shfl_xor goes through ds_bpermute_b32 (an LDS round trip of ~100 cycles, four of them serialised per 64-key tile).
 __device__ __forceinline__ float attn_rowgroup_max(float v) {
+  // plain v_max_f32 through inline asm: fmaxf() on the bit-cast halves made hipcc canonicalise both operands first (4 extra VALU
+  // instructions per call; the scores are finite or -inf here, never signalling NaNs)
   const unsigned u = __float_as_uint(v);
   const auto a = __builtin_amdgcn_permlane32_swap(u, u, false, false);   // a[0] = {lo, lo}, a[1] = {hi, hi}
-  const float m = fmaxf(__uint_as_float(a[0]), __uint_as_float(a[1]));
-  const unsigned w = __float_as_uint(m);
+  unsigned w;
+  asm("v_max_f32 %0, %1, %2" : "=v"(w) : "v"(a[0]), "v"(a[1]));
   const auto b = __builtin_amdgcn_permlane16_swap(w, w, false, false);   // rows {0,0,2,2} and {1,1,3,3}
-  return fmaxf(__uint_as_float(b[0]), __uint_as_float(b[1]));
+  unsigned r;
+  asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(b[0]), "v"(b[1]));
+  return __uint_as_float(r);
 }
 
 // ABL: ablation switches for scratch/attn_bench.hip only (the library instantiates ABL = 0):
