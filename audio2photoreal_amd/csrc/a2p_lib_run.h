@@ -176,7 +176,7 @@ static int chain_build_streams(a2p_ctx* c, hipStream_t s) {
     const Buf& w2 = c->wt.at(pf(l) + "linear2.weight");
     for (int h = 0; h < ff / 128; ++h) {
       for (int ks = 0; ks < d / 64; ++ks) q.push_back({reinterpret_cast<const bf16_t*>(w1.p), d, h * 128, ks * 64, ff, 0});
-      for (int ks = 0; ks < 2; ++ks)   // k-major over the d/128 output tiles (chain_body::ffn2_kmajor)
+      for (int ks = 0; ks < 2; ++ks)   // k-major over the d/128 output tiles (chain_body::gemm_group)
         for (int t = 0; t < d / 128; ++t) q.push_back({reinterpret_cast<const bf16_t*>(w2.p), ff, t * 128, h * 128 + ks * 64, d, 0});
     }
     std::vector<std::pair<const float*, int>> aux = {{W32(c, pf(l) + "linear1.bias"), ff}};

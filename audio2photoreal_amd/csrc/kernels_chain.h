@@ -31,6 +31,16 @@
 // Wave w owns output columns [tile*128 + w*32, +32) of every 128-column tile, all BM rows: MT x 2 MFMA
 // 16x16x32 fragments per k-chunk.  Accumulator layout (operands swapped, D = C^T): lane (l15 = lane & 15,
 // g = lane >> 4) holds C[m = mt*16 + l15][n = ... + j*16 + g*4 + r], r = 0..3.
+//
+// Round 2 on top of that (each one bit-identical to the form it replaced; DESIGN.md section 4.1 has the measurements):
+//   * two workgroup shapes, 4 waves x 512 registers or 8 waves x 256 (NW), same bits, chosen per box at run time;
+//   * out_proj and the linear2 partials run as k-major GROUP GEMMs over all output tiles (gemm_group): the panel fragments of a
+//     k-step are read once for the group, one pipeline ramp per group;
+//   * every store writes >= 64 contiguous bytes per row: V^T tiles and (8 waves) Q/K/V tile pairs are transposed through a
+//     wave-private slice of the idle hidden-chunk buffer, the 8-wave shape owns its columns under a paired map;
+//   * the fp32 residual rows are tiled per 16-row block between chain kernels (one 1 KiB run per load / store instruction) and
+//     stored last; the rotary table comes in the matching panel layout;
+//   * chain_kernel_mix launches two panel heights at once so that large forwards fill whole rounds of the 256 CUs.
 #pragma once
 #include "a2p_common.h"
 
