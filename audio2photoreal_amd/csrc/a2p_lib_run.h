@@ -235,7 +235,7 @@ static int chain_pick_nw(a2p_ctx* c, int64_t rows, hipEvent_t* e0, hipEvent_t* e
   if (const char* f = getenv("A2P_CHAIN_NW")) return atoi(f) == 8 ? 8 : 4;
   if (const char* m = getenv("A2P_CHAIN_MT")) {  // a forced panel height the 8-wave kernels do not have
     const int mt = atoi(m);
-    if (mt > 4) return 4;
+    if ((mt > 4 && c->d == 512) || mt > 5) return 4;
   }
   auto& t = c->ch_tune[rows];
   if (t.choice) return t.choice;
@@ -270,10 +270,10 @@ static int launch_chain(a2p_ctx* c, int mode, const ChainP& p, hipStream_t s) {
   int mt = env_mt ? atoi(env_mt) : 0;
   // panel heights instantiated per width (LDS: the [16*MT][d] bf16 panel + hidden chunk + >= 3 ring slots must fit 160 KiB)
   static const int kMt512[] = {4, 3, 2}, kMt256[] = {6, 5, 4, 3, 2};
-  static const int kMt512w8[] = {4, 3, 2}, kMt256w8[] = {4, 3, 2};  // 8 waves: 256 registers per wave bound the panel height
+  static const int kMt512w8[] = {4, 3, 2}, kMt256w8[] = {5, 4, 3, 2};  // 8 waves: 256 registers per wave bound the panel height (d = 256, 96 rows: 46 spilled)
   const bool w8 = c->ch_nw == 8;
   const int* cands = c->d == 512 ? (w8 ? kMt512w8 : kMt512) : (w8 ? kMt256w8 : kMt256);
-  const int ncand = c->d == 512 ? 3 : (w8 ? 3 : 5);
+  const int ncand = c->d == 512 ? 3 : (w8 ? 4 : 5);
   bool ok = false;
   for (int i = 0; i < ncand; ++i) ok = ok || cands[i] == mt;
   if (!ok) {  // fewest rounds over the 256 CUs, then the cheaper (shorter) panel: every panel streams all weights once.
@@ -327,7 +327,8 @@ static int launch_chain(a2p_ctx* c, int mode, const ChainP& p, hipStream_t s) {
     } else {
       if (mt == 2) A2P_CHAIN_W(256, 2, 8);
       else if (mt == 3) A2P_CHAIN_W(256, 3, 8);
-      else A2P_CHAIN_W(256, 4, 8);
+      else if (mt == 4) A2P_CHAIN_W(256, 4, 8);
+      else A2P_CHAIN_W(256, 5, 8);
     }
   } else if (c->d == 512) {
     if (mt == 2) A2P_CHAIN(512, 2);
