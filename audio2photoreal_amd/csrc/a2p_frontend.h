@@ -217,7 +217,22 @@ extern "C" int a2p_frontend_set_weight(a2p_frontend_ctx* f, const char* name, co
   ARG(f && name && dev_ptr, "null argument");
   const std::string n(name);
   auto it = f->expect.find(n);
-  if (it == f->expect.end()) return 1;  // other audio_model.* / lip_model.* tensors of a checkpoint (aggregator, quantiser): not on this path
+  if (it == f->expect.end()) {
+    // Tensors the reference's conditioning path reads but this geometry does not implement (fairseq's GroupNorm affine terms
+    // conv_layers.{i}.2.*, the lip encoder's feature_aggregator.*, audio_encoder.py:43-44) are an error: skipping them would
+    // change the features silently.  Other audio_model.* / lip_model.* tensors (quantiser, prediction heads, the vq-wav2vec
+    // aggregator encode_audio never calls) are not read by the reference on this path either: 1 = skipped.
+    static const char* on_path[] = {"audio_model.feature_extractor.", "lip_model.audio_encoder.wav2vec_model.feature_extractor.",
+                                    "lip_model.audio_encoder.wav2vec_model.feature_aggregator.", "lip_model.regression_model.",
+                                    "lip_model.project_output."};
+    for (const char* p : on_path)
+      if (n.rfind(p, 0) == 0 && (f->cfg.lip || n.rfind("lip_model.", 0) != 0)) {
+        set_err("front end: parameter '%s' is on the conditioning path but not implemented by the stub geometry (bias-free conv + ReLU, "
+                "identity aggregator); refusing to skip it", name);
+        return A2P_ERR_NOWEIGHT;
+      }
+    return 1;
+  }
   if (it->second != numel) {
     set_err("front-end parameter '%s': expected %lld elements, got %lld", name, (long long)it->second, (long long)numel);
     return A2P_ERR_NOWEIGHT;

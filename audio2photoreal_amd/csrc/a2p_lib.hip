@@ -132,6 +132,11 @@ struct a2p_ctx {
   bool use_arena = true;
   int d, H, DH, L, C, Cpad, ff, F, Fc, FcPad, Kd, KdPad, Tmax, Tld, S0max, Sld, Bmax, Nmax, KFmax;
   bool bf16, pose;
+  // 16-bit modes: the operand classes that carry the error of the sampling LOOP's return value stay exact fp32 (error budget in
+  // profiles/r03_error_budget*.json: final_layer's operand rows alone are 3.05e-3 of the 3.11e-3 loop error of the face model,
+  // the dilated conv tail 7e-4 of the body model's 8.2e-4): input_projection, final_layer and the pose conv tail run as
+  // exact-fp32 MFMA GEMMs on fp32 buffers (< 3 % of a step's FLOPs).  A2P_TAIL16=1 restores the all-16-bit path for A/B runs.
+  bool tail32 = false;
   size_t esz;
   int64_t rows_cap, conv_rows;
   std::map<std::string, Buf> w;   // fp32 parameters by reference state_dict key
@@ -169,6 +174,19 @@ struct a2p_ctx {
 
   void* offT(const Buf& b, int64_t elems) const { return reinterpret_cast<char*>(b.p) + elems * (int64_t)esz; }
   void* offT(void* p, int64_t elems) const { return reinterpret_cast<char*>(p) + elems * (int64_t)esz; }
+};
+
+// RAII: inside the scope the launch helpers (launch_gemm, launch_cast, make_wt, offT) treat the context as an fp32 one --
+// the exact-fp32 islands of the 16-bit modes (a2p_ctx::tail32)
+struct Fp32Scope {
+  a2p_ctx* c;
+  bool on, saved;
+  Fp32Scope(a2p_ctx* ctx, bool enable) : c(ctx), on(enable), saved(ctx->bf16) {
+    if (on) { c->bf16 = false; c->esz = 4; }
+  }
+  ~Fp32Scope() {
+    if (on) { c->bf16 = saved; c->esz = saved ? 2 : 4; }
+  }
 };
 
 // ------------------------------------------------------------------------------------------------
@@ -425,6 +443,8 @@ extern "C" int a2p_ctx_create(const a2p_config* cfg, a2p_ctx** out) {
   c->Bmax = cfg->max_batch; c->Nmax = 2 * c->Bmax;
   c->KFmax = (c->Tmax + cfg->keyframe_step - 1) / cfg->keyframe_step;
   c->bf16 = cfg->precision == A2P_PREC_BF16; c->esz = c->bf16 ? 2 : 4;
+  c->tail32 = c->bf16 && !getenv("A2P_TAIL16");
+  const size_t tsz = c->tail32 ? 4 : c->esz;   // element size of the exact-fp32 islands' buffers
   ARG(c->KFmax <= 64, "too many keyframes");
   const int64_t r1 = (int64_t)c->Nmax * c->Tmax, r2 = (int64_t)c->Bmax * c->S0max;
   c->rows_cap = (r1 > r2 ? r1 : r2) + 128;
@@ -435,11 +455,11 @@ extern "C" int a2p_ctx_create(const a2p_config* cfg, a2p_ctx** out) {
   A(c->x, R * d * 4); A(c->xn, R * d * c->esz); A(c->xr, R * d * c->esz); A(c->qk, R * 2 * d * c->esz);
   A(c->ao, R * d * c->esz); A(c->hff, R * c->ff * c->esz);
   A(c->vt, (size_t)c->Nmax * d * c->Tld * c->esz);
-  A(c->inpack, (size_t)c->Bmax * c->Tmax * c->Cpad * c->esz);
+  A(c->inpack, (size_t)c->Bmax * c->Tmax * c->Cpad * tsz);
   A(c->mo, (size_t)c->conv_rows * c->C * 4);
   if (c->pose) {
-    A(c->cb[0], (size_t)c->conv_rows * 128 * c->esz); A(c->cb[1], (size_t)c->conv_rows * 256 * c->esz);
-    A(c->cb[2], (size_t)c->conv_rows * 128 * c->esz); A(c->cb[3], (size_t)c->conv_rows * 128 * c->esz);
+    A(c->cb[0], (size_t)c->conv_rows * 128 * tsz); A(c->cb[1], (size_t)c->conv_rows * 256 * tsz);
+    A(c->cb[2], (size_t)c->conv_rows * 128 * tsz); A(c->cb[3], (size_t)c->conv_rows * 128 * tsz);
   }
   const int64_t B = c->Bmax, N = c->Nmax, LF = (int64_t)c->L * c->F;
   A(c->emb, B * d * 4); A(c->th, B * 4 * d * 4); A(c->tct, B * 3 * d * 4); A(c->tvec, N * d * 4); A(c->mt, N * d * 4);
@@ -582,9 +602,12 @@ extern "C" int a2p_finalize_weights(a2p_ctx* c, void* stream) {
     HIPCHK(hipMemcpy(c->time_freq.p, tf.data(), half * 4, hipMemcpyHostToDevice));
   }
   // compute-dtype copies of every GEMM weight
-  CHK(make_wt(c, "input_projection.weight", W32(c, "input_projection.weight"), d, c->C, s));
+  {
+    Fp32Scope f32(c, c->tail32);
+    CHK(make_wt(c, "input_projection.weight", W32(c, "input_projection.weight"), d, c->C, s));
+    CHK(make_wt(c, "final_layer.weight", W32(c, "final_layer.weight"), c->C, d, s));
+  }
   CHK(make_wt(c, "cond_projection.weight", W32(c, "cond_projection.weight"), d, c->Fc, s));
-  CHK(make_wt(c, "final_layer.weight", W32(c, "final_layer.weight"), c->C, d, s));
   if (c->pose) CHK(make_wt(c, "frame_cond_projection.weight", W32(c, "frame_cond_projection.weight"), d, c->Kd, s));
   auto attn_wt = [&](const std::string& p) -> int {
     CHK(make_wt(c, p + ".in_proj_weight", W32(c, p + ".in_proj_weight"), 3 * d, d, s));
@@ -664,6 +687,7 @@ extern "C" int a2p_finalize_weights(a2p_ctx* c, void* stream) {
     // conv tail weights [Co, Ci, 3] -> [tap][Co][CiPad]
     const int C = c->C, hid = C > 256 ? C : 256;
     const int ci[7] = {C, hid, C, C, C, C, C}, co[7] = {hid, C, C, C, C, C, C};
+    Fp32Scope f32(c, c->tail32);
     for (int i = 0; i < 7; ++i) {
       const int taps = i < 6 ? 3 : 1, cip = rup(ci[i], 64);
       const std::string nm = i < 6 ? "post_pose_layers." + std::to_string(i) + ".weight" : "final_conv.weight";

@@ -183,7 +183,7 @@ static int chain_build_streams(a2p_ctx* c, hipStream_t s) {
     if (l + 1 < L) {
       add_pre(q, l + 1);
       aux.push_back({W32(c, pf(l + 1) + "self_attn.in_proj_bias"), 3 * d});
-    } else if (!c->pose) {  // last layer of the face model: final_layer rides on the same stream (pose feeds the conv tail instead)
+    } else if (!c->pose && !c->tail32) {  // A2P_TAIL16: final_layer of the face model rides on the last stream (16-bit operands)
       pk_gemm(q, c->wt.at("final_layer.weight").p, d, c->C, d);
       aux.push_back({W32(c, "final_layer.bias"), c->C});
     }
@@ -610,15 +610,16 @@ static int run_forward(a2p_ctx* c, const float* x_in, const int64_t* t_orig, int
   } else {
     CHK(time_path(c, t_orig, N, slots, s));
   }
-  // input permute + projection (model/diffusion.py:345-346,364)
+  // input permute + projection (model/diffusion.py:345-346,364); exact fp32 in every mode (a2p_ctx::tail32)
   {
+    Fp32Scope f32(c, c->tail32);
     dim3 grid((T + 31) / 32, (c->Cpad + 31) / 32, B);
     if (c->bf16) pack_input_kernel<bf16_t><<<grid, 256, 0, s>>>(x_in, (bf16_t*)c->inpack.p, B, c->C, T, c->Cpad);
     else pack_input_kernel<float><<<grid, 256, 0, s>>>(x_in, (float*)c->inpack.p, B, c->C, T, c->Cpad);
     const bool shared_half = use_chain && N == 2 * B && !getenv("A2P_NO_SHARED_HALF");
     GemmP p = gemm_base(c->inpack.p, c->Cpad, c->wt.at("input_projection.weight").p, c->Cpad, W32(c, "input_projection.bias"),
                         shared_half ? c->hff.p : c->x.p, d, B * T, d, c->Cpad);
-    p.out_f32 = 1;
+    p.out_f32 = c->bf16 ? 1 : 0;   // gemm_kernel<float> stores fp32 either way; the flag only selects a 16-bit kernel instance
     CHK(launch_gemm(c, p, s));
     if (N == 2 * B && !shared_half) {   // chain path under guidance: layer 0 reads the one copy for both halves (decoder_layer_chain)
       const int64_t n4 = (int64_t)B * T * d / 4;
@@ -648,23 +649,29 @@ static int run_forward(a2p_ctx* c, const float* x_in, const int64_t* t_orig, int
     fr.seq_stride = (int64_t)L * F * 2 * d;
     if (use_chain)
       CHK(decoder_layer_chain(c, l, N, T, kv, c->pose ? &kv2 : nullptr, fr, l == 0, l + 1 < L, s, (overlap_tpath && l == 0) ? c->ev_join : nullptr,
-                              /*fuse_final=*/!c->pose, /*shared_half=*/l == 0 && N == 2 * B && !getenv("A2P_NO_SHARED_HALF")));
+                              /*fuse_final=*/!c->pose && !c->tail32, /*shared_half=*/l == 0 && N == 2 * B && !getenv("A2P_NO_SHARED_HALF")));
     else CHK(decoder_layer(c, l, N, T, kv, c->pose ? &kv2 : nullptr, fr, s));
   }
   if (tune1) HIPCHK(hipEventRecord(tune1, s));
-  // final_layer (model/diffusion.py:397): cast the stream, GEMM   (face + chain mode: already done by the last POST kernel)
-  if (use_chain && !c->pose) {
+  // final_layer (model/diffusion.py:397)   (A2P_TAIL16 + face + chain mode: already done by the last POST kernel)
+  if (use_chain && !c->pose && !c->tail32) {
     *mo_seq_rows = T;
     return 0;
   }
-  CHK(launch_ln_rope(c, false, c->x.f(), d, nullptr, nullptr, c->xn.p, nullptr, d, N * T, T, 0, s));
+  // fp32 GEMMs read the residual stream in place; the all-16-bit variant casts it first
+  Fp32Scope f32(c, c->tail32);
+  const void* rows = c->x.p;
+  if (c->bf16) {
+    CHK(launch_ln_rope(c, false, c->x.f(), d, nullptr, nullptr, c->xn.p, nullptr, d, N * T, T, 0, s));
+    rows = c->xn.p;
+  }
   if (!c->pose) {
-    GemmP p = gemm_base(c->xn.p, d, c->wt.at("final_layer.weight").p, d, W32(c, "final_layer.bias"), c->mo.p, c->C, N * T, c->C, d);
-    p.out_f32 = 1;
+    GemmP p = gemm_base(rows, d, c->wt.at("final_layer.weight").p, d, W32(c, "final_layer.bias"), c->mo.p, c->C, N * T, c->C, d);
+    p.out_f32 = c->bf16 ? 1 : 0;
     CHK(launch_gemm(c, p, s));
     *mo_seq_rows = T;
   } else {
-    GemmP p = gemm_base(c->xn.p, d, c->wt.at("final_layer.weight").p, d, W32(c, "final_layer.bias"), c->offT(c->cb[0], (int64_t)24 * 128),
+    GemmP p = gemm_base(rows, d, c->wt.at("final_layer.weight").p, d, W32(c, "final_layer.bias"), c->offT(c->cb[0], (int64_t)24 * 128),
                         128, N * T, c->C, d);
     p.rows_per_seq = T;
     p.out_seq_pad = 24;

@@ -12,10 +12,13 @@ owner model's precision -- the conv stacks' GEMMs on 16-bit operands).
   lip_model     Audio2LipRegressionTransformer (model/diffusion.py:37-79): Wav2VecEncoder (audio_encoder.py:24-46) +
                 RegressionTransformer (transformer_modules.py:560-627) + Linear(512, 1014).
 
-fairseq and torchaudio are absent offline: the conv stacks use the published layer geometry (bias-free Conv1d + ReLU), the
-resampler is torchaudio's documented windowed-sinc kernel ("sinc", default) or the 3:1 decimation of the golden generator's
-stub ("decimate").  Everything that IS in the reference tree -- the regression transformer, chunking, interpolation, concat --
-is pinned by reference-generated goldens (tests/golden/golden_frontend_v1.npz).
+fairseq and torchaudio are absent offline: the conv stacks implement the STUB geometry of SURVEY.md Appendix A (8 bias-free
+Conv1d + ReLU layers, identity aggregator) -- the published layer shapes WITHOUT fairseq's per-layer GroupNorm, log
+compression and the lip encoder's ConvAggregator -- and the resampler is torchaudio's documented windowed-sinc kernel ("sinc",
+default) or the 3:1 decimation of the golden generator's stub ("decimate").  Everything that IS in the reference tree -- the
+regression transformer, chunking, interpolation, concat -- is pinned by reference-generated goldens
+(tests/golden/golden_frontend_v1.npz).  A real fairseq checkpoint carries tensors this geometry does not consume; the ones
+that sit on the conditioning path are REFUSED (`check_keys`, `a2p_frontend_set_weight`), never skipped.
 """
 from __future__ import annotations
 
@@ -29,6 +32,15 @@ import torch.nn as nn
 from .. import _lib
 
 CONV_GEOMETRY = ((10, 5), (8, 4), (4, 2), (4, 2), (4, 2), (1, 1), (1, 1), (1, 1))   # (kernel, stride), 512 channels
+
+# Sub-modules of the two wav2vec models whose tensors the reference's conditioning path READS (model/diffusion.py:285-313,
+# model/modules/audio_encoder.py:43-44): a checkpoint tensor under one of these that the native front end does not implement
+# changes the features, so it is an error.  Everything else under audio_model.* / lip_model.* (vector quantiser, the
+# vq-wav2vec aggregator that encode_audio never calls, the prediction heads, torchaudio's resampling kernel buffer -- recomputed
+# here) is not read by the reference on this path either and is skipped.
+ON_PATH_PREFIXES = ("audio_model.feature_extractor.", "lip_model.audio_encoder.wav2vec_model.feature_extractor.",
+                    "lip_model.audio_encoder.wav2vec_model.feature_aggregator.", "lip_model.regression_model.",
+                    "lip_model.project_output.")
 
 
 # ----------------------------------------------------------------------------- parameter containers (reference key layout)
@@ -137,6 +149,20 @@ class NativeAudioFrontend:
         self.owner, self.resample, self.max_batch, self.max_frames = owner, resample, max_batch, max_frames
         self.precision = precision
         self._ctx, self._sig, self._ctx_lib = None, None, None
+
+    def check_keys(self, unconsumed) -> None:
+        """`unconsumed`: checkpoint keys under audio_model.* / lip_model.* that the parameter containers do not hold.  Raises for
+        the ones on the conditioning path (ON_PATH_PREFIXES): fairseq's real ConvFeatureExtractionModel block is Conv1d -> Dropout ->
+        Fp32GroupNorm(1, 512) -> activation (+ log compression after the stack), and Wav2VecEncoder.forward also runs the 12-layer
+        ConvAggregator (audio_encoder.py:44); the native front end implements the stub geometry only."""
+        has_lip = self.has_lip
+        bad = sorted(k for k in unconsumed if k.startswith(ON_PATH_PREFIXES) and (has_lip or not k.startswith("lip_model.")))
+        if bad:
+            raise _lib.A2PError(
+                f"the native audio front end does not implement {len(bad)} checkpoint tensor(s) that sit on the conditioning path, e.g. "
+                f"{bad[:3]} (GroupNorm affine terms / feature aggregator of a real fairseq wav2vec checkpoint): loading would silently "
+                f"change the features.  Feed y['cond_embed'] computed by the reference's encode_audio / encode_lip instead "
+                f"(audio_frontend=None), or use weights exported for the stub geometry.")
 
     def _params(self):
         out = {}

@@ -7,16 +7,22 @@ from .diffusion import gaussian_diffusion as gd
 from .diffusion.respace import SpacedDiffusion, space_timesteps
 from .model.diffusion import FiLMTransformer
 
-_IGNORED_PREFIXES = ("audio_model.", "lip_model.")  # conditioning producers, outside the hot path
+_IGNORED_PREFIXES = ("audio_model.", "lip_model.")  # conditioning producers (the audio front end)
 
 
 def load_model(model, state_dict):
-    """Non-strict load with the reference's checks (utils/model_util.py:30-38): no unexpected keys
-    (the out-of-scope audio/lip front-end tensors of a reference checkpoint are skipped), and only
-    `transformer.` / `tokenizer.` keys may be missing."""
+    """Non-strict load with the reference's checks (utils/model_util.py:30-38): no unexpected keys, and only
+    `transformer.` / `tokenizer.` keys may be missing.
+
+    Front-end tensors (`audio_model.*`, `lip_model.*`): a model built WITHOUT the native front end is fed `y["cond_embed"]` and
+    skips them.  A model built with audio_frontend="native" owns those sub-models and computes the conditioning from them, so a
+    tensor that sits ON that path but is not implemented (fairseq's GroupNorm affine terms `conv_layers.{i}.2.*`, the lip
+    encoder's `feature_aggregator.*`) must not be dropped silently -- the features would differ from the reference's without
+    any error: `model.audio_frontend.check_keys` raises for those."""
     own = set(model.state_dict().keys())
-    # front-end tensors: loaded when the model was built with audio_frontend="native" (it then owns audio_model / lip_model);
-    # tensors of those sub-models that are not on the path (aggregator, quantiser, GroupNorm ...) are skipped either way
+    fe = getattr(model, "audio_frontend", None)
+    if fe is not None and hasattr(fe, "check_keys"):
+        fe.check_keys(k for k in state_dict if k.startswith(_IGNORED_PREFIXES) and k not in own)
     state_dict = {k: v for k, v in state_dict.items() if not k.startswith(_IGNORED_PREFIXES) or k in own}
     missing_keys, unexpected_keys = model.load_state_dict(state_dict, strict=False)
     assert len(unexpected_keys) == 0, unexpected_keys

@@ -14,7 +14,11 @@ from typing import Callable, Dict, Optional
 import numpy as np
 import torch
 
-from ..sample_parallel import per_sample_noise, sample_parallel, shared_base_seed
+import itertools
+
+from ..sample_parallel import derive_seed, per_sample_noise, sample_parallel, shared_base_seed
+
+_CALLS = itertools.count()   # sampling calls of this process: every rank makes the same calls in the same order
 
 
 def fixseed(seed: int) -> None:
@@ -100,26 +104,28 @@ def _replace_keyframes(model_kwargs, model, uniforms: Optional[torch.Tensor] = N
 
 
 def _run_single_diffusion(args, model_kwargs, diffusion, model, inv_transform: Callable, gt: Optional[torch.Tensor],
-                          noise: Optional[torch.Tensor] = None):
+                          noise: Optional[torch.Tensor] = None, rep_i: Optional[int] = None):
     """One ddim_sample_loop over the (possibly rank-sharded) batch + un-normalisation (reference :74-107).
 
-    Under torch.distributed every random draw is a function of (shared base seed, GLOBAL sample id): the initial noise via
-    `per_sample_noise`, the guide transformer's uniforms from one generator all ranks seed alike -- so the gathered result does
-    not depend on the world size, and the keyframes rank 0 saves are the ones every rank conditioned on."""
+    Under torch.distributed every random draw is a function of (shared base seed, repetition, GLOBAL sample id): the initial
+    noise via `per_sample_noise`, the guide transformer's uniforms from one generator all ranks seed alike -- so the gathered
+    result does not depend on the world size, the keyframes rank 0 saves are the ones every rank conditioned on, and every
+    repetition draws fresh noise like the reference's `randn` does (`rep_i`; default = this process's call counter)."""
     import torch.distributed as dist
     sharded = dist.is_available() and dist.is_initialized()
     base = shared_base_seed() if sharded else None
+    rep = next(_CALLS) if rep_i is None else int(rep_i)
     has_guide = getattr(args, "resume_trans", None) is not None or getattr(model, "resume_trans", None) is not None
     if args.data_format == "pose" and has_guide:   # reference :82-83
         y = model_kwargs["y"]
         uniforms = None
         if sharded:
             n = y["keyframes"].shape[1] * model.tokenizer.residual_depth
-            uniforms = torch.rand(n, y["keyframes"].shape[0], generator=torch.Generator().manual_seed(base ^ 0x6775696465))
+            uniforms = torch.rand(n, y["keyframes"].shape[0], generator=torch.Generator().manual_seed(derive_seed(base, rep, 0x6775696465)))
         y["keyframes"] = _replace_keyframes(model_kwargs, model, uniforms).to(y["keyframes"].device)
     shape = (args.batch_size, model.nfeats, 1, args.curr_seq_length)
     if noise is None and sharded:
-        noise = per_sample_noise(shape, [base + g for g in range(shape[0])])
+        noise = per_sample_noise(shape, [derive_seed(base, rep, g) for g in range(shape[0])])
     with torch.no_grad():
         sample = sample_parallel(diffusion.ddim_sample_loop, model, shape, model_kwargs, noise=noise,
                                  clip_denoised=False, init_image=None, progress=False, dump_steps=None, const_noise=False)
@@ -138,7 +144,8 @@ def _generate_sequences(args, model_kwargs, diffusion, model, inv_transform: Cal
         if args.guidance_param != 1:
             model_kwargs["y"]["scale"] = torch.ones(args.batch_size, device=args.device) * args.guidance_param
         model_kwargs["y"] = {k: v.to(args.device) if torch.is_tensor(v) else v for k, v in model_kwargs["y"].items()}
-        sample, curr_audio, keyframes, gt_seq = _run_single_diffusion(args, model_kwargs, diffusion, model, inv_transform, gt)
+        sample, curr_audio, keyframes, gt_seq = _run_single_diffusion(args, model_kwargs, diffusion, model, inv_transform, gt,
+                                                                      rep_i=rep_i)
         motions.append(sample.cpu().numpy())
         if curr_audio is not None:
             audio.append(curr_audio)

@@ -56,6 +56,23 @@ def shared_base_seed(group=None) -> int:
     return seed[0]
 
 
+def derive_seed(base: int, *ids: int) -> int:
+    """A 63-bit seed from (base, ids...), each component passed through the splitmix64 finaliser before it is folded in:
+    distinct (repetition, sample) pairs of one run AND the same pair under neighbouring base seeds get unrelated streams (a
+    plain `base + g` makes run s / sample 1 equal run s+1 / sample 0)."""
+    m = (1 << 64) - 1
+
+    def mix(x: int) -> int:
+        x = (x + 0x9E3779B97F4A7C15) & m
+        x = ((x ^ (x >> 30)) * 0xBF58476D1CE4E5B9) & m
+        x = ((x ^ (x >> 27)) * 0x94D049BB133111EB) & m
+        return x ^ (x >> 31)
+    h = mix(int(base) & m)
+    for v in ids:
+        h = mix(h ^ mix(int(v) & m))
+    return h & 0x7FFFFFFFFFFFFFFF
+
+
 def gather_samples(local: torch.Tensor, total: int, group=None) -> torch.Tensor:
     """The single end-of-run collective: all ranks receive all samples, in global order."""
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:

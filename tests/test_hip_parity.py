@@ -1,8 +1,8 @@
 """Parity of the HIP path (through the C ABI) against the golden vectors produced by the
 reference and against the pinned oracle.  Needs a real MI355X: `pytest -m gpu`.
 
-Tolerances: fp32 mode <= 1e-3 relative (north_star; observed ~1e-5..1e-4);
-bf16 mode is the throughput mode, its measured error is asserted loosely and printed.
+Tolerances: fp32 mode <= 1e-3 relative (north_star; observed ~1e-6..1e-5); the 16-bit throughput modes ("fp16" = the
+benchmarked one, "bf16") are gated at about 2x their measured errors, which the tests also write to gpurun_out/parity_tests.json.
 """
 import ctypes as C
 
@@ -19,7 +19,6 @@ from conftest import record, rel_l2, rel_max
 
 pytestmark = pytest.mark.gpu
 SEED = 10
-TOL = {"fp32": 1e-3, "bf16": 6e-2}
 
 
 @pytest.fixture(scope="module")
@@ -273,13 +272,14 @@ def test_properties_full_size(dev):
     assert torch.isfinite(full).all()
 
 
+@pytest.mark.parametrize("precision", ["bf16", "fp16"])
 @pytest.mark.parametrize("fmt,mt", [("face", "2"), ("face", "3"), ("face", "4"), ("pose", "2"), ("pose", "3"), ("pose", "5"), ("pose", "6")])
-def test_chain_kernels_match_the_per_op_kernels_bf16(dev, golden, fmt, mt, monkeypatch):
-    """bf16 mode runs the decoder layers as fused row-panel chain kernels (csrc/kernels_chain.h); the per-op
-    kernels (GEMM / LayerNorm launches) must give the same answer to bf16 rounding, for every panel height,
+def test_chain_kernels_match_the_per_op_kernels_16bit(dev, golden, fmt, mt, precision, monkeypatch):
+    """The 16-bit modes run the decoder layers as fused row-panel chain kernels (csrc/kernels_chain.h); the per-op
+    kernels (GEMM / LayerNorm launches) must give the same answer to operand rounding, for every panel height,
     including a ragged last panel (2*2*240 = 960 rows is not a multiple of 64 / 80 / 96) and a panel that
-    straddles two sequences."""
-    spec, model = get_model(fmt, "bf16", dev)
+    straddles two sequences.  Both builds (bfloat16 and IEEE-half operands)."""
+    spec, model = get_model(fmt, precision, dev)
     inp = synthetic_inputs(spec, 2, 240, SEED)
     if spec.is_pose:
         inp["mask"][1, :, :, 90:] = False
@@ -296,17 +296,21 @@ def test_chain_kernels_match_the_per_op_kernels_bf16(dev, golden, fmt, mt, monke
     monkeypatch.delenv("A2P_NO_CHAIN")
     ref = golden[f"{fmt}/fwd_cfg"]
     e_pair, e_gold, e_old = rel_l2(chained, per_op), rel_l2(chained, ref), rel_l2(per_op, ref)
-    record(f"chain_vs_perop/{fmt}/MT{mt}", pair=e_pair, chain_vs_golden=e_gold, perop_vs_golden=e_old)
-    # measured: chain vs per-op 3.0e-3 (face) / 8.4e-3 (pose), both 4.4e-3 / 8.5e-3 from the fp32 reference (round 1: 3e-2 / 0.25)
-    assert e_pair < (6.5e-3 if fmt == "face" else 1.7e-2) and e_gold < (9e-3 if fmt == "face" else 1.7e-2) and e_gold < 1.2 * e_old + 1e-3
+    record(f"chain_vs_perop/{precision}/{fmt}/MT{mt}", pair=e_pair, chain_vs_golden=e_gold, perop_vs_golden=e_old)
+    # bf16 measured in round 2: chain vs per-op 3.0e-3 (face) / 8.4e-3 (pose), both 4.4e-3 / 8.5e-3 from the fp32 reference;
+    # IEEE-half operands carry 3 more mantissa bits: gates 1/6 of the bf16 ones
+    k = 1.0 if precision == "bf16" else 1.0 / 6.0
+    assert e_pair < k * (6.5e-3 if fmt == "face" else 1.7e-2) and e_gold < k * (9e-3 if fmt == "face" else 1.7e-2) \
+        and e_gold < 1.2 * e_old + k * 1e-3
 
 
+@pytest.mark.parametrize("precision", ["bf16", "fp16"])
 @pytest.mark.parametrize("fmt,B,frames", [("face", 4, 150), ("pose", 5, 210)])
-def test_chain_kernels_with_frame_counts_that_are_not_a_multiple_of_4(dev, fmt, B, frames, monkeypatch):
+def test_chain_kernels_with_frame_counts_that_are_not_a_multiple_of_4(dev, fmt, B, frames, precision, monkeypatch):
     """The reference derives the frame count from the audio length (demo/demo.py: int(len/sr) * 30), so T = 150, 210, ... occur:
     4-row groups of the transposed V^T store then straddle sequences.  Chain path == per-op path, and both close to the oracle."""
     from oracle import a2p_oracle as O
-    spec, model = get_model(fmt, "bf16", dev)
+    spec, model = get_model(fmt, precision, dev)
     inp = synthetic_inputs(spec, B, frames, SEED)
     scale = 10.0 if fmt == "face" else 2.0
     y = y_for(spec, inp, dev, scale)
@@ -322,18 +326,19 @@ def test_chain_kernels_with_frame_counts_that_are_not_a_multiple_of_4(dev, fmt, 
     ref = den.forward_cfg(inp["x_T"][:2], times[:2].cpu(), inp["cond_embed"][:2], torch.full((2,), scale),
                           inp.get("keyframes", [None])[:2] if spec.is_pose else None, inp["mask"][:2] if spec.is_pose else None)
     e_pair, e_ref = rel_l2(chained, per_op), rel_l2(chained[:2], ref)
-    record(f"chain_ragged/{fmt}/T{frames}", pair=e_pair, chain_vs_oracle=e_ref, perop_vs_oracle=rel_l2(per_op[:2], ref))
-    assert e_pair < (6.5e-3 if fmt == "face" else 1.8e-2) and e_ref < (9e-3 if fmt == "face" else 1.5e-2)   # measured 3.1e-3 / 8.8e-3, 4.3e-3 / 7.5e-3
+    record(f"chain_ragged/{precision}/{fmt}/T{frames}", pair=e_pair, chain_vs_oracle=e_ref, perop_vs_oracle=rel_l2(per_op[:2], ref))
+    k = 1.0 if precision == "bf16" else 1.0 / 6.0    # bf16 measured 3.1e-3 / 8.8e-3, 4.3e-3 / 7.5e-3
+    assert e_pair < k * (6.5e-3 if fmt == "face" else 1.8e-2) and e_ref < k * (9e-3 if fmt == "face" else 1.5e-2)
 
 
-@pytest.mark.parametrize("fmt,B,frames", [("face", 4, 240)])
-def test_chain_workgroup_shapes_are_bit_identical(dev, fmt, B, frames, monkeypatch):
+@pytest.mark.parametrize("precision", ["bf16", "fp16"])
+@pytest.mark.parametrize("fmt,B,frames", [("face", 4, 240), ("pose", 4, 240)])
+def test_chain_workgroup_shapes_are_bit_identical(dev, fmt, B, frames, precision, monkeypatch):
     """The library picks the 4- or the 8-wave chain workgroup shape per box from in-situ timings (chain_pick_nw), so the two
-    must agree to the last bit: same GEMM accumulation order per output, one shared 8-partial LayerNorm reduction tree.
-    (Also verified by output digests at face B=8 / B=32: scratch/ab_hash.py.  The body model, d=256, is excluded from the per-box
-    choice: its two shapes agree at B=16 / T=600 but differ at bf16-rounding level on small forwards -- scratch/pose_nw_check.py,
-    DESIGN.md section 6 -- so it always runs the 4-wave shape.)"""
-    spec, model = get_model(fmt, "bf16", dev)
+    must agree to the last bit in BOTH 16-bit builds and for both model widths: same GEMM accumulation order per output, one
+    shared 8-partial LayerNorm reduction tree, no floating-point contraction (kernels_chain.h).  The 7 un-forced forwards
+    afterwards walk through the calibration (alternating shapes) and the sticky choice."""
+    spec, model = get_model(fmt, precision, dev)
     inp = synthetic_inputs(spec, B, frames, SEED)
     y = y_for(spec, inp, dev, 10.0 if fmt == "face" else 2.0)
     times = torch.tensor([901, 417, 33, 0][:B], device=dev)
@@ -347,6 +352,7 @@ def test_chain_workgroup_shapes_are_bit_identical(dev, fmt, B, frames, monkeypat
     auto = [cfg(x, times, y).clone() for _ in range(7)]          # calibration forwards alternate the shapes, then one sticks
     assert torch.equal(outs["4"], outs["8"])
     assert all(torch.equal(a, outs["4"]) for a in auto)
+    record(f"nw_identity/{precision}/{fmt}_B{B}_T{frames}", max_abs_diff=0.0)
 
 
 # ----------------------------------------------------------------------------- edge shapes / sampler API surface
@@ -466,15 +472,16 @@ def test_weight_updates_are_picked_up(dev):
     assert torch.allclose(model(x, t, y), base, atol=1e-5)
 
 
-def test_chain_path_is_bitwise_reproducible_under_repetition(dev):
+@pytest.mark.parametrize("precision", ["bf16", "fp16"])
+def test_chain_path_is_bitwise_reproducible_under_repetition(dev, precision):
     """Race screen for the LDS-DMA weight rings / panel hand-offs of the chain kernels: 24 repeated guided forwards at
-    the full bench size (B=8, T=600, bf16) must be bit-identical (a late DMA landing or an early fragment read shows up
-    as run-to-run differences), and a second context with the same weights must agree too."""
+    the full bench size (B=8, T=600, both 16-bit builds) must be bit-identical (a late DMA landing or an early fragment read
+    shows up as run-to-run differences), and a second context with the same weights must agree too."""
     spec = face_spec()
     sd = synthetic_state_dict(spec, SEED)
     outs = []
     for rep in range(2):
-        model, _ = create_model_and_diffusion(default_args("face", timestep_respacing=""), "test", precision="bf16", max_batch=8)
+        model, _ = create_model_and_diffusion(default_args("face", timestep_respacing=""), "test", precision=precision, max_batch=8)
         load_model(model, sd)
         cfg = ClassifierFreeSampleModel(model.to(dev).eval())
         inp = synthetic_inputs(spec, 8, 600, SEED)

@@ -37,20 +37,21 @@ def build(fmt, precision, dev, max_batch=2, layers=None, respacing="ddim10"):
 
 
 # ----------------------------------------------------------------------------- parity at the benchmarked shape
-# bf16 bounds = 2x the values measured on MI355X in round 2 (profiles/r02_parity.json); fp32 = the north_star bar.
-# measured (gpurun_out/parity_tests.json -> profiles/r02_parity_tests.json): bf16 fwd 4.3e-3 / 6.4e-3, ddim10 2.5e-2 / 6.2e-3
-BF16_FWD_TOL = {"face": 9.0e-3, "pose": 1.3e-2}
-BF16_DDIM10_TOL = {"face": 5.0e-2, "pose": 1.3e-2}
-# IEEE-half operands: 3 more mantissa bits than bf16
-# measured: fwd 5.3e-4 / 8.1e-4, ddim10 3.1e-3 / 8.3e-4
-FP16_FWD_TOL = {"face": 1.1e-3, "pose": 1.7e-3}
-FP16_DDIM10_TOL = {"face": 6.5e-3, "pose": 1.7e-3}
+# Round 3: input_projection, final_layer and the pose conv tail are exact-fp32 islands in the 16-bit modes (a2p_ctx::tail32; the
+# error budget in profiles/r03_error_budget*.json found final_layer's operand rows to carry 3.05e-3 of the face model's 3.11e-3
+# loop error).  fp16 -- the benchmarked mode -- is now gated at the north_star bar itself, 1e-3, on the forward AND on the loop's
+# return value (oracle/lowprec_model.py predicts 4.1e-4 / 3.6e-4 face, 3.1e-4 / 3.1e-4 body).
+# bf16 (8 mantissa bits) cannot reach it: gates = 2x the model's prediction (face 3.4e-3 / 3.1e-3, body 2.5e-3 / 2.5e-3).
+BF16_FWD_TOL = {"face": 7.0e-3, "pose": 5.0e-3}
+BF16_DDIM10_TOL = {"face": 6.5e-3, "pose": 5.0e-3}
+FP16_FWD_TOL = {"face": 1.0e-3, "pose": 1.0e-3}
+FP16_DDIM10_TOL = {"face": 1.0e-3, "pose": 1.0e-3}
 
 
 @pytest.mark.parametrize("fmt", ["face", "pose"])
 def test_T600_forward_and_ddim10_vs_oracle_both_precisions(dev, fmt):
     """The shape the throughput is quoted on (T=600, S=1998+2): guided forward and 10 DDIM steps against the oracle.
-    fp32 mode <= 1e-3 (rel-L2 and max-norm); bf16 mode -- the benchmarked mode -- gated at 2x its measured error."""
+    fp32 mode <= 1e-3 (rel-L2 and max-norm); fp16 -- the benchmarked mode -- <= 1e-3 rel-L2 on both; bf16 at 2x its error."""
     from oracle import a2p_oracle as O
     B, T = 1, 600
     spec = face_spec() if fmt == "face" else pose_spec()
@@ -146,7 +147,7 @@ def test_guide_cache_survives_address_reuse(dev):
 
 
 # ----------------------------------------------------------------------------- N > 1 on the GPU that exists
-@pytest.mark.parametrize("precision", ["bf16", "fp32"])
+@pytest.mark.parametrize("precision", ["bf16", "fp16", "fp32"])
 def test_two_ranks_sharing_the_gpu_match_single_rank_bit_for_bit(dev, tmp_path, precision):
     """SURVEY §8e on the HIP sampler: 2 processes (gloo collectives, both on cuda:0) run sample_parallel(ddim_sample_loop)
     over a global batch of 4; the gathered samples must equal the single-process result bit for bit (noise indexed by
@@ -171,10 +172,13 @@ def test_two_ranks_sharing_the_gpu_match_single_rank_bit_for_bit(dev, tmp_path, 
 
 
 # ----------------------------------------------------------------------------- chain workgroup shapes, body model
+@pytest.mark.parametrize("precision", ["bf16", "fp16"])
 @pytest.mark.parametrize("B,T", [(3, 448), (4, 450), (3, 600), (16, 600)])
-def test_chain_workgroup_shapes_are_bit_identical_pose(dev, B, T, monkeypatch):
-    """Round-1 open item: the 4- and 8-wave chain shapes disagreed at bf16-rounding level for d=256 on small forwards."""
-    spec, sd, model, _ = build("pose", "bf16", dev, max_batch=B)
+def test_chain_workgroup_shapes_are_bit_identical_pose(dev, B, T, precision, monkeypatch):
+    """Round-1 open item: the 4- and 8-wave chain shapes disagreed at bf16-rounding level for d=256 on small forwards.
+    Both 16-bit builds: liba2p_hip_f16.so is a second compile of every instantiation (the contraction bug was specific to one
+    instantiation of one compile) and it is the build whose shape is picked at run time in the benchmark."""
+    spec, sd, model, _ = build("pose", precision, dev, max_batch=B)
     cfg = ClassifierFreeSampleModel(model)
     inp = synthetic_inputs(spec, B, T, SEED)
     y = {"cond_embed": inp["cond_embed"].to(dev), "keyframes": inp["keyframes"].to(dev), "mask": inp["mask"].to(dev),
@@ -187,19 +191,20 @@ def test_chain_workgroup_shapes_are_bit_identical_pose(dev, B, T, monkeypatch):
         outs[nw] = cfg(x, t, y).clone()
     monkeypatch.delenv("A2P_CHAIN_NW")
     d = float((outs["4"] - outs["8"]).abs().max())
-    record(f"pose_nw/B{B}_T{T}", max_abs_diff=d)
+    record(f"pose_nw/{precision}/B{B}_T{T}", max_abs_diff=d)
     assert torch.equal(outs["4"], outs["8"]), f"max |diff| = {d:.3e}"
     model.release()
 
 
 # ----------------------------------------------------------------------------- layer-0 work shared by the two guidance halves
+@pytest.mark.parametrize("precision", ["bf16", "fp16"])
 @pytest.mark.parametrize("fmt,B,T", [("face", 4, 240), ("face", 8, 600), ("pose", 16, 600)])
-def test_layer0_shared_half_is_bit_identical_to_the_duplicated_path(dev, fmt, B, T, monkeypatch):
+def test_layer0_shared_half_is_bit_identical_to_the_duplicated_path(dev, fmt, B, T, precision, monkeypatch):
     """Under classifier-free guidance both halves of the 2B sequences enter layer 0 with the same x, so norm1 / Q,K,V / the
     first self attention run once (csrc/a2p_lib_run.h `shared_half`).  Same bits as running them twice -- including grids of
     several rounds, where a second-half workgroup starts after the first-half one has stored its rows (the source rows live in
     a separate buffer for exactly that reason)."""
-    spec, sd, model, _ = build(fmt, "bf16", dev, max_batch=B)
+    spec, sd, model, _ = build(fmt, precision, dev, max_batch=B)
     cfg = ClassifierFreeSampleModel(model)
     inp = synthetic_inputs(spec, B, T, SEED)
     y = {"cond_embed": inp["cond_embed"].to(dev), "scale": torch.full((B,), 10.0 if fmt == "face" else 2.0, device=dev)}
@@ -217,16 +222,18 @@ def test_layer0_shared_half_is_bit_identical_to_the_duplicated_path(dev, fmt, B,
         assert torch.equal(shared, dup), f"NW={nw}: max |diff| = {float((shared - dup).abs().max()):.3e}"
         outs[nw] = shared
     assert torch.equal(outs["4"], outs["8"])
+    record(f"layer0_shared/{precision}/{fmt}_B{B}_T{T}", max_abs_diff=0.0)
     model.release()
 
 
 # ----------------------------------------------------------------------------- two panel heights in one chain launch
+@pytest.mark.parametrize("precision", ["bf16", "fp16"])
 @pytest.mark.parametrize("B,T", [(11, 600), (32, 600), (13, 592)])
-def test_mixed_panel_heights_are_bit_identical_to_the_uniform_launch(dev, B, T, monkeypatch):
+def test_mixed_panel_heights_are_bit_identical_to_the_uniform_launch(dev, B, T, precision, monkeypatch):
     """Forwards of more than 256 48-row panels (face, d=512) launch the chain kernels with 64-row panels for the first workgroups
     so that the grid fills whole rounds of the 256 CUs (csrc/kernels_chain.h `chain_kernel_mix`, a2p_lib_run.h `launch_chain`).
     Same bits as the uniform 48-row launch for both workgroup shapes, ragged tails included."""
-    spec, sd, model, _ = build("face", "bf16", dev, max_batch=B)
+    spec, sd, model, _ = build("face", precision, dev, max_batch=B)
     cfg = ClassifierFreeSampleModel(model)
     inp = synthetic_inputs(spec, B, T, SEED)
     y = {"cond_embed": inp["cond_embed"].to(dev), "scale": torch.full((B,), 10.0, device=dev)}
@@ -244,4 +251,5 @@ def test_mixed_panel_heights_are_bit_identical_to_the_uniform_launch(dev, B, T, 
         assert torch.equal(mixed, uniform), f"NW={nw}: max |diff| = {float((mixed - uniform).abs().max()):.3e}"
         outs[nw] = mixed
     assert torch.equal(outs["4"], outs["8"])
+    record(f"mixed_panels/{precision}/B{B}_T{T}", max_abs_diff=0.0)
     model.release()

@@ -346,3 +346,81 @@ def test_plms_argument_checks_need_no_gpu():
         assert callable(getattr(d, name))
     with pytest.raises(NotImplementedError):
         d.training_losses(None, None, None)
+
+
+# ----------------------------------------------------------------------------- round 3: repetition seeding under dist (ADVICE medium)
+def test_derive_seed_separates_neighbouring_runs_repetitions_and_samples():
+    from audio2photoreal_amd.sample_parallel import derive_seed
+    seen = {derive_seed(b, r, g) for b in (10, 11, 12) for r in range(3) for g in range(8)}
+    assert len(seen) == 3 * 3 * 8                                  # base + g collided: (10, 1) == (11, 0)
+    assert derive_seed(10, 0, 1) != derive_seed(11, 0, 0)
+    assert all(0 <= s < 2 ** 63 for s in seen)
+    assert derive_seed(10, 2, 5) == derive_seed(10, 2, 5)
+
+
+class _EchoDiffusion:
+    """ddim_sample_loop that returns its initial noise: what _generate_sequences gathers IS the noise each sample started from."""
+
+    def ddim_sample_loop(self, model, shape, noise=None, model_kwargs=None, **kw):
+        assert noise is not None and tuple(noise.shape) == tuple(shape)
+        return noise.clone()
+
+
+def _rep_worker(rank, world, port, out_dir):
+    import argparse
+    import torch.distributed as dist
+    from audio2photoreal_amd.sample import generate as G
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.manual_seed(1234)
+    args = argparse.Namespace(num_repetitions=2, guidance_param=2.0, batch_size=5, device="cpu", data_format="face",
+                              curr_seq_length=6, resume_trans=None)
+    model = argparse.Namespace(nfeats=4)
+    y = {"cond_embed": torch.zeros(5, 3, 2)}
+    out = G._generate_sequences(args, {"y": y}, _EchoDiffusion(), model, lambda d, kind: d)
+    np.save(os.path.join(out_dir, f"r{rank}.npy"), out["motions"])
+    dist.destroy_process_group()
+
+
+def test_sharded_repetitions_draw_fresh_noise(tmp_path):
+    """under torch.distributed every repetition of _generate_sequences started from the SAME noise (the shared
+    base seed does not advance).  Now seed = derive_seed(base, repetition, global sample id)."""
+    from audio2photoreal_amd.sample_parallel import derive_seed
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    mp.spawn(_rep_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    r0, r1 = np.load(tmp_path / "r0.npy"), np.load(tmp_path / "r1.npy")
+    assert np.array_equal(r0, r1) and r0.shape == (10, 4, 1, 6)
+    rep0, rep1 = r0[:5], r0[5:]
+    assert not np.array_equal(rep0, rep1), "repetition 1 repeated repetition 0's samples"
+    want = per_sample_noise((5, 4, 1, 6), [derive_seed(1234, 1, g) for g in range(5)]).numpy()
+    assert np.array_equal(rep1, want)                                # a function of (base seed, repetition, global id) only
+
+
+# ----------------------------------------------------------------------------- round 3: f1 honesty (VERDICT item 5a, ADVICE high)
+def test_native_front_end_refuses_on_path_tensors_it_does_not_implement():
+    """A real fairseq (vq-)wav2vec checkpoint carries GroupNorm affine terms per conv layer and, for the lip encoder, a 12-layer
+    feature aggregator -- both ON the reference's conditioning path (model/diffusion.py:290-291, audio_encoder.py:43-44).  The stub
+    geometry does not implement them: loading must fail loudly, not skip them.  Off-path tensors (quantiser, prediction heads,
+    the vq-wav2vec aggregator encode_audio never calls) are still skipped."""
+    from audio2photoreal_amd import _lib
+    from audio2photoreal_amd.model_util import create_model_and_diffusion, default_args, load_model
+    from audio2photoreal_amd.synthetic import synthetic_frontend_state_dict
+    spec = face_spec(num_layers=1)
+    model, _ = create_model_and_diffusion(default_args("face", layers=1), "test", audio_frontend="native")
+    sd = {**synthetic_state_dict(spec, 10), **synthetic_frontend_state_dict(10, lip=True)}
+    load_model(model, sd)                                                                     # stub-geometry weights: fine
+    off_path = {"audio_model.vector_quantizer.vars": torch.zeros(1, 640, 128), "audio_model.feature_aggregator.conv_layers.0.1.weight": torch.zeros(512, 512, 2),
+                "audio_model.wav2vec_predictions.project_to_steps.weight": torch.zeros(512, 512, 1, 12),
+                "lip_model.audio_encoder.resampler.kernel": torch.zeros(1, 1, 41)}
+    load_model(model, {**sd, **off_path})                                                     # not read by the reference on this path
+    for bad in ("audio_model.feature_extractor.conv_layers.0.2.weight", "audio_model.feature_extractor.conv_layers.3.2.bias",
+                "lip_model.audio_encoder.wav2vec_model.feature_extractor.conv_layers.1.2.weight",
+                "lip_model.audio_encoder.wav2vec_model.feature_aggregator.conv_layers.0.1.weight"):
+        with pytest.raises(_lib.A2PError, match="conditioning path"):
+            load_model(model, {**sd, bad: torch.ones(512)})
+    # a model WITHOUT the native front end is fed y["cond_embed"] by the caller: front-end tensors are none of its business
+    plain, _ = create_model_and_diffusion(default_args("face", layers=1), "test")
+    load_model(plain, {**synthetic_state_dict(spec, 10), "audio_model.feature_extractor.conv_layers.0.2.weight": torch.ones(512)})
