@@ -119,18 +119,30 @@ def load(half: bool = False) -> C.CDLL:
         "a2p_frontend_encode_audio": [vp, vp, i32, i64, vp, i32, vp],
         "a2p_frontend_encode_lip": [vp, vp, i32, i64, vp, i32, i32, vp, vp],
     }
+    def note_failure(result, func, args, lib=lib):   # ctypes errcheck hook: remember WHICH build returned the error
+        if result < 0:
+            _failed.append(lib)
+        return result
     for name, args in sig.items():
         fn = getattr(lib, name)
         fn.argtypes = args
         fn.restype = C.c_int
+        fn.errcheck = note_failure
     _libs[half] = lib
     return lib
 
 
+_failed = []   # libraries whose last call returned an error status, newest last
+
+
 def check(rc: int, what: str) -> int:
+    """Raise A2PError with the message of the library build that made the failing call (both builds keep their own
+    `a2p_last_error` string, which is never cleared: joining them would report a stale message of the other build)."""
     if rc < 0:
-        msg = b"; ".join(l.a2p_last_error() for l in _libs.values() if l.a2p_last_error())   # the failing library set it
-        raise A2PError(f"{what} failed ({rc}): {msg.decode()}")
+        lib = _failed.pop() if _failed else None
+        del _failed[:]
+        msg = lib.a2p_last_error() if lib is not None else b"; ".join(l.a2p_last_error() for l in _libs.values() if l.a2p_last_error())
+        raise A2PError(f"{what} failed ({rc}): {(msg or b'').decode()}")
     return rc
 
 

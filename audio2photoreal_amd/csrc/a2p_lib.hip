@@ -26,6 +26,7 @@
 #include "../../include/a2p_hip.h"
 #include "kernels_attn.h"
 #include "kernels_chain.h"
+#include "kernels_chain2.h"
 #include "kernels_gemm.h"
 #include "kernels_misc.h"
 
@@ -147,8 +148,11 @@ struct a2p_ctx {
   Buf cak_w32, cak_b, cav_w32, cav_b, cak_wt, cav_wt;
   Buf ca2k_wt, ca2v_wt, ca2k_b, ca2v_b;
   Buf conv_wt[7];
-  std::vector<Buf> ch_stream, ch_aux;  // packed weight streams [(nw == 8) * L*4 + layer*4 + kind] / bias blocks [layer*4 + kind]
+  std::vector<Buf> ch_stream, ch_aux;  // packed weight streams [layout * L*4 + layer*4 + kind] (layout 0: 4-wave LDS slices, 1: 8-wave, 2: direct
+                                       // MFMA operands of kernels_chain2.h) / bias blocks [layer*4 + kind]
+  std::vector<int> ch_nstages;          // stages of the generation-2 stream [layer*4 + kind] (stream leaders walk exactly these)
   int ch_nw = 4;                       // waves per chain workgroup of the forward being enqueued (4 or 8; chain_pick_nw)
+  int ch_ver = 2;                      // chain kernel generation of the forward being enqueued: 2 = kernels_chain2.h, 1 = kernels_chain.h
   struct ChainTune {                   // per forward size (rows): which workgroup shape is faster ON THIS BOX, measured in situ
     int choice = 0, calls = 0;
     std::vector<std::tuple<int, hipEvent_t, hipEvent_t>> samples;

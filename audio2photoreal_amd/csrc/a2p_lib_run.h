@@ -122,7 +122,7 @@ static void pk_gemm(std::vector<ChainPackDesc>& v, const void* W, int ldw, int n
 }
 
 static int chain_pack(a2p_ctx* c, int idx, const std::vector<ChainPackDesc>& descs, const std::vector<std::pair<const float*, int>>& aux,
-                      hipStream_t s) {
+                      hipStream_t s, const std::vector<ChainPackDesc>* descs_gen2 = nullptr) {
   const size_t pad = CHAIN_STREAM_PAD;  // the DMA runs up to NS-1 (<= 5) stages past the end
   Buf dd;
   CHK(buf_alloc_tmp(dd, descs.size() * sizeof(ChainPackDesc)));
@@ -131,6 +131,21 @@ static int chain_pack(a2p_ctx* c, int idx, const std::vector<ChainPackDesc>& des
     Buf& st = c->ch_stream[(size_t)w8 * c->L * 4 + idx];
     CHK(buf_alloc(st, (descs.size() + pad) * CHAIN_STAGE_ELEMS * 2));
     chain_pack_kernel<<<(int)descs.size(), 256, 0, s>>>(reinterpret_cast<const ChainPackDesc*>(dd.p), reinterpret_cast<bf16_t*>(st.p), w8 ? 8 : 4);
+  }
+  Buf dd2;
+  {  // second-generation kernels (kernels_chain2.h): the same stages (POST: in the software-pipelined order `descs_gen2`) as MFMA
+     // operands for direct global loads
+    const std::vector<ChainPackDesc>& d2 = descs_gen2 ? *descs_gen2 : descs;
+    const ChainPackDesc* dev = reinterpret_cast<const ChainPackDesc*>(dd.p);
+    if (descs_gen2) {
+      CHK(buf_alloc_tmp(dd2, d2.size() * sizeof(ChainPackDesc)));
+      HIPCHK(hipMemcpyAsync(dd2.p, d2.data(), d2.size() * sizeof(ChainPackDesc), hipMemcpyHostToDevice, s));
+      dev = reinterpret_cast<const ChainPackDesc*>(dd2.p);
+    }
+    Buf& st = c->ch_stream[(size_t)2 * c->L * 4 + idx];
+    CHK(buf_alloc(st, (d2.size() + pad) * CHAIN_STAGE_ELEMS * 2));
+    chain2_pack_kernel<<<(int)d2.size(), 256, 0, s>>>(dev, reinterpret_cast<bf16_t*>(st.p));
+    c->ch_nstages[idx] = (int)d2.size();
   }
   HIPCHK(hipGetLastError());
   Buf& ax = c->ch_aux[idx];
@@ -142,15 +157,17 @@ static int chain_pack(a2p_ctx* c, int idx, const std::vector<ChainPackDesc>& des
   }
   HIPCHK(hipStreamSynchronize(s));  // descs is host memory of the caller
   buf_free(dd);
+  buf_free(dd2);
   return 0;
 }
 
 // pre-pack every chain's weight stream in consumption order (called from a2p_finalize_weights)
 static int chain_build_streams(a2p_ctx* c, hipStream_t s) {
   const int d = c->d, ff = c->ff, L = c->L;
-  if (c->ch_stream.size() != (size_t)L * 8) {  // first build; later builds (weight updates) refill the same buffers
-    c->ch_stream.assign((size_t)L * 8, Buf());
+  if (c->ch_stream.size() != (size_t)L * 12) {  // first build; later builds (weight updates) refill the same buffers
+    c->ch_stream.assign((size_t)L * 12, Buf());
     c->ch_aux.assign((size_t)L * 4, Buf());
+    c->ch_nstages.assign((size_t)L * 4, 0);
   }
   auto pf = [&](int l) { return "seqTransDecoder.stack." + std::to_string(l) + "."; };
   auto add_pre = [&](std::vector<ChainPackDesc>& v, int l) {  // [Q|K] then V of layer l's self attention
@@ -174,11 +191,15 @@ static int chain_build_streams(a2p_ctx* c, hipStream_t s) {
     pk_gemm(q, c->wt.at(pf(l) + (c->pose ? "multihead_attn2" : "multihead_attn") + ".out_proj.weight").p, d, d, d, 0, d / 128);
     const Buf& w1 = c->wt.at(pf(l) + "linear1.weight");
     const Buf& w2 = c->wt.at(pf(l) + "linear2.weight");
-    for (int h = 0; h < ff / 128; ++h) {
-      for (int ks = 0; ks < d / 64; ++ks) q.push_back({reinterpret_cast<const bf16_t*>(w1.p), d, h * 128, ks * 64, ff, 0});
+    auto lin1 = [&](std::vector<ChainPackDesc>& v, int h) {
+      for (int ks = 0; ks < d / 64; ++ks) v.push_back({reinterpret_cast<const bf16_t*>(w1.p), d, h * 128, ks * 64, ff, 0});
+    };
+    auto lin2 = [&](std::vector<ChainPackDesc>& v, int h) {
       for (int ks = 0; ks < 2; ++ks)   // k-major over the d/128 output tiles (chain_body::gemm_group)
-        for (int t = 0; t < d / 128; ++t) q.push_back({reinterpret_cast<const bf16_t*>(w2.p), ff, t * 128, h * 128 + ks * 64, d, 0});
-    }
+        for (int t = 0; t < d / 128; ++t) v.push_back({reinterpret_cast<const bf16_t*>(w2.p), ff, t * 128, h * 128 + ks * 64, d, 0});
+    };
+    const int FTn = ff / 128;
+    for (int h = 0; h < FTn; ++h) { lin1(q, h); lin2(q, h); }
     std::vector<std::pair<const float*, int>> aux = {{W32(c, pf(l) + "linear1.bias"), ff}};
     if (l + 1 < L) {
       add_pre(q, l + 1);
@@ -196,8 +217,14 @@ static void chain_base(a2p_ctx* c, ChainP& p, int N, int T, int idx, int aux_flo
   memset(&p, 0, sizeof(p));
   p.M = N * T; p.rows_per_seq = T; p.x = c->x.f(); p.cst = reinterpret_cast<const f32x4*>(c->rope_cst.p); p.cs_npos = c->rope_npos;
   p.ain = reinterpret_cast<const bf16_t*>(c->ao.p); p.ld_ain = c->d;
-  p.stream = reinterpret_cast<const bf16_t*>(c->ch_stream[(size_t)(c->ch_nw == 8) * c->L * 4 + idx].p);
+  p.stream = reinterpret_cast<const bf16_t*>(c->ch_stream[(size_t)(c->ch_ver == 2 ? 2 : (c->ch_nw == 8)) * c->L * 4 + idx].p);
   p.aux = c->ch_aux[idx].f(); p.aux_kb = (aux_floats + 255) / 256;
+  if (c->ch_ver == 2) {   // stream leaders (kernels_chain2.h): one workgroup per XCD walks the weight stream ahead of the consumers
+    // off by default: -14 % kernel time when L2 and MALL are cold (scratch/chain2_bench), nothing inside the step
+    static const int leaders = getenv("A2P_CHAIN_LEADERS") ? atoi(getenv("A2P_CHAIN_LEADERS")) : 0;
+    static const int pfw = getenv("A2P_CHAIN_PFW") ? atoi(getenv("A2P_CHAIN_PFW")) : 2;
+    p.n_pf = leaders; p.pf_waves = pfw; p.n_stages = c->ch_nstages[idx];
+  }
   if (c->clk.p) {  // A2P_CHAIN_CLK=1: every chain launch of a forward gets its own 8 x 4 slot (a2p_debug_read "clk")
     p.clk = reinterpret_cast<unsigned long long*>(c->clk.p) + (size_t)(c->clk_turn++ % 64) * 32;
   }
@@ -265,7 +292,59 @@ static int chain_pick_nw(a2p_ctx* c, int64_t rows, hipEvent_t* e0, hipEvent_t* e
   return t.choice;
 }
 
+// Second-generation chain kernels (kernels_chain2.h): weights straight into VGPRs, 8 waves, panels of up to 96 rows.
+// Panel height: fewest rounds over the 256 CUs, then the cheaper panel.  A workgroup's time is a fixed part (prologue, barriers,
+// drain) + a per-stage part that is flat up to 64 rows (the 64 B/clk weight path: 256 cycles per stage) and MFMA-bound beyond
+// (64 cycles per 16 rows) + epilogues that grow with the rows (scratch/tall_probe, profiles/r03_tall_probe.txt).
+static int launch_chain2(a2p_ctx* c, int mode, const ChainP& p, hipStream_t s) {
+  const char* env_mt = getenv("A2P_CHAIN_MT");
+  int mt = env_mt ? atoi(env_mt) : 0;
+  const int lo = 2, hi = c->d == 512 ? 5 : 6;
+  if (mt < lo || mt > hi) {
+    float best = 1e30f;
+    for (int m = lo; m <= hi; ++m) {
+      const int blocks = (p.M + 16 * m - 1) / (16 * m);
+      const int cus = 256 - p.n_pf;   // the stream leaders hold one CU each
+      const float cost = (float)((blocks + cus - 1) / cus) * ((m > 4 ? (float)m : 4.0f) + 0.6f * (float)m + 2.0f);
+      if (cost < best) { best = cost; mt = m; }
+    }
+  }
+  const int grid = (p.M + 16 * mt - 1) / (16 * mt) + p.n_pf;   // the leaders come first: block b runs on XCD b % 8 from the start
+  KernelTimer kt(c, A2P_KERNEL_CHAIN);
+#define A2P_CHAIN2(D, MT)                                                                               \
+  do {                                                                                                  \
+    if (mode == CHAIN_PRE) A2P_LAUNCH(kt, (chain2_kernel<D, MT, CHAIN_PRE>), grid, 512, s, p);          \
+    else if (mode == CHAIN_MID) A2P_LAUNCH(kt, (chain2_kernel<D, MT, CHAIN_MID>), grid, 512, s, p);     \
+    else A2P_LAUNCH(kt, (chain2_kernel<D, MT, CHAIN_POST>), grid, 512, s, p);                           \
+  } while (0)
+  if (c->d == 512) {
+    if (mt == 2) A2P_CHAIN2(512, 2);
+    else if (mt == 3) A2P_CHAIN2(512, 3);
+    else if (mt == 4) A2P_CHAIN2(512, 4);
+    else A2P_CHAIN2(512, 5);
+  } else {
+    if (mt == 2) A2P_CHAIN2(256, 2);
+    else if (mt == 3) A2P_CHAIN2(256, 3);
+    else if (mt == 4) A2P_CHAIN2(256, 4);
+    else if (mt == 5) A2P_CHAIN2(256, 5);
+    else A2P_CHAIN2(256, 6);
+  }
+#undef A2P_CHAIN2
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+// Chain kernel generation for a forward of T-frame sequences: 1 (kernels_chain.h) unless A2P_CHAIN_V=2 asks for the round-3
+// restructure (kernels_chain2.h: bit-identical, measured equal at 48-row panels and slower at 80 -- DESIGN.md section 4.1b),
+// which does not implement final_layer fused into the last POST kernel (A2P_TAIL16) nor frame counts that are not a multiple
+// of 8 (only the staged V^T store: 8 frames per 16-byte piece)
+static int chain_pick_ver(const a2p_ctx* c, int T) {
+  const char* v = getenv("A2P_CHAIN_V");
+  return (!(v && atoi(v) == 2) || (!c->tail32 && !c->pose) || (T & 7)) ? 1 : 2;
+}
+
 static int launch_chain(a2p_ctx* c, int mode, const ChainP& p, hipStream_t s) {
+  if (c->ch_ver == 2) return launch_chain2(c, mode, p, s);
   const char* env_mt = getenv("A2P_CHAIN_MT");  // tuning / test override of the panel height (rows = 16 * MT)
   int mt = env_mt ? atoi(env_mt) : 0;
   // panel heights instantiated per width (LDS: the [16*MT][d] bf16 panel + hidden chunk + >= 3 ring slots must fit 160 KiB)
@@ -629,8 +708,11 @@ static int run_forward(a2p_ctx* c, const float* x_in, const int64_t* t_orig, int
   }
   hipEvent_t tune0 = nullptr, tune1 = nullptr;
   if (use_chain) {
-    c->ch_nw = chain_pick_nw(c, (int64_t)N * T, &tune0, &tune1);
-    if (tune0) HIPCHK(hipEventRecord(tune0, s));
+    c->ch_ver = chain_pick_ver(c, T);
+    if (c->ch_ver == 1) {
+      c->ch_nw = chain_pick_nw(c, (int64_t)N * T, &tune0, &tune1);
+      if (tune0) HIPCHK(hipEventRecord(tune0, s));
+    }
   }
   CrossKV kv, kv2;
   for (int l = 0; l < L; ++l) {
@@ -936,6 +1018,7 @@ extern "C" int a2p_decoder_layer_forward(a2p_ctx* c, int32_t layer, float* x, co
   fr.base = flm.f();
   fr.seq_stride = (int64_t)F * 2 * d;
   HIPCHK(hipMemcpyAsync(c->x.p, x, (size_t)N * T * d * 4, hipMemcpyDeviceToDevice, s));
+  c->ch_ver = chain_pick_ver(c, T);
   int rc = chain_supported(c) ? decoder_layer_chain(c, layer, N, T, kv, memory2 ? &kv2 : nullptr, fr, true, false, s)
                               : decoder_layer(c, layer, N, T, kv, memory2 ? &kv2 : nullptr, fr, s);
   if (rc == 0) hipMemcpyAsync(x, c->x.p, (size_t)N * T * d * 4, hipMemcpyDeviceToDevice, s);

@@ -1,0 +1,140 @@
+"""Round-3 GPU tests (`pytest -m gpu`): the second-generation chain kernels (csrc/kernels_chain2.h: weights straight into VGPRs,
+80-row panels, residual rows parked between GEMM groups) against the round-2 kernels they replace -- bit for bit, both 16-bit
+builds, both model widths, every panel height, ragged sizes; the multi-GPU control flow of bench.py on the GPU that exists; and a
+device-tensor all_gather that lights up on a node with >= 2 GPUs."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+import torch
+
+from audio2photoreal_amd.model.cfg_sampler import ClassifierFreeSampleModel
+from audio2photoreal_amd.model_util import create_model_and_diffusion, default_args, load_model
+from audio2photoreal_amd.spec import face_spec, pose_spec
+from audio2photoreal_amd.synthetic import synthetic_inputs, synthetic_state_dict
+from conftest import ROOT, record
+
+pytestmark = pytest.mark.gpu
+SEED = 10
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "GPU tests need the MI355X"
+    return torch.device("cuda:0")
+
+
+def _model(fmt, precision, dev, B):
+    spec = face_spec() if fmt == "face" else pose_spec()
+    model, _ = create_model_and_diffusion(default_args(fmt), "test", precision=precision, max_batch=B)
+    load_model(model, synthetic_state_dict(spec, SEED))
+    return spec, model.to(dev).eval()
+
+
+def _inputs(spec, fmt, B, T, dev):
+    inp = synthetic_inputs(spec, B, T, SEED)
+    y = {"cond_embed": inp["cond_embed"].to(dev), "scale": torch.full((B,), 10.0 if fmt == "face" else 2.0, device=dev)}
+    if spec.is_pose:
+        y["keyframes"], y["mask"] = inp["keyframes"].to(dev), inp["mask"].to(dev)
+    t = torch.tensor(([901, 417, 33, 0] * 8)[:B], device=dev)
+    return inp["x_T"].to(dev), t, y
+
+
+@pytest.mark.parametrize("precision", ["bf16", "fp16"])
+@pytest.mark.parametrize("fmt,B,T", [("face", 2, 240), ("face", 3, 150), ("face", 8, 600), ("face", 5, 592), ("pose", 3, 210), ("pose", 16, 600), ("pose", 4, 450)])
+def test_generation2_chain_kernels_are_bit_identical_to_generation1(dev, fmt, B, T, precision, monkeypatch):
+    """Same column ownership, same accumulation order per output, same 8-partial LayerNorm tree, same epilogue arithmetic: the
+    guided forward through kernels_chain2.h must equal the one through kernels_chain.h (8-wave shape) to the last bit -- for the
+    panel height the host picks and for every height it can be forced to, including ragged last panels (T = 150, 210, 592),
+    panels that straddle sequences and frame counts that are not a multiple of 4 or 8 (the V^T store's three regimes)."""
+    spec, model = _model(fmt, precision, dev, B)
+    cfg = ClassifierFreeSampleModel(model)
+    x, t, y = _inputs(spec, fmt, B, T, dev)
+    monkeypatch.setenv("A2P_CHAIN_MT", "3")            # both generations take the chain path at every size of this test
+    monkeypatch.setenv("A2P_CHAIN_V", "1")
+    monkeypatch.setenv("A2P_CHAIN_NW", "8")
+    want = cfg(x, t, y).clone()
+    monkeypatch.delenv("A2P_CHAIN_NW")
+    monkeypatch.setenv("A2P_CHAIN_V", "2")
+    assert torch.isfinite(want).all()
+    worst = 0.0
+    for mt in ["2", "3", "4", "5"] + (["6"] if fmt == "pose" else []):
+        monkeypatch.setenv("A2P_CHAIN_MT", mt)
+        got = cfg(x, t, y)
+        d = float((got - want).abs().max())
+        worst = max(worst, d)
+        assert torch.equal(got, want), f"generation 2, {16 * int(mt)}-row panels: max |diff| = {d:.3e}"
+    if 2 * B * T >= 960:                                 # generation 2 at the panel height its host code picks, and the default path
+        monkeypatch.delenv("A2P_CHAIN_MT")
+        assert torch.equal(cfg(x, t, y), want)
+        monkeypatch.delenv("A2P_CHAIN_V")
+        assert torch.equal(cfg(x, t, y), want)
+    record(f"gen2_vs_gen1/{precision}/{fmt}_B{B}_T{T}", max_abs_diff=worst)
+    model.release()
+
+
+@pytest.mark.parametrize("precision", ["bf16", "fp16"])
+@pytest.mark.parametrize("fmt,B,T", [("face", 8, 600), ("pose", 16, 600)])
+def test_generation2_layer0_shared_half_equals_the_duplicated_path(dev, fmt, B, T, precision, monkeypatch):
+    """Layer 0 under guidance runs norm1 / Q,K,V / the self attention once for both halves; the MID kernel of the second half reads
+    the first half's rows (ChainP::src_rows, xsrc).  Generation 2 reads those rows in its FiLM epilogue instead of at kernel start."""
+    spec, model = _model(fmt, precision, dev, B)
+    cfg = ClassifierFreeSampleModel(model)
+    x, t, y = _inputs(spec, fmt, B, T, dev)
+    monkeypatch.setenv("A2P_CHAIN_V", "2")
+    shared = cfg(x, t, y).clone()
+    monkeypatch.setenv("A2P_NO_SHARED_HALF", "1")
+    dup = cfg(x, t, y).clone()
+    assert torch.equal(shared, dup), f"max |diff| = {float((shared - dup).abs().max()):.3e}"
+    record(f"gen2_shared_half/{precision}/{fmt}_B{B}_T{T}", max_abs_diff=0.0)
+    model.release()
+
+
+# ----------------------------------------------------------------------------- multi-GPU readiness
+def test_bench_two_ranks_sharing_the_gpu(tmp_path):
+    """bench.py's own N > 1 branch (shard_bounds, barrier + max-over-ranks timing, the single end-of-run gather) with two ranks on
+    the one GPU of the test box and gloo collectives; on a multi-GPU node the driver runs the same code with backend "nccl"."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ, A2P_BENCH_SHARE_GPU="1", A2P_BENCH_BACKEND="gloo", A2P_TUNE_VERBOSE="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "1", "--repeats", "1",
+           "--batch", "2", "--no-cpu-baseline", "--no-legs", "--no-kernel-timing"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["scaling"] == "weak" and line["config"]["global_batch"] == 4
+    assert line["gather_ms"] is not None and line["gather_ms"] > 0.0          # the one collective of the data path ran
+    assert line["value"] > 0 and line["steps"] == 4
+    record("bench_2ranks_shared_gpu", value=float(line["value"]), gather_ms=float(line["gather_ms"]))
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two GPUs (lights up on the driver's multi-GPU node)")
+def test_device_tensor_all_gather_over_rccl(tmp_path):
+    """gather_samples on DEVICE tensors with backend "nccl" (= RCCL over xGMI): the collective production runs."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    code = (
+        "import os, torch, torch.distributed as dist\n"
+        "from audio2photoreal_amd.sample_parallel import gather_samples, shard_bounds\n"
+        "r = int(os.environ['LOCAL_RANK']); torch.cuda.set_device(r); dev = torch.device('cuda', r)\n"
+        "dist.init_process_group('nccl', device_id=dev)\n"
+        "lo, hi = shard_bounds(5, 2, r)\n"
+        "mine = torch.arange(lo, hi, device=dev, dtype=torch.float32).view(-1, 1, 1, 1).expand(-1, 4, 1, 6).contiguous()\n"
+        "allx = gather_samples(mine, 5)\n"
+        "assert allx.is_cuda and allx.shape == (5, 4, 1, 6) and torch.equal(allx[:, 0, 0, 0].cpu(), torch.arange(5.))\n"
+        "dist.barrier(); dist.destroy_process_group()\n")
+    env = dict(os.environ, PYTHONPATH=ROOT, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    script = tmp_path / "w.py"
+    script.write_text(code)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), str(script)]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
