@@ -4,19 +4,19 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
-// The 16-bit operand type of the throughput mode.  Default build: bfloat16 (the dtype BASELINE's configs name).  The SAME sources
-// compiled with -DA2P_HALF give liba2p_hip_f16.so, where every "bf16" below is IEEE half: same MFMA rate (v_mfma_f32_16x16x32_f16),
+// h16_t: the 16-bit MFMA operand type of the throughput modes.  Default build: bfloat16 (the dtype BASELINE's configs name).  The SAME
+// sources compiled with -DA2P_HALF give liba2p_hip_f16.so, where h16_t is IEEE half: same MFMA rate (v_mfma_f32_16x16x32_f16),
 // 3 more mantissa bits -- the rounding error of every staged operand drops 8x (precision="fp16" on the Python side; measured
-// parity in profiles/r02_parity.json).  Accumulation, statistics, the residual stream and the sampler stay fp32 in both.
+// parity in profiles/r03_parity.json).  Accumulation, statistics, the residual stream and the sampler stay fp32 in both.
 #ifdef A2P_HALF
-typedef _Float16 bf16_t;
+typedef _Float16 h16_t;
 #define A2P_MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0)
 #else
-typedef __bf16 bf16_t;
+typedef __bf16 h16_t;
 #define A2P_MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0)
 #endif
-typedef __attribute__((ext_vector_type(8))) bf16_t bf16x8;
-typedef __attribute__((ext_vector_type(4))) bf16_t bf16x4;
+typedef __attribute__((ext_vector_type(8))) h16_t h16x8;
+typedef __attribute__((ext_vector_type(4))) h16_t h16x4;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(2))) float f32x2;
 
@@ -38,24 +38,24 @@ struct Prec<float> {  // v_mfma_f32_16x16x4_f32: exact fp32, 1/16 of the bf16 ra
 };
 
 template <>
-struct Prec<bf16_t> {  // v_mfma_f32_16x16x32_bf16
-  using Frag = bf16x8;
+struct Prec<h16_t> {  // v_mfma_f32_16x16x32_bf16
+  using Frag = h16x8;
   static constexpr int KCH = 32;
   static constexpr int EPL = 8;
   __device__ static __forceinline__ f32x4 mfma(Frag a, Frag b, f32x4 c) {
     return A2P_MFMA16(a, b, c);
   }
-  __device__ static __forceinline__ Frag load(const bf16_t* p) { return *reinterpret_cast<const bf16x8*>(p); }
+  __device__ static __forceinline__ Frag load(const h16_t* p) { return *reinterpret_cast<const h16x8*>(p); }
 };
 
 __device__ __forceinline__ float to_f32(float v) { return v; }
-__device__ __forceinline__ float to_f32(bf16_t v) { return (float)v; }
+__device__ __forceinline__ float to_f32(h16_t v) { return (float)v; }
 template <typename T>
 __device__ __forceinline__ T from_f32(float v);
 template <>
 __device__ __forceinline__ float from_f32<float>(float v) { return v; }
 template <>
-__device__ __forceinline__ bf16_t from_f32<bf16_t>(float v) { return (bf16_t)v; }
+__device__ __forceinline__ h16_t from_f32<h16_t>(float v) { return (h16_t)v; }
 
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll

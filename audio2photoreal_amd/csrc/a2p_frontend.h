@@ -94,9 +94,9 @@ __global__ __launch_bounds__(256) void fe_conv0_kernel(const float* __restrict__
 }
 
 // fp32 -> 16-bit copy of a repacked conv weight
-__global__ void fe_cast_kernel(const float* __restrict__ src, bf16_t* __restrict__ dst, int64_t n) {
+__global__ void fe_cast_kernel(const float* __restrict__ src, h16_t* __restrict__ dst, int64_t n) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n) dst[i] = (bf16_t)src[i];
+  if (i < n) dst[i] = (h16_t)src[i];
 }
 
 // Conv1d weight [Co][Ci][k] -> GEMM operand [Co][k*Ci] (tap-major: a channel-last window of k rows is one contiguous A row);
@@ -263,7 +263,7 @@ extern "C" int a2p_frontend_finalize(a2p_frontend_ctx* f, void* stream) {
       if (f->conv16 && i > 0) {   // layers 1..7 are GEMMs on 16-bit operands; layer 0 keeps fp32 taps (VALU arithmetic)
         Buf h;
         CHK(buf_alloc_tmp(h, (size_t)n * 2));
-        fe_cast_kernel<<<(int)((n + 255) / 256), 256, 0, s>>>(dst[i].f(), reinterpret_cast<bf16_t*>(h.p), n);
+        fe_cast_kernel<<<(int)((n + 255) / 256), 256, 0, s>>>(dst[i].f(), reinterpret_cast<h16_t*>(h.p), n);
         HIPCHK(hipStreamSynchronize(s));
         buf_free(dst[i]);
         dst[i] = h;
@@ -321,7 +321,7 @@ static int fe_features(a2p_frontend_ctx* f, const float* wav48, int64_t L, int l
   ARG(T0 >= 1, "sequence of %lld samples is shorter than the first conv kernel", (long long)L);
   {
     const dim3 g0((unsigned)((T0 + FE0_TB - 1) / FE0_TB), (unsigned)((C + 255) / 256));
-    if (f->conv16) fe_conv0_kernel<bf16_t><<<g0, 256, 0, s>>>(f->pcm.f(), cw[0].f(), reinterpret_cast<bf16_t*>(f->act[0].p), T0, C, kFeK[0], kFeS[0]);
+    if (f->conv16) fe_conv0_kernel<h16_t><<<g0, 256, 0, s>>>(f->pcm.f(), cw[0].f(), reinterpret_cast<h16_t*>(f->act[0].p), T0, C, kFeK[0], kFeS[0]);
     else fe_conv0_kernel<float><<<g0, 256, 0, s>>>(f->pcm.f(), cw[0].f(), f->act[0].f(), T0, C, kFeK[0], kFeS[0]);
   }
   n = T0;

@@ -138,6 +138,10 @@ struct a2p_ctx {
   // the dilated conv tail 7e-4 of the body model's 8.2e-4): input_projection, final_layer and the pose conv tail run as
   // exact-fp32 MFMA GEMMs on fp32 buffers (< 3 % of a step's FLOPs).  A2P_TAIL16=1 restores the all-16-bit path for A/B runs.
   bool tail32 = false;
+  // ... and by default not as fp32 MFMA (1/16 of the 16-bit rate: -14 % steps/s for the body model) but as SPLIT-OPERAND 16-bit
+  // GEMMs (kernels_misc.h split3_kernel: hi/lo pairs, three products per element over a 3x longer contraction; the dropped lo*lo
+  // term is 2^-22 relative).  A2P_TAIL_F32=1 keeps the fp32 MFMA islands for A/B runs.
+  bool tail_x3 = false;
   size_t esz;
   int64_t rows_cap, conv_rows;
   std::map<std::string, Buf> w;   // fp32 parameters by reference state_dict key
@@ -163,7 +167,7 @@ struct a2p_ctx {
   unsigned clk_turn = 0;
   int pB = 0, pS0 = 0, pT = 0, pK = 0;
   // workspaces
-  Buf x, xn, xr, qk, vt, ao, hff, inpack, mo, cb[4];
+  Buf x, xn, xr, qk, vt, ao, hff, inpack, mo, cb[4], t3;
   Buf emb, th, tct, tvec, mt, tokn, tokr, film, ktail, vtail;
   Buf ce_pack, pooled, tmpa, tmpb, kf_pack, kf_tok;
   // timing
@@ -262,8 +266,8 @@ static int launch_gemm(a2p_ctx* c, const GemmP& p, hipStream_t s) {
   // 2-deep ring; they take the 4-deep one (A2P_GEMM_RING2=1 keeps the 2-deep ring for A/B runs)
   static const bool ring2 = getenv("A2P_GEMM_RING2") != nullptr;
   const int64_t blocks64 = (int64_t)((p.N + 127) / 128) * ((p.M + 63) / 64);
-  if (c->bf16 && small && blocks64 <= 256 && p.ntaps == 1 && !ring2) rc = gemm_dispatch<bf16_t, 2, 4>(kt, p, s);
-  else if (c->bf16) rc = small ? gemm_dispatch<bf16_t, 2>(kt, p, s) : gemm_dispatch<bf16_t, 4>(kt, p, s);
+  if (c->bf16 && small && blocks64 <= 256 && p.ntaps == 1 && !ring2) rc = gemm_dispatch<h16_t, 2, 4>(kt, p, s);
+  else if (c->bf16) rc = small ? gemm_dispatch<h16_t, 2>(kt, p, s) : gemm_dispatch<h16_t, 4>(kt, p, s);
   else rc = small ? gemm_dispatch<float, 2>(kt, p, s) : gemm_dispatch<float, 4>(kt, p, s);
   CHK(rc);
   HIPCHK(hipGetLastError());
@@ -292,10 +296,10 @@ static int launch_ln_rope(a2p_ctx* c, bool as_f32, const float* x, int64_t ldx, 
   KernelTimer kt(c, A2P_KERNEL_LNROPE);
   const bool b16 = c->bf16 && !as_f32;
   if (c->d == 512) {
-    if (b16) A2P_LAUNCH(kt, (ln_rope_kernel<bf16_t, 8>), grid, 256, s, p);
+    if (b16) A2P_LAUNCH(kt, (ln_rope_kernel<h16_t, 8>), grid, 256, s, p);
     else A2P_LAUNCH(kt, (ln_rope_kernel<float, 8>), grid, 256, s, p);
   } else {
-    if (b16) A2P_LAUNCH(kt, (ln_rope_kernel<bf16_t, 4>), grid, 256, s, p);
+    if (b16) A2P_LAUNCH(kt, (ln_rope_kernel<h16_t, 4>), grid, 256, s, p);
     else A2P_LAUNCH(kt, (ln_rope_kernel<float, 4>), grid, 256, s, p);
   }
   HIPCHK(hipGetLastError());
@@ -317,12 +321,12 @@ static int launch_attn(a2p_ctx* c, const AttnP& p0, int nseq, int kind, hipStrea
     ARG(!c->bf16, "head_dim 128 is instantiated for fp32 only");
     A2P_LAUNCH(kt, (attn_kernel<float, 128>), grid, 256, s, p);
   } else if (c->DH == 64) {
-    if (c->bf16 && nwv == 2) A2P_LAUNCH(kt, (attn_kernel<bf16_t, 64, 0, 2>), grid, 128, s, p);
-    else if (c->bf16) A2P_LAUNCH(kt, (attn_kernel<bf16_t, 64>), grid, 256, s, p);
+    if (c->bf16 && nwv == 2) A2P_LAUNCH(kt, (attn_kernel<h16_t, 64, 0, 2>), grid, 128, s, p);
+    else if (c->bf16) A2P_LAUNCH(kt, (attn_kernel<h16_t, 64>), grid, 256, s, p);
     else A2P_LAUNCH(kt, (attn_kernel<float, 64>), grid, 256, s, p);
   } else {
-    if (c->bf16 && nwv == 2) A2P_LAUNCH(kt, (attn_kernel<bf16_t, 32, 0, 2>), grid, 128, s, p);
-    else if (c->bf16) A2P_LAUNCH(kt, (attn_kernel<bf16_t, 32>), grid, 256, s, p);
+    if (c->bf16 && nwv == 2) A2P_LAUNCH(kt, (attn_kernel<h16_t, 32, 0, 2>), grid, 128, s, p);
+    else if (c->bf16) A2P_LAUNCH(kt, (attn_kernel<h16_t, 32>), grid, 256, s, p);
     else A2P_LAUNCH(kt, (attn_kernel<float, 32>), grid, 256, s, p);
   }
   HIPCHK(hipGetLastError());
@@ -333,7 +337,7 @@ static int launch_cast(a2p_ctx* c, const float* src, int64_t lds, void* dst, int
                        const uint8_t* keep, hipStream_t s, int src_col_stride = 1) {
   const int64_t n = rows * cols_pad;
   const int grid = (int)((n + 255) / 256);
-  if (c->bf16) cast_pad_kernel<bf16_t><<<grid, 256, 0, s>>>(src, lds, src_col_stride, (bf16_t*)dst, ldd, rows, cols, cols_pad, keep);
+  if (c->bf16) cast_pad_kernel<h16_t><<<grid, 256, 0, s>>>(src, lds, src_col_stride, (h16_t*)dst, ldd, rows, cols, cols_pad, keep);
   else cast_pad_kernel<float><<<grid, 256, 0, s>>>(src, lds, src_col_stride, (float*)dst, ldd, rows, cols, cols_pad, keep);
   HIPCHK(hipGetLastError());
   return 0;
@@ -408,6 +412,16 @@ static void expected_weights(const a2p_ctx* c, std::map<std::string, int64_t>& e
 
 static float* W32(a2p_ctx* c, const std::string& n) { return c->w.at(n).f(); }
 
+// split-operand copy [rows][3 * rup(cols, 64)] = [hi | hi | lo] of a [rows, cols] fp32 matrix (row stride lds, column stride cs)
+static int make_wt3(a2p_ctx* c, Buf& b, const float* src, int64_t lds, int cs, int rows, int cols, hipStream_t s) {
+  const int kp = rup(cols, 64);
+  CHK(buf_alloc(b, (size_t)rows * 3 * kp * 2));
+  const int64_t n = (int64_t)rows * kp;
+  split3_kernel<<<(int)((n + 255) / 256), 256, 0, s>>>(src, lds, cs, reinterpret_cast<h16_t*>(b.p), rows, cols, kp, 1);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
 // compute-dtype copy of a [rows, cols] fp32 matrix, K padded to a multiple of 64
 static int make_wt(a2p_ctx* c, const std::string& name, const float* src, int rows, int cols, hipStream_t s, Buf* into = nullptr) {
   const int kp = rup(cols, 64);
@@ -448,7 +462,8 @@ extern "C" int a2p_ctx_create(const a2p_config* cfg, a2p_ctx** out) {
   c->KFmax = (c->Tmax + cfg->keyframe_step - 1) / cfg->keyframe_step;
   c->bf16 = cfg->precision == A2P_PREC_BF16; c->esz = c->bf16 ? 2 : 4;
   c->tail32 = c->bf16 && !getenv("A2P_TAIL16");
-  const size_t tsz = c->tail32 ? 4 : c->esz;   // element size of the exact-fp32 islands' buffers
+  c->tail_x3 = c->tail32 && !getenv("A2P_TAIL_F32");
+  const size_t tsz = c->tail_x3 ? 6 : (c->tail32 ? 4 : c->esz);   // bytes per element of the exact islands' buffers (split rows: 3 x 16 bit)
   ARG(c->KFmax <= 64, "too many keyframes");
   const int64_t r1 = (int64_t)c->Nmax * c->Tmax, r2 = (int64_t)c->Bmax * c->S0max;
   c->rows_cap = (r1 > r2 ? r1 : r2) + 128;
@@ -461,6 +476,7 @@ extern "C" int a2p_ctx_create(const a2p_config* cfg, a2p_ctx** out) {
   A(c->vt, (size_t)c->Nmax * d * c->Tld * c->esz);
   A(c->inpack, (size_t)c->Bmax * c->Tmax * c->Cpad * tsz);
   A(c->mo, (size_t)c->conv_rows * c->C * 4);
+  if (c->tail_x3) A(c->t3, (size_t)R * 3 * d * 2);   // split rows of the residual stream for final_layer
   if (c->pose) {
     A(c->cb[0], (size_t)c->conv_rows * 128 * tsz); A(c->cb[1], (size_t)c->conv_rows * 256 * tsz);
     A(c->cb[2], (size_t)c->conv_rows * 128 * tsz); A(c->cb[3], (size_t)c->conv_rows * 128 * tsz);
@@ -503,7 +519,7 @@ extern "C" int a2p_ctx_destroy(a2p_ctx* c) {
                 &c->k2c, &c->vt2c, &c->slot_cond, &c->slot_unc, &c->slot_cfg, &c->x, &c->xn, &c->xr, &c->qk, &c->vt, &c->ao,
                 &c->hff, &c->inpack, &c->mo, &c->cb[0], &c->cb[1], &c->cb[2], &c->cb[3], &c->emb, &c->th, &c->tct, &c->tvec,
                 &c->mt, &c->tokn, &c->tokr, &c->film, &c->ktail, &c->vtail, &c->ce_pack, &c->pooled, &c->tmpa, &c->tmpb,
-                &c->kf_pack, &c->kf_tok, &c->clk};
+                &c->kf_pack, &c->kf_tok, &c->clk, &c->t3};
   for (Buf* b : all) buf_free(*b);
   for (int i = 0; i < 7; ++i) buf_free(c->conv_wt[i]);
   for (auto& b : c->ch_stream) buf_free(b);
@@ -606,7 +622,10 @@ extern "C" int a2p_finalize_weights(a2p_ctx* c, void* stream) {
     HIPCHK(hipMemcpy(c->time_freq.p, tf.data(), half * 4, hipMemcpyHostToDevice));
   }
   // compute-dtype copies of every GEMM weight
-  {
+  if (c->tail_x3) {   // split weight rows [hi | hi | lo]
+    CHK(make_wt3(c, c->wt["input_projection.weight"], W32(c, "input_projection.weight"), c->C, 1, d, c->C, s));
+    CHK(make_wt3(c, c->wt["final_layer.weight"], W32(c, "final_layer.weight"), d, 1, c->C, d, s));
+  } else {
     Fp32Scope f32(c, c->tail32);
     CHK(make_wt(c, "input_projection.weight", W32(c, "input_projection.weight"), d, c->C, s));
     CHK(make_wt(c, "final_layer.weight", W32(c, "final_layer.weight"), c->C, d, s));
@@ -691,10 +710,20 @@ extern "C" int a2p_finalize_weights(a2p_ctx* c, void* stream) {
     // conv tail weights [Co, Ci, 3] -> [tap][Co][CiPad]
     const int C = c->C, hid = C > 256 ? C : 256;
     const int ci[7] = {C, hid, C, C, C, C, C}, co[7] = {hid, C, C, C, C, C, C};
-    Fp32Scope f32(c, c->tail32);
+    Fp32Scope f32(c, c->tail32 && !c->tail_x3);
     for (int i = 0; i < 7; ++i) {
       const int taps = i < 6 ? 3 : 1, cip = rup(ci[i], 64);
       const std::string nm = i < 6 ? "post_pose_layers." + std::to_string(i) + ".weight" : "final_conv.weight";
+      if (c->tail_x3) {   // [tap][Co][3 * CiPad] split rows
+        CHK(buf_alloc(c->conv_wt[i], (size_t)taps * co[i] * 3 * cip * 2));
+        for (int t = 0; t < taps; ++t) {
+          const int64_t n = (int64_t)co[i] * cip;
+          split3_kernel<<<(int)((n + 255) / 256), 256, 0, s>>>(W32(c, nm) + t, (int64_t)ci[i] * taps, taps,
+                                                              reinterpret_cast<h16_t*>(c->conv_wt[i].p) + (int64_t)t * co[i] * 3 * cip, co[i], ci[i], cip, 1);
+        }
+        HIPCHK(hipGetLastError());
+        continue;
+      }
       CHK(buf_alloc(c->conv_wt[i], (size_t)taps * co[i] * cip * c->esz));
       for (int t = 0; t < taps; ++t)  // src element (co, ci, tap) at (co*Ci + ci)*taps + tap
         CHK(launch_cast(c, W32(c, nm) + t, (int64_t)ci[i] * taps, c->offT(c->conv_wt[i], (int64_t)t * co[i] * cip), cip, co[i], ci[i],

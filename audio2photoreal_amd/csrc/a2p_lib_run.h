@@ -113,12 +113,12 @@ static void pk_gemm(std::vector<ChainPackDesc>& v, const void* W, int ldw, int n
   const int nt = (nrows + 127) / 128;
   if (group <= 0) {
     for (int t = 0; t < nt; ++t)
-      for (int ks = 0; ks < K / 64; ++ks) v.push_back({reinterpret_cast<const bf16_t*>(W), ldw, t * 128, ks * 64, nrows, omap});
+      for (int ks = 0; ks < K / 64; ++ks) v.push_back({reinterpret_cast<const h16_t*>(W), ldw, t * 128, ks * 64, nrows, omap});
     return;
   }
   for (int t0 = 0; t0 < nt; t0 += group)
     for (int ks = 0; ks < K / 64; ++ks)
-      for (int t = t0; t < t0 + group && t < nt; ++t) v.push_back({reinterpret_cast<const bf16_t*>(W), ldw, t * 128, ks * 64, nrows, omap});
+      for (int t = t0; t < t0 + group && t < nt; ++t) v.push_back({reinterpret_cast<const h16_t*>(W), ldw, t * 128, ks * 64, nrows, omap});
 }
 
 static int chain_pack(a2p_ctx* c, int idx, const std::vector<ChainPackDesc>& descs, const std::vector<std::pair<const float*, int>>& aux,
@@ -130,7 +130,7 @@ static int chain_pack(a2p_ctx* c, int idx, const std::vector<ChainPackDesc>& des
   for (int w8 = 0; w8 < 2; ++w8) {  // both slice layouts: 4 waves x 32 out-cols and 8 waves x 16 (chain_pick_nw chooses per box)
     Buf& st = c->ch_stream[(size_t)w8 * c->L * 4 + idx];
     CHK(buf_alloc(st, (descs.size() + pad) * CHAIN_STAGE_ELEMS * 2));
-    chain_pack_kernel<<<(int)descs.size(), 256, 0, s>>>(reinterpret_cast<const ChainPackDesc*>(dd.p), reinterpret_cast<bf16_t*>(st.p), w8 ? 8 : 4);
+    chain_pack_kernel<<<(int)descs.size(), 256, 0, s>>>(reinterpret_cast<const ChainPackDesc*>(dd.p), reinterpret_cast<h16_t*>(st.p), w8 ? 8 : 4);
   }
   Buf dd2;
   {  // second-generation kernels (kernels_chain2.h): the same stages (POST: in the software-pipelined order `descs_gen2`) as MFMA
@@ -144,7 +144,7 @@ static int chain_pack(a2p_ctx* c, int idx, const std::vector<ChainPackDesc>& des
     }
     Buf& st = c->ch_stream[(size_t)2 * c->L * 4 + idx];
     CHK(buf_alloc(st, (d2.size() + pad) * CHAIN_STAGE_ELEMS * 2));
-    chain2_pack_kernel<<<(int)d2.size(), 256, 0, s>>>(dev, reinterpret_cast<bf16_t*>(st.p));
+    chain2_pack_kernel<<<(int)d2.size(), 256, 0, s>>>(dev, reinterpret_cast<h16_t*>(st.p));
     c->ch_nstages[idx] = (int)d2.size();
   }
   HIPCHK(hipGetLastError());
@@ -192,11 +192,11 @@ static int chain_build_streams(a2p_ctx* c, hipStream_t s) {
     const Buf& w1 = c->wt.at(pf(l) + "linear1.weight");
     const Buf& w2 = c->wt.at(pf(l) + "linear2.weight");
     auto lin1 = [&](std::vector<ChainPackDesc>& v, int h) {
-      for (int ks = 0; ks < d / 64; ++ks) v.push_back({reinterpret_cast<const bf16_t*>(w1.p), d, h * 128, ks * 64, ff, 0});
+      for (int ks = 0; ks < d / 64; ++ks) v.push_back({reinterpret_cast<const h16_t*>(w1.p), d, h * 128, ks * 64, ff, 0});
     };
     auto lin2 = [&](std::vector<ChainPackDesc>& v, int h) {
       for (int ks = 0; ks < 2; ++ks)   // k-major over the d/128 output tiles (chain_body::gemm_group)
-        for (int t = 0; t < d / 128; ++t) v.push_back({reinterpret_cast<const bf16_t*>(w2.p), ff, t * 128, h * 128 + ks * 64, d, 0});
+        for (int t = 0; t < d / 128; ++t) v.push_back({reinterpret_cast<const h16_t*>(w2.p), ff, t * 128, h * 128 + ks * 64, d, 0});
     };
     const int FTn = ff / 128;
     for (int h = 0; h < FTn; ++h) { lin1(q, h); lin2(q, h); }
@@ -216,8 +216,8 @@ static int chain_build_streams(a2p_ctx* c, hipStream_t s) {
 static void chain_base(a2p_ctx* c, ChainP& p, int N, int T, int idx, int aux_floats) {
   memset(&p, 0, sizeof(p));
   p.M = N * T; p.rows_per_seq = T; p.x = c->x.f(); p.cst = reinterpret_cast<const f32x4*>(c->rope_cst.p); p.cs_npos = c->rope_npos;
-  p.ain = reinterpret_cast<const bf16_t*>(c->ao.p); p.ld_ain = c->d;
-  p.stream = reinterpret_cast<const bf16_t*>(c->ch_stream[(size_t)(c->ch_ver == 2 ? 2 : (c->ch_nw == 8)) * c->L * 4 + idx].p);
+  p.ain = reinterpret_cast<const h16_t*>(c->ao.p); p.ld_ain = c->d;
+  p.stream = reinterpret_cast<const h16_t*>(c->ch_stream[(size_t)(c->ch_ver == 2 ? 2 : (c->ch_nw == 8)) * c->L * 4 + idx].p);
   p.aux = c->ch_aux[idx].f(); p.aux_kb = (aux_floats + 255) / 256;
   if (c->ch_ver == 2) {   // stream leaders (kernels_chain2.h): one workgroup per XCD walks the weight stream ahead of the consumers
     // off by default: -14 % kernel time when L2 and MALL are cold (scratch/chain2_bench), nothing inside the step
@@ -235,8 +235,8 @@ static void chain_set_pre(a2p_ctx* c, ChainP& p, int l, int T) {
   const int d = c->d;
   const std::string pf = "seqTransDecoder.stack." + std::to_string(l) + ".";
   p.lnB_g = W32(c, pf + "norm1.weight"); p.lnB_b = W32(c, pf + "norm1.bias");
-  p.qk_out = reinterpret_cast<bf16_t*>(c->qk.p); p.ld_qk = 2 * d;
-  p.vt_out = reinterpret_cast<bf16_t*>(c->vt.p);
+  p.qk_out = reinterpret_cast<h16_t*>(c->qk.p); p.ld_qk = 2 * d;
+  p.vt_out = reinterpret_cast<h16_t*>(c->vt.p);
   const int Tld = rup(T, 64);
   p.vt_seq_stride = (int64_t)d * Tld; p.ld_vt = Tld;
 }
@@ -486,7 +486,7 @@ static int decoder_layer_chain(a2p_ctx* c, int l, int N, int T, const CrossKV& k
     chain_base(c, p, N, T, ch_index(l, kind), d);
     chain_set_out_proj(c, p, pf + attn_done, fr, film_idx);
     p.lnA_g = W32(c, pf + norm + ".weight"); p.lnA_b = W32(c, pf + norm + ".bias");
-    p.q_out = reinterpret_cast<bf16_t*>(c->qk.p); p.ld_q = d;
+    p.q_out = reinterpret_cast<h16_t*>(c->qk.p); p.ld_q = d;
     if (shared_half && kind == CH_MID) {
       p.src_rows = (N / 2) * T;
       p.xsrc = x0;
@@ -629,27 +629,30 @@ static int pose_conv_tail(a2p_ctx* c, int N, int T, hipStream_t s) {
   const int C = c->C, hid = C > 256 ? C : 256, R = T + 24;
   const int M = N * R;
   const int ci[6] = {C, hid, C, C, C, C}, co[6] = {hid, C, C, C, C, C}, dil[6] = {1, 2, 3, 1, 2, 3};
+  const int X = c->tail_x3 ? 3 : 1;   // split-operand rows are [hi | lo | hi]: three times as wide, contraction three times as long
   Buf* src = &c->cb[0];
   int cur = 0;
   for (int i = 0; i < 6; ++i) {
     const int cip = rup(ci[i], 64), cop = rup(co[i], 64);
     Buf* dst = (i == 0) ? &c->cb[1] : ((cur == 2) ? &c->cb[3] : &c->cb[2]);
-    GemmP p = gemm_base(src->p, cip, c->conv_wt[i].p, cip, W32(c, "post_pose_layers." + std::to_string(i) + ".bias"), dst->p, cop, M,
-                        co[i], cip);
+    GemmP p = gemm_base(src->p, X * cip, c->conv_wt[i].p, X * cip, W32(c, "post_pose_layers." + std::to_string(i) + ".bias"), dst->p, X * cop, M,
+                        co[i], X * cip);
     p.ntaps = 3;
-    p.a_tap_stride = (int64_t)dil[i] * cip;
-    p.w_tap_stride = (int64_t)co[i] * cip;
+    p.a_tap_stride = (int64_t)dil[i] * X * cip;
+    p.w_tap_stride = (int64_t)co[i] * X * cip;
     p.epi = EPI_CONV;
     p.act = ACT_LRELU;
+    if (c->tail_x3) p.split_third = cop;
     if (ci[i] == co[i]) {  // out = (in[t + 2*dil] + y) / 2
-      p.skip = c->offT(*src, (int64_t)2 * dil[i] * cip);
-      p.ld_skip = cip;
+      p.skip = c->offT(*src, (int64_t)2 * dil[i] * X * cip);
+      p.ld_skip = X * cip;
+      if (c->tail_x3) p.skip_lo = cip;
     }
     CHK(launch_gemm(c, p, s));
     src = dst;
     cur = (dst == &c->cb[2]) ? 2 : (dst == &c->cb[3] ? 3 : 1);
   }
-  GemmP pf = gemm_base(src->p, rup(C, 64), c->conv_wt[6].p, rup(C, 64), W32(c, "final_conv.bias"), c->mo.p, C, M, C, rup(C, 64));
+  GemmP pf = gemm_base(src->p, X * rup(C, 64), c->conv_wt[6].p, X * rup(C, 64), W32(c, "final_conv.bias"), c->mo.p, C, M, C, X * rup(C, 64));
   pf.out_f32 = 1;
   return launch_gemm(c, pf, s);
 }
@@ -691,13 +694,15 @@ static int run_forward(a2p_ctx* c, const float* x_in, const int64_t* t_orig, int
   }
   // input permute + projection (model/diffusion.py:345-346,364); exact fp32 in every mode (a2p_ctx::tail32)
   {
-    Fp32Scope f32(c, c->tail32);
+    Fp32Scope f32(c, c->tail32 && !c->tail_x3);
     dim3 grid((T + 31) / 32, (c->Cpad + 31) / 32, B);
-    if (c->bf16) pack_input_kernel<bf16_t><<<grid, 256, 0, s>>>(x_in, (bf16_t*)c->inpack.p, B, c->C, T, c->Cpad);
+    const int X = c->tail_x3 ? 3 : 1;
+    if (c->tail_x3) pack_input_split3_kernel<<<grid, 256, 0, s>>>(x_in, (h16_t*)c->inpack.p, B, c->C, T, c->Cpad);
+    else if (c->bf16) pack_input_kernel<h16_t><<<grid, 256, 0, s>>>(x_in, (h16_t*)c->inpack.p, B, c->C, T, c->Cpad);
     else pack_input_kernel<float><<<grid, 256, 0, s>>>(x_in, (float*)c->inpack.p, B, c->C, T, c->Cpad);
     const bool shared_half = use_chain && N == 2 * B && !getenv("A2P_NO_SHARED_HALF");
-    GemmP p = gemm_base(c->inpack.p, c->Cpad, c->wt.at("input_projection.weight").p, c->Cpad, W32(c, "input_projection.bias"),
-                        shared_half ? c->hff.p : c->x.p, d, B * T, d, c->Cpad);
+    GemmP p = gemm_base(c->inpack.p, X * c->Cpad, c->wt.at("input_projection.weight").p, X * c->Cpad, W32(c, "input_projection.bias"),
+                        shared_half ? c->hff.p : c->x.p, d, B * T, d, X * c->Cpad);
     p.out_f32 = c->bf16 ? 1 : 0;   // gemm_kernel<float> stores fp32 either way; the flag only selects a 16-bit kernel instance
     CHK(launch_gemm(c, p, s));
     if (N == 2 * B && !shared_half) {   // chain path under guidance: layer 0 reads the one copy for both halves (decoder_layer_chain)
@@ -740,21 +745,27 @@ static int run_forward(a2p_ctx* c, const float* x_in, const int64_t* t_orig, int
     *mo_seq_rows = T;
     return 0;
   }
-  // fp32 GEMMs read the residual stream in place; the all-16-bit variant casts it first
-  Fp32Scope f32(c, c->tail32);
+  // fp32 GEMMs read the residual stream in place; the split-operand variant splits it, the all-16-bit variant casts it first
+  Fp32Scope f32(c, c->tail32 && !c->tail_x3);
   const void* rows = c->x.p;
-  if (c->bf16) {
+  const int X = c->tail_x3 ? 3 : 1;
+  if (c->tail_x3) {
+    const int64_t n = (int64_t)N * T * d;
+    split3_kernel<<<(int)((n + 255) / 256), 256, 0, s>>>(c->x.f(), d, 1, reinterpret_cast<h16_t*>(c->t3.p), (int64_t)N * T, d, d, 0);
+    rows = c->t3.p;
+  } else if (c->bf16) {
     CHK(launch_ln_rope(c, false, c->x.f(), d, nullptr, nullptr, c->xn.p, nullptr, d, N * T, T, 0, s));
     rows = c->xn.p;
   }
   if (!c->pose) {
-    GemmP p = gemm_base(rows, d, c->wt.at("final_layer.weight").p, d, W32(c, "final_layer.bias"), c->mo.p, c->C, N * T, c->C, d);
+    GemmP p = gemm_base(rows, X * d, c->wt.at("final_layer.weight").p, X * d, W32(c, "final_layer.bias"), c->mo.p, c->C, N * T, c->C, X * d);
     p.out_f32 = c->bf16 ? 1 : 0;
     CHK(launch_gemm(c, p, s));
     *mo_seq_rows = T;
   } else {
-    GemmP p = gemm_base(rows, d, c->wt.at("final_layer.weight").p, d, W32(c, "final_layer.bias"), c->offT(c->cb[0], (int64_t)24 * 128),
-                        128, N * T, c->C, d);
+    GemmP p = gemm_base(rows, X * d, c->wt.at("final_layer.weight").p, X * d, W32(c, "final_layer.bias"), c->offT(c->cb[0], (int64_t)24 * X * 128),
+                        X * 128, N * T, c->C, X * d);
+    if (c->tail_x3) p.split_third = 128;
     p.rows_per_seq = T;
     p.out_seq_pad = 24;
     CHK(launch_gemm(c, p, s));
@@ -912,7 +923,7 @@ extern "C" int a2p_gemm(a2p_ctx* c, const float* A, const float* W, const float*
   return rc;
 }
 
-__global__ void widen_kernel(const bf16_t* a, float* o, int64_t n) {
+__global__ void widen_kernel(const h16_t* a, float* o, int64_t n) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) o[i] = (float)a[i];
 }
@@ -941,7 +952,7 @@ extern "C" int a2p_attention(a2p_ctx* c, const float* q, const float* k, const f
   for (int n = 0; n < N; ++n)
     CHK(launch_cast(c, k + (size_t)n * S * d, d, c->offT(kb, (int64_t)n * Sld * d), d, S, d, d, nullptr, s));
   dim3 tg((unsigned)(((int64_t)S * d + 255) / 256), 1, N);
-  if (c->bf16) transpose_cast_kernel<bf16_t><<<tg, 256, 0, s>>>(v, (bf16_t*)vb.p, S, d, Sld);
+  if (c->bf16) transpose_cast_kernel<h16_t><<<tg, 256, 0, s>>>(v, (h16_t*)vb.p, S, d, Sld);
   else transpose_cast_kernel<float><<<tg, 256, 0, s>>>(v, (float*)vb.p, S, d, Sld);
   AttnP a;
   memset(&a, 0, sizeof(a));
@@ -956,7 +967,7 @@ extern "C" int a2p_attention(a2p_ctx* c, const float* q, const float* k, const f
   if (rc == 0) {
     if (c->bf16) {
       const int64_t n = (int64_t)N * Tq * d;
-      widen_kernel<<<(int)((n + 255) / 256), 256, 0, s>>>((const bf16_t*)ob.p, out, n);
+      widen_kernel<<<(int)((n + 255) / 256), 256, 0, s>>>((const h16_t*)ob.p, out, n);
     } else {
       hipMemcpyAsync(out, ob.p, (size_t)N * Tq * d * 4, hipMemcpyDeviceToDevice, s);
     }

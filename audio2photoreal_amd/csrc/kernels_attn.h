@@ -82,7 +82,7 @@ struct AttnLds {
 };
 
 template <int AUX>  // cache policy of the tile DMA: 0 default, 2 non-temporal
-__device__ __forceinline__ void attn_glds16(const bf16_t* gsrc, bf16_t* lds_wave_base) {
+__device__ __forceinline__ void attn_glds16(const h16_t* gsrc, h16_t* lds_wave_base) {
   __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
                                    (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, AUX);
 }
@@ -195,10 +195,10 @@ __global__ __launch_bounds__(64 * NWV, 3) void attn_kernel(AttnP p) {
   };
   auto stage_dma = [&](int tile, int buf) {
     if constexpr (L::DMA) {
-      bf16_t* Ks = reinterpret_cast<bf16_t*>(smem) + buf * (L::KSZ + L::VSZ);
-      bf16_t* Vs = Ks + L::KSZ;
-      const bf16_t* Kt = reinterpret_cast<const bf16_t*>(Kb) + (int64_t)tile * KV * p.ldk;
-      const bf16_t* Vt = reinterpret_cast<const bf16_t*>(Vb) + tile * KV;
+      h16_t* Ks = reinterpret_cast<h16_t*>(smem) + buf * (L::KSZ + L::VSZ);
+      h16_t* Vs = Ks + L::KSZ;
+      const h16_t* Kt = reinterpret_cast<const h16_t*>(Kb) + (int64_t)tile * KV * p.ldk;
+      const h16_t* Vt = reinterpret_cast<const h16_t*>(Vb) + tile * KV;
       if (kv_nt) {  // block-uniform
 #pragma unroll
         for (int j = 0; j < KPW; ++j) attn_glds16<2>(Kt + kpiece(j), Ks + (j * NWV + widu) * KRPI_ * DH);
@@ -298,11 +298,11 @@ __global__ __launch_bounds__(64 * NWV, 3) void attn_kernel(AttnP p) {
     // 16-bit path: all V^T fragments of the tile are requested NOW, behind the QK^T MFMAs, so that their LDS latency passes
     // under the softmax arithmetic (hipcc otherwise sinks each ds_read_b128 directly in front of its MFMA with an
     // s_waitcnt lgkmcnt(0) between them: 8 exposed LDS round trips per tile and wave)
-    [[maybe_unused]] bf16x8 vfr[2][DVT];
+    [[maybe_unused]] h16x8 vfr[2][DVT];
     auto load_vfr = [&](int c) __attribute__((always_inline)) {
 #pragma unroll
       for (int dv = 0; dv < DVT; ++dv)
-        vfr[c][dv] = *reinterpret_cast<const bf16x8*>(&Vs[L::vidx(dv * 16 + l15, c * 32 + g * 8)]);
+        vfr[c][dv] = *reinterpret_cast<const h16x8*>(&Vs[L::vidx(dv * 16 + l15, c * 32 + g * 8)]);
     };
     if constexpr (sizeof(T) == 2) load_vfr(0);   // the second half follows the softmax (register budget: 3 waves per SIMD)
     // ---- online softmax (log2 domain); lane owns query l15, keys kt*16 + g*4 + r ----
@@ -363,18 +363,18 @@ __global__ __launch_bounds__(64 * NWV, 3) void attn_kernel(AttnP p) {
       load_vfr(1);
 #pragma unroll
       for (int c = 0; c < 2; ++c) {  // 32-key chunk: k-slot e of lane group g -> key c*32 + g*8 + e (see AttnLds::krow)
-        bf16x8 pf[QT];
+        h16x8 pf[QT];
 #pragma unroll
         for (int qt = 0; qt < QT; ++qt) {
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
-            pf[qt][r] = (bf16_t)s[2 * c][qt][r];
-            pf[qt][4 + r] = (bf16_t)s[2 * c + 1][qt][r];
+            pf[qt][r] = (h16_t)s[2 * c][qt][r];
+            pf[qt][4 + r] = (h16_t)s[2 * c + 1][qt][r];
           }
         }
 #pragma unroll
         for (int dv = 0; dv < DVT; ++dv) {
-          const bf16x8 vf = vfr[c][dv];
+          const h16x8 vf = vfr[c][dv];
 #pragma unroll
           for (int qt = 0; qt < QT; ++qt) {
             if constexpr (!(ABL & 8)) o[qt][dv] = P::mfma(vf, pf[qt], o[qt][dv]);
@@ -434,17 +434,17 @@ __global__ __launch_bounds__(64 * NWV, 3) void attn_kernel(AttnP p) {
 #pragma unroll
       for (int dv = 0; dv < DVT; ++dv) {
         const f32x4 v = o[qt][dv];
-        *reinterpret_cast<bf16x4*>(stw + (qt * 16 + l15) * SP + dv * 16 + g * 4) =
-            bf16x4{(bf16_t)(v[0] * inv), (bf16_t)(v[1] * inv), (bf16_t)(v[2] * inv), (bf16_t)(v[3] * inv)};
+        *reinterpret_cast<h16x4*>(stw + (qt * 16 + l15) * SP + dv * 16 + g * 4) =
+            h16x4{(h16_t)(v[0] * inv), (h16_t)(v[1] * inv), (h16_t)(v[2] * inv), (h16_t)(v[3] * inv)};
       }
     }
     T* Ob = reinterpret_cast<T*>(p.O) + (int64_t)seq * p.o_seq_stride + head * DH;
 #pragma unroll
     for (int i = 0; i < NPC; ++i) {
       const int pc = lane + 64 * i, row = pc / PPR, part = pc % PPR;
-      const bf16x8 v = *reinterpret_cast<const bf16x8*>(stw + row * SP + part * 8);
+      const h16x8 v = *reinterpret_cast<const h16x8*>(stw + row * SP + part * 8);
       const int q = q0 + row;
-      if (q < p.Tq) *reinterpret_cast<bf16x8*>(Ob + (int64_t)q * p.ldo + part * 8) = v;
+      if (q < p.Tq) *reinterpret_cast<h16x8*>(Ob + (int64_t)q * p.ldo + part * 8) = v;
     }
   } else {
 #pragma unroll

@@ -74,10 +74,10 @@ struct ChainP {
   // apart.  A 16-row block occupies the same bytes in both layouts and a workgroup owns whole blocks, so the buffer can change
   // layout in place; the first kernel of a forward reads row-major (input projection), the last one writes row-major.
   int x_in_tiled, x_out_tiled;
-  const bf16_t* stream;   // packed weight stream of this chain
+  const h16_t* stream;   // packed weight stream of this chain
   const float* aux;       // per-tile biases of this chain, aux_kb KiB: POST [bias_1 | bias_qk' | bias_v'], MID [bias_q], PRE [bias_qk | bias_v]
   // MID / POST: attention output panel
-  const bf16_t* ain;
+  const h16_t* ain;
   int64_t ld_ain;
   // out_proj epilogue
   const float* bias_o;
@@ -88,7 +88,7 @@ struct ChainP {
   const float* lnA_g;
   const float* lnA_b;
   // MID: query projection of the following cross attention
-  bf16_t* q_out;
+  h16_t* q_out;
   int64_t ld_q;
   // POST: feed forward
   const float* bias_2;
@@ -96,9 +96,9 @@ struct ChainP {
   // PRE work (MODE_PRE, or the tail of MODE_POST when has_next): norm1 -> rotary -> [Q|K], V^T
   const float* lnB_g;
   const float* lnB_b;
-  bf16_t* qk_out;
+  h16_t* qk_out;
   int64_t ld_qk;
-  bf16_t* vt_out;
+  h16_t* vt_out;
   int64_t vt_seq_stride, ld_vt;
   const f32x4* cst;  // rotary table in the panel layout [D/4][cs_npos]: (cos, sin) x 2 of 4 consecutive columns (rope_table_t_kernel)
   int cs_npos;
@@ -119,13 +119,13 @@ struct ChainP {
 
 // one 16 KiB stage of a packed stream: stage = rows [row0, row0+128) x k [k0, k0+64) of W[., ldw]
 struct ChainPackDesc {
-  const bf16_t* W;
+  const h16_t* W;
   int ldw, row0, k0, nrows;  // rows >= nrows are zero-filled
   int omap;                  // 1: stage of a GEMM whose output tiles go straight to HBM (chain_body::gemm_store): the 8-wave slices use
                              // the PAIRED column map below (the 4-wave slices are the same for both values)
 };
 
-__global__ __launch_bounds__(256) void chain_pack_kernel(const ChainPackDesc* __restrict__ descs, bf16_t* __restrict__ dst, int nw) {
+__global__ __launch_bounds__(256) void chain_pack_kernel(const ChainPackDesc* __restrict__ descs, h16_t* __restrict__ dst, int nw) {
   const ChainPackDesc d = descs[blockIdx.x];
   uint4* out = reinterpret_cast<uint4*>(dst + (int64_t)blockIdx.x * CHAIN_STAGE_ELEMS);
   const int cw = 128 / nw;  // out-cols (weight rows) per wave: 32 (4 waves) or 16 (8 waves)
@@ -176,13 +176,13 @@ __device__ __forceinline__ void chain_st4(float* p, f32x4 v) {
   if constexpr (CHAIN_NT_ST) __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(p));
   else *reinterpret_cast<f32x4*>(p) = v;
 }
-__device__ __forceinline__ void chain_st_bf8(bf16_t* p, bf16x8 v) {
-  if constexpr (CHAIN_NT_ST) __builtin_nontemporal_store(v, reinterpret_cast<bf16x8*>(p));
-  else *reinterpret_cast<bf16x8*>(p) = v;
+__device__ __forceinline__ void chain_st_bf8(h16_t* p, h16x8 v) {
+  if constexpr (CHAIN_NT_ST) __builtin_nontemporal_store(v, reinterpret_cast<h16x8*>(p));
+  else *reinterpret_cast<h16x8*>(p) = v;
 }
-__device__ __forceinline__ void chain_st_bf4(bf16_t* p, bf16x4 v) {
-  if constexpr (CHAIN_NT_ST) __builtin_nontemporal_store(v, reinterpret_cast<bf16x4*>(p));
-  else *reinterpret_cast<bf16x4*>(p) = v;
+__device__ __forceinline__ void chain_st_bf4(h16_t* p, h16x4 v) {
+  if constexpr (CHAIN_NT_ST) __builtin_nontemporal_store(v, reinterpret_cast<h16x4*>(p));
+  else *reinterpret_cast<h16x4*>(p) = v;
 }
 
 // LDS-only barrier: never waits for the DMA queue
@@ -207,7 +207,7 @@ struct ChainLds {
 
 // The chain of one row panel: rows [m0, m0 + 16*MT) of the launch, LDS at `smem` (ChainLds<D, MT>::ELEMS elements).
 template <int D, int MT, int MODE, int ABL, int NW>
-__device__ __forceinline__ void chain_body(const ChainP& p, bf16_t* const smem, const int m0) {
+__device__ __forceinline__ void chain_body(const ChainP& p, h16_t* const smem, const int m0) {
   constexpr int CW = 128 / NW;   // columns of a 128-column tile owned by one wave
   constexpr int NJ = CW / 16;    // 16-column sub-tiles per wave per tile
   constexpr int PCS = CW / 8;    // 1 KiB LDS-DMA pieces per wave per stage
@@ -223,11 +223,11 @@ __device__ __forceinline__ void chain_body(const ChainP& p, bf16_t* const smem, 
   static_assert(ChainLds<D, MT>::AUX_F == AUX_F && ChainLds<D, MT>::BM == BM && HLD == 128, "ChainLds out of step");
   static_assert(NS >= 3, "panel too tall for a 3-deep weight ring");
   constexpr int WSLICE = CHAIN_STAGE_ELEMS / NW;  // elements per wave per stage
-  bf16_t* const panelA = smem;
-  bf16_t* const panelH = panelA + BM * D;
+  h16_t* const panelA = smem;
+  h16_t* const panelH = panelA + BM * D;
   float* const red = reinterpret_cast<float*>(panelH + BM * HLD);  // [2][8][BM]: LayerNorm partial sums per 16-column group
   float* const aux = red + 16 * BM;                                  // [AUX_F]
-  bf16_t* const ring = reinterpret_cast<bf16_t*>(aux + AUX_F);      // [wave][NS][32][64]
+  h16_t* const ring = reinterpret_cast<h16_t*>(aux + AUX_F);      // [wave][NS][32][64]
 
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int l15 = lane & 15, g = lane >> 4;
@@ -243,15 +243,15 @@ __device__ __forceinline__ void chain_body(const ChainP& p, bf16_t* const smem, 
     p.clk[blockIdx.x * 4 + 0] = __builtin_readcyclecounter();
     p.clk[blockIdx.x * 4 + 1] = wall_clock64();
   }
-  bf16_t* const myring = ring + wid * NS * WSLICE;
+  h16_t* const myring = ring + wid * NS * WSLICE;
 
   // ---- weight stream ---------------------------------------------------------------------------------------
-  const bf16_t* wsrc = p.stream + wid * WSLICE + lane * 8;  // this lane's 16 bytes of instruction 0 of stage 0
+  const h16_t* wsrc = p.stream + wid * WSLICE + lane * 8;  // this lane's 16 bytes of instruction 0 of stage 0
   // ring positions as running element offsets with a compare-and-wrap (a `% NS` with NS = 5 costs a multiply-high chain of
   // scalar instructions per stage, and with one wave per SIMD every instruction is 4 issue cycles)
   int issue_off = 0, consume_off = 0;
   auto issue_stage = [&]() __attribute__((always_inline)) {
-    bf16_t* buf = myring + issue_off;
+    h16_t* buf = myring + issue_off;
     if constexpr (!(ABL & 4)) {  // 4 x 1 KiB; the instruction offset advances the global AND the LDS address (one M0 write per stage)
       const auto gp = (const __attribute__((address_space(1))) void*)wsrc;
       const auto lp = (__attribute__((address_space(3))) void*)buf;
@@ -266,34 +266,34 @@ __device__ __forceinline__ void chain_body(const ChainP& p, bf16_t* const smem, 
     issue_off = issue_off + WSLICE == NS * WSLICE ? 0 : issue_off + WSLICE;
   };
   // wait for this wave's oldest slice (NS-2 newer ones stay in flight), hand the just-freed slot to the DMA
-  auto stage_begin = [&]() __attribute__((always_inline)) -> const bf16_t* {
+  auto stage_begin = [&]() __attribute__((always_inline)) -> const h16_t* {
     // lgkmcnt(0): the fragment reads of the slot that is about to be refilled have returned
     if constexpr (!(ABL & 4)) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(PCS * (NS - 2)) : "memory");
     // pin the step boundary: hipcc otherwise hoists the NEXT step's MFMAs above this wait, right behind their fragment
     // reads, which un-pipelines the loop (cdna_hip_programming.md §5.4 rule 18)
     __builtin_amdgcn_sched_barrier(0);
     issue_stage();
-    const bf16_t* wb = myring + consume_off;
+    const h16_t* wb = myring + consume_off;
     consume_off = consume_off + WSLICE == NS * WSLICE ? 0 : consume_off + WSLICE;
     return wb;
   };
   // one k-step (64) of a [BM x 128] tile = this wave's fragments of 2 MFMA k-chunks.  Reads and MFMAs are split so the
   // reads of step s+1 are in flight while the MFMAs of step s issue (one wave per SIMD: nobody else hides LDS latency).
   struct Frags {
-    bf16x8 a[2][MT], w[2][NJ];
+    h16x8 a[2][MT], w[2][NJ];
   };
-  auto load_frags = [&](Frags& f, const bf16_t* P, int pld, int kchunk0, const bf16_t* wb) __attribute__((always_inline)) {
+  auto load_frags = [&](Frags& f, const h16_t* P, int pld, int kchunk0, const h16_t* wb) __attribute__((always_inline)) {
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk) {
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt)
         if constexpr (ABL & 16) asm volatile("" : "=v"(f.a[kk][mt]));
-        else f.a[kk][mt] = *reinterpret_cast<const bf16x8*>(P + (mt * 16 + l15) * pld + (((kchunk0 + kk * 4 + g) ^ l15) << 3));
+        else f.a[kk][mt] = *reinterpret_cast<const h16x8*>(P + (mt * 16 + l15) * pld + (((kchunk0 + kk * 4 + g) ^ l15) << 3));
 #pragma unroll
       for (int j = 0; j < NJ; ++j) {
         const int wrow = j * 16 + l15;
         if constexpr (ABL & 16) asm volatile("" : "=v"(f.w[kk][j]));
-        else f.w[kk][j] = *reinterpret_cast<const bf16x8*>(wb + wrow * 64 + (((kk * 4 + g) ^ ((wrow >> 1) & 7)) << 3));
+        else f.w[kk][j] = *reinterpret_cast<const h16x8*>(wb + wrow * 64 + (((kk * 4 + g) ^ ((wrow >> 1) & 7)) << 3));
       }
     }
   };
@@ -315,7 +315,7 @@ __device__ __forceinline__ void chain_body(const ChainP& p, bf16_t* const smem, 
         }
   };
   // acc += P[:, 0:64*nks] * (the next nks stream stages)^T, nks even
-  auto gemm_tile = [&](f32x4(&acc)[MT][NJ], const bf16_t* P, int pld, int nks, bool swap = false) __attribute__((always_inline)) {
+  auto gemm_tile = [&](f32x4(&acc)[MT][NJ], const h16_t* P, int pld, int nks, bool swap = false) __attribute__((always_inline)) {
     // Issue order inside one step (one wave per SIMD, in-order issue): each MFMA occupies the matrix pipe for 16 cycles
     // but its issue slot for 4, so the DMA pieces and fragment reads of the NEXT step are slotted between the MFMAs
     // of the current one instead of in front of them.
@@ -350,23 +350,23 @@ __device__ __forceinline__ void chain_body(const ChainP& p, bf16_t* const smem, 
   // k-major order (stage = ks*NT + t; the host packs them so): the A fragments of a k-step are read once for all NT tiles instead of
   // once per tile (8 waves are LDS-read bound: every wave reads every panel row), and the group pays one pipeline ramp instead of
   // NT.  Per tile the k-order is unchanged: same bits as the tile-major form.
-  auto gemm_group = [&](f32x4(&acc)[NT][MT][NJ], const bf16_t* P, int pld, auto nks_c, bool swap = false) __attribute__((always_inline)) {
+  auto gemm_group = [&](f32x4(&acc)[NT][MT][NJ], const h16_t* P, int pld, auto nks_c, bool swap = false) __attribute__((always_inline)) {
     constexpr int NKS = decltype(nks_c)::value, NST = NKS * NT;
-    bf16x8 a[2][2][MT], w[2][2][NJ];   // [buffer][k-chunk][...]
+    h16x8 a[2][2][MT], w[2][2][NJ];   // [buffer][k-chunk][...]
     auto load_a = [&](int buf, int ks) __attribute__((always_inline)) {
 #pragma unroll
       for (int kk = 0; kk < 2; ++kk)
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt)
-          a[buf][kk][mt] = *reinterpret_cast<const bf16x8*>(P + (mt * 16 + l15) * pld + (((ks * 8 + kk * 4 + g) ^ l15) << 3));
+          a[buf][kk][mt] = *reinterpret_cast<const h16x8*>(P + (mt * 16 + l15) * pld + (((ks * 8 + kk * 4 + g) ^ l15) << 3));
     };
-    auto load_w = [&](int buf, const bf16_t* wb) __attribute__((always_inline)) {
+    auto load_w = [&](int buf, const h16_t* wb) __attribute__((always_inline)) {
 #pragma unroll
       for (int kk = 0; kk < 2; ++kk)
 #pragma unroll
         for (int j = 0; j < NJ; ++j) {
           const int wrow = j * 16 + l15;
-          w[buf][kk][j] = *reinterpret_cast<const bf16x8*>(wb + wrow * 64 + (((kk * 4 + g) ^ ((wrow >> 1) & 7)) << 3));
+          w[buf][kk][j] = *reinterpret_cast<const h16x8*>(wb + wrow * 64 + (((kk * 4 + g) ^ ((wrow >> 1) & 7)) << 3));
         }
     };
     load_a(0, 0);
@@ -639,7 +639,7 @@ __device__ __forceinline__ void chain_body(const ChainP& p, bf16_t* const smem, 
       }
     }
     // rows -> bf16 panel: with 4 waves a lane's two sub-tiles are adjacent columns, so one 16-byte LDS write per (row, tile)
-    auto norm4 = [&](int mt, int ns) __attribute__((always_inline)) -> bf16x4 {
+    auto norm4 = [&](int mt, int ns) __attribute__((always_inline)) -> h16x4 {
       // (x - mean) * rstd as one fma per element: x * rstd + (-mean * rstd)
       const float rs = ln_rstd[mt], nm = -ln_mean[mt] * rs;
       float v0 = fmaf(fmaf(xrow[mt][ns][0], rs, nm), ga[ns][0], be[ns][0]);
@@ -652,19 +652,19 @@ __device__ __forceinline__ void chain_body(const ChainP& p, bf16_t* const smem, 
         const float r2 = fmaf(v2, t[2], -(v3 * t[3])), r3 = fmaf(v3, t[2], v2 * t[3]);
         v0 = r0; v1 = r1; v2 = r2; v3 = r3;
       }
-      return bf16x4{(bf16_t)v0, (bf16_t)v1, (bf16_t)v2, (bf16_t)v3};
+      return h16x4{(h16_t)v0, (h16_t)v1, (h16_t)v2, (h16_t)v3};
     };
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
       const int n = col_of(t, 0);
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt) {
-        bf16_t* dst = panelA + (mt * 16 + l15) * D + ((((n >> 3) ^ l15) << 3) | (n & 7));
+        h16_t* dst = panelA + (mt * 16 + l15) * D + ((((n >> 3) ^ l15) << 3) | (n & 7));
         if constexpr (NJ == 2) {
-          const bf16x4 lo = norm4(mt, t * NJ), hi = norm4(mt, t * NJ + 1);
-          *reinterpret_cast<bf16x8*>(dst) = bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+          const h16x4 lo = norm4(mt, t * NJ), hi = norm4(mt, t * NJ + 1);
+          *reinterpret_cast<h16x8*>(dst) = h16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
         } else {
-          *reinterpret_cast<bf16x4*>(dst) = norm4(mt, t);
+          *reinterpret_cast<h16x4*>(dst) = norm4(mt, t);
         }
       }
     }
@@ -685,7 +685,7 @@ __device__ __forceinline__ void chain_body(const ChainP& p, bf16_t* const smem, 
   // `fin`: this is the kernel's last GEMM.  Before the stores of its last tile the weight DMA is drained (the ring runs up to
   // NS-1 stages past the end of the stream and must have landed before the LDS is released), so that the kernel can end with
   // its final stores -- the last tile's and the residual rows' -- still in flight instead of waiting for their acknowledgement.
-  auto gemm_store = [&](int ntiles, const float* bias_lds, bf16_t* out, int64_t ldo, bool transposed, bool fin = false) __attribute__((always_inline)) {
+  auto gemm_store = [&](int ntiles, const float* bias_lds, h16_t* out, int64_t ldo, bool transposed, bool fin = false) __attribute__((always_inline)) {
     // V^T through LDS (frame count a multiple of 8): the accumulators hold 4 consecutive frames of one column per lane, i.e. an
     // 8-byte store per lane with 64 different 8-byte segments per instruction -- measured 150 issue cycles per instruction
     // against 45-60 for 16-byte stores (scratch/issue_probe "V^T pattern": +1.6 us per tile).  Each wave therefore transposes ITS
@@ -693,7 +693,7 @@ __device__ __forceinline__ void chain_body(const ChainP& p, bf16_t* const smem, 
     // consecutive frames of one column, 2*MT adjacent pieces per column.  Same bytes, a quarter of the store instructions' cost.
     constexpr int VP = (CW * BM / 8 + 63) / 64;   // 16-byte pieces per lane
     const bool vt_staged = transposed && (p.rows_per_seq & 7) == 0;
-    bf16_t* const stg = panelH + wid * (CW * BM);
+    h16_t* const stg = panelH + wid * (CW * BM);
     int64_t voff[VP];
     int vcol[VP];
     if (vt_staged) {
@@ -705,7 +705,7 @@ __device__ __forceinline__ void chain_body(const ChainP& p, bf16_t* const smem, 
         voff[i] = (q < CW * BM / 8 && m < p.M) ? (int64_t)sq * p.vt_seq_stride + (m - sq * p.rows_per_seq) : -1;
       }
     }
-    [[maybe_unused]] bf16x4 held[MT];   // 8 waves: the even tile of a pair, kept until its neighbour is done
+    [[maybe_unused]] h16x4 held[MT];   // 8 waves: the even tile of a pair, kept until its neighbour is done
     for (int t = 0; t < ntiles; ++t) {
       f32x4 acc[MT][NJ];
       if constexpr (NW == 8) {
@@ -726,25 +726,25 @@ __device__ __forceinline__ void chain_body(const ChainP& p, bf16_t* const smem, 
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) {
               const f32x4 v = acc[mt][0];
-              held[mt] = bf16x4{(bf16_t)v[0], (bf16_t)v[1], (bf16_t)v[2], (bf16_t)v[3]};
+              held[mt] = h16x4{(h16_t)v[0], (h16_t)v[1], (h16_t)v[2], (h16_t)v[3]};
             }
           } else {
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) {
               const f32x4 v = acc[mt][0];
-              const bf16x4 o = {(bf16_t)v[0], (bf16_t)v[1], (bf16_t)v[2], (bf16_t)v[3]};
+              const h16x4 o = {(h16_t)v[0], (h16_t)v[1], (h16_t)v[2], (h16_t)v[3]};
               // [16 rows][32 columns] with the two 32-byte halves of rows 4..7 and 12..15 swapped: rows r, r+4, r+8, r+12 share
               // their LDS banks (64-byte pitch), and un-swizzled the 16 rows of one ds_write_b64 hit the same 4 slots 4 times
               // (scratch/lds_probe: 128 vs 32 cycles per instruction with 8 waves writing)
               const int hsw = (l15 >> 2) & 1;
-              const uint32_t wa = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) bf16_t*)(stg + l15 * 32 + hsw * 16 + g * 4);
-              const uint32_t wb = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) bf16_t*)(stg + l15 * 32 + (hsw ^ 1) * 16 + g * 4);
+              const uint32_t wa = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) h16_t*)(stg + l15 * 32 + hsw * 16 + g * 4);
+              const uint32_t wb = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) h16_t*)(stg + l15 * 32 + (hsw ^ 1) * 16 + g * 4);
               asm volatile("ds_write_b64 %0, %2\n\tds_write_b64 %1, %3" ::"v"(wa), "v"(wb), "v"(held[mt]), "v"(o) : "memory");
-              bf16x8 w;
+              h16x8 w;
               const int prow = lane >> 2, pp = lane & 3;   // this lane stores piece pp (8 columns) of row prow
               asm volatile("s_waitcnt lgkmcnt(0)\n\tds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)"
                            : "=v"(w)
-                           : "v"((uint32_t)(uintptr_t)(__attribute__((address_space(3))) bf16_t*)(stg + prow * 32 + (((pp >> 1) ^ ((prow >> 2) & 1)) * 2 + (pp & 1)) * 8))
+                           : "v"((uint32_t)(uintptr_t)(__attribute__((address_space(3))) h16_t*)(stg + prow * 32 + (((pp >> 1) ^ ((prow >> 2) & 1)) * 2 + (pp & 1)) * 8))
                            : "memory");
               if constexpr (ABL & 1) {
                 asm volatile("" ::"v"(w));
@@ -766,13 +766,13 @@ __device__ __forceinline__ void chain_body(const ChainP& p, bf16_t* const smem, 
             continue;
           }
           if (m0 + mt * 16 + l15 >= p.M) continue;
-          bf16_t* dst = out + (int64_t)row_m[mt] * ldo + col_of(t, 0);
+          h16_t* dst = out + (int64_t)row_m[mt] * ldo + col_of(t, 0);
           const f32x4 v = acc[mt][0];
           if constexpr (NJ == 2) {
             const f32x4 u = acc[mt][1];
-            chain_st_bf8(dst, bf16x8{(bf16_t)v[0], (bf16_t)v[1], (bf16_t)v[2], (bf16_t)v[3], (bf16_t)u[0], (bf16_t)u[1], (bf16_t)u[2], (bf16_t)u[3]});
+            chain_st_bf8(dst, h16x8{(h16_t)v[0], (h16_t)v[1], (h16_t)v[2], (h16_t)v[3], (h16_t)u[0], (h16_t)u[1], (h16_t)u[2], (h16_t)u[3]});
           } else {
-            chain_st_bf4(dst, bf16x4{(bf16_t)v[0], (bf16_t)v[1], (bf16_t)v[2], (bf16_t)v[3]});
+            chain_st_bf4(dst, h16x4{(h16_t)v[0], (h16_t)v[1], (h16_t)v[2], (h16_t)v[3]});
           }
         }
       } else if (vt_staged) {
@@ -782,14 +782,14 @@ __device__ __forceinline__ void chain_body(const ChainP& p, bf16_t* const smem, 
 #pragma unroll
           for (int mt = 0; mt < MT; ++mt) {
             const f32x4 v = acc[mt][j];
-            const bf16x4 o = {(bf16_t)v[0], (bf16_t)v[1], (bf16_t)v[2], (bf16_t)v[3]};
-            asm volatile("ds_write_b64 %0, %1" ::"v"((uint32_t)(uintptr_t)(__attribute__((address_space(3))) bf16_t*)(stg + (j * 16 + l15) * BM + mt * 16 + g * 4)), "v"(o) : "memory");
+            const h16x4 o = {(h16_t)v[0], (h16_t)v[1], (h16_t)v[2], (h16_t)v[3]};
+            asm volatile("ds_write_b64 %0, %1" ::"v"((uint32_t)(uintptr_t)(__attribute__((address_space(3))) h16_t*)(stg + (j * 16 + l15) * BM + mt * 16 + g * 4)), "v"(o) : "memory");
           }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
         for (int i = 0; i < VP; ++i) {
-          bf16x8 v;
-          asm volatile("ds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"((uint32_t)(uintptr_t)(__attribute__((address_space(3))) bf16_t*)(stg + (lane + 64 * i) * 8)) : "memory");
+          h16x8 v;
+          asm volatile("ds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"((uint32_t)(uintptr_t)(__attribute__((address_space(3))) h16_t*)(stg + (lane + 64 * i) * 8)) : "memory");
           if constexpr (ABL & 1) {
             asm volatile("" ::"v"(v));
             continue;
@@ -806,7 +806,7 @@ __device__ __forceinline__ void chain_body(const ChainP& p, bf16_t* const smem, 
               asm volatile("" ::"v"(v));
               continue;
             }
-            const bf16x4 o = {(bf16_t)v[0], (bf16_t)v[1], (bf16_t)v[2], (bf16_t)v[3]};
+            const h16x4 o = {(h16_t)v[0], (h16_t)v[1], (h16_t)v[2], (h16_t)v[3]};
             // rows m .. m+3 (m % 4 == 0) of column n: one 8-byte store when the frame count is a multiple of 4 (the four rows
             // then share a sequence and the address is aligned), else row by row (T = 30 k frames, k odd)
             const int m = m0 + mt * 16 + g * 4;
@@ -889,16 +889,16 @@ __device__ __forceinline__ void chain_body(const ChainP& p, bf16_t* const smem, 
         {
           const int c = W4 * 32 + g * 8 + J0 * 4;  // first column inside the hidden chunk (col_of within the tile)
           auto gelu4 = [&](const f32x4 v) __attribute__((always_inline)) {
-            return bf16x4{(bf16_t)act_gelu_fast(v[0]), (bf16_t)act_gelu_fast(v[1]), (bf16_t)act_gelu_fast(v[2]), (bf16_t)act_gelu_fast(v[3])};
+            return h16x4{(h16_t)act_gelu_fast(v[0]), (h16_t)act_gelu_fast(v[1]), (h16_t)act_gelu_fast(v[2]), (h16_t)act_gelu_fast(v[3])};
           };
 #pragma unroll
           for (int mt = 0; mt < MT; ++mt) {
-            bf16_t* dst = panelH + (mt * 16 + l15) * HLD + ((((c >> 3) ^ l15) << 3) | (c & 7));
+            h16_t* dst = panelH + (mt * 16 + l15) * HLD + ((((c >> 3) ^ l15) << 3) | (c & 7));
             if constexpr (NJ == 2) {
-              const bf16x4 lo = gelu4(acc[mt][0]), hi = gelu4(acc[mt][1]);
-              *reinterpret_cast<bf16x8*>(dst) = bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+              const h16x4 lo = gelu4(acc[mt][0]), hi = gelu4(acc[mt][1]);
+              *reinterpret_cast<h16x8*>(dst) = h16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
             } else {
-              *reinterpret_cast<bf16x4*>(dst) = gelu4(acc[mt][0]);
+              *reinterpret_cast<h16x4*>(dst) = gelu4(acc[mt][0]);
             }
           }
         }
@@ -918,8 +918,8 @@ __device__ __forceinline__ void chain_body(const ChainP& p, bf16_t* const smem, 
           const int n = col_of(ns / NJ, ns % NJ);
 #pragma unroll
           for (int mt = 0; mt < MT; ++mt) {
-            const bf16x4 o = {(bf16_t)xrow[mt][ns][0], (bf16_t)xrow[mt][ns][1], (bf16_t)xrow[mt][ns][2], (bf16_t)xrow[mt][ns][3]};
-            *reinterpret_cast<bf16x4*>(panelA + (mt * 16 + l15) * D + ((((n >> 3) ^ l15) << 3) | (n & 7))) = o;
+            const h16x4 o = {(h16_t)xrow[mt][ns][0], (h16_t)xrow[mt][ns][1], (h16_t)xrow[mt][ns][2], (h16_t)xrow[mt][ns][3]};
+            *reinterpret_cast<h16x4*>(panelA + (mt * 16 + l15) * D + ((((n >> 3) ^ l15) << 3) | (n & 7))) = o;
           }
         }
         chain_bar();
@@ -957,7 +957,7 @@ __device__ __forceinline__ void chain_body(const ChainP& p, bf16_t* const smem, 
 
 template <int D, int MT, int MODE, int ABL = 0, int NW = 4>
 __global__ __launch_bounds__(64 * NW, 1) void chain_kernel(const ChainP p) {
-  __shared__ __attribute__((aligned(16))) bf16_t smem[ChainLds<D, MT>::ELEMS];
+  __shared__ __attribute__((aligned(16))) h16_t smem[ChainLds<D, MT>::ELEMS];
   chain_body<D, MT, MODE, ABL, NW>(p, smem, blockIdx.x * (16 * MT));
 }
 
@@ -968,7 +968,7 @@ __global__ __launch_bounds__(64 * NW, 1) void chain_kernel(const ChainP p) {
 // Every row's result is independent of the panel height (tests/test_hip_round2.py), so the mix is invisible in the output.
 template <int D, int MTA, int MTB, int MODE, int NW>
 __global__ __launch_bounds__(64 * NW, 1) void chain_kernel_mix(const ChainP p) {
-  __shared__ __attribute__((aligned(16))) bf16_t smem[ChainLds<D, MTB>::ELEMS > ChainLds<D, MTA>::ELEMS ? ChainLds<D, MTB>::ELEMS : ChainLds<D, MTA>::ELEMS];
+  __shared__ __attribute__((aligned(16))) h16_t smem[ChainLds<D, MTB>::ELEMS > ChainLds<D, MTA>::ELEMS ? ChainLds<D, MTB>::ELEMS : ChainLds<D, MTA>::ELEMS];
   const int b = blockIdx.x;   // wave-uniform
   if (b < p.n_tall) chain_body<D, MTA, MODE, 0, NW>(p, smem, b * (16 * MTA));
   else chain_body<D, MTB, MODE, 0, NW>(p, smem, p.n_tall * (16 * MTA) + (b - p.n_tall) * (16 * MTB));

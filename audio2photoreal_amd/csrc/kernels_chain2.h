@@ -44,7 +44,7 @@ struct Chain2Lds {
 // Repack of one 16 KiB stage for the direct path: [wave 0..7][k-chunk 0..1][lane 0..63][8 k-values] -- lane (l15, g) of wave w
 // gets W[col(w, l15)][k0 + (kk*4 + g)*8 .. +8], the B operand of v_mfma_f32_16x16x32 for k-chunk kk.  Column ownership as in
 // chain_pack_kernel (8 waves: 32-column group w >> 1, sub-tile w & 1, paired map for stored tiles).
-__global__ __launch_bounds__(256) void chain2_pack_kernel(const ChainPackDesc* __restrict__ descs, bf16_t* __restrict__ dst) {
+__global__ __launch_bounds__(256) void chain2_pack_kernel(const ChainPackDesc* __restrict__ descs, h16_t* __restrict__ dst) {
   const ChainPackDesc d = descs[blockIdx.x];
   uint4* out = reinterpret_cast<uint4*>(dst + (int64_t)blockIdx.x * CHAIN_STAGE_ELEMS);
   for (int q = threadIdx.x; q < 1024; q += 256) {
@@ -58,11 +58,11 @@ __global__ __launch_bounds__(256) void chain2_pack_kernel(const ChainPackDesc* _
 }
 
 template <int D, int MT, int MODE>
-__device__ __forceinline__ void chain2_body(const ChainP& p, bf16_t* const smem, const int m0) {
+__device__ __forceinline__ void chain2_body(const ChainP& p, h16_t* const smem, const int m0) {
   constexpr int NW = 8, CW = 16, BM = 16 * MT, CPR = D / 8, NT = D / 128, KS = D / 64, FT = 8, HLD = 128, AUX_F = 2560, PF = CHAIN2_PF;
   static_assert(KS % PF == 0 && (2 * NT) % PF == 0, "every GEMM must consume a multiple of the register ring");
-  bf16_t* const panelA = smem;
-  bf16_t* const panelH = panelA + BM * D;
+  h16_t* const panelA = smem;
+  h16_t* const panelH = panelA + BM * D;
   float* const red = reinterpret_cast<float*>(panelH + BM * HLD);   // [2][8][BM] LayerNorm partial sums, one per wave
   float* const aux = red + 16 * BM;                                   // [AUX_F] per-tile biases
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, l15 = lane & 15, g = lane >> 4;
@@ -82,12 +82,12 @@ __device__ __forceinline__ void chain2_body(const ChainP& p, bf16_t* const smem,
   // valid before it -- as inline asm the loads worked until the register allocator copied a ring register across a loop
   // back-edge BEFORE the hand-written wait (a copy of a register whose load is still in flight copies garbage).
   uint32_t woff = (uint32_t)(wid * 128 + lane) * 16;   // byte offset of this lane's 16 bytes of k-chunk 0 of the next stage to load
-  bf16x8 wr[PF][2];
+  h16x8 wr[PF][2];
   auto w_issue = [&](int slot) __attribute__((always_inline)) {
     // default cache policy: every workgroup of the launch walks the same stream, L2 serves all but the first
     const char* q = reinterpret_cast<const char*>(p.stream) + woff;   // uniform base + 32-bit offset: SGPR-base addressing
-    wr[slot][0] = *reinterpret_cast<const bf16x8*>(q);
-    wr[slot][1] = *reinterpret_cast<const bf16x8*>(q + 1024);
+    wr[slot][0] = *reinterpret_cast<const h16x8*>(q);
+    wr[slot][1] = *reinterpret_cast<const h16x8*>(q + 1024);
     woff += 16384;            // the host pads CHAIN_STREAM_PAD stages behind the last one
   };
   auto w_wait = [&](int) __attribute__((always_inline)) {};
@@ -140,15 +140,15 @@ __device__ __forceinline__ void chain2_body(const ChainP& p, bf16_t* const smem,
   // the last chunk runs past the tile's K range into the next panel row: valid LDS, never used).
   // `fill_c`: the caller has independent vector arithmetic (the GELU of the previous hidden chunk) in the same scheduling region;
   // two of its instructions are slotted behind every MFMA (an MFMA holds the matrix pipe for 16 cycles and its issue slot for 4).
-  auto gemm_tile = [&](f32x4(&acc)[MT], const bf16_t* P, int pld, auto nks_c, bool swap, auto fill_c) __attribute__((always_inline)) {
+  auto gemm_tile = [&](f32x4(&acc)[MT], const h16_t* P, int pld, auto nks_c, bool swap, auto fill_c) __attribute__((always_inline)) {
     constexpr int NKS = decltype(nks_c)::value;
     constexpr int FILL = decltype(fill_c)::value;
     static_assert(NKS % PF == 0 && PF == 4, "ring phase");
     const char* rp = reinterpret_cast<const char*>(P) + l15 * pld * 2;
     const int rstep = 32 * pld;   // bytes between the 16-row blocks of a panel
-    bf16x8 a[2][MT];
+    h16x8 a[2][MT];
 #pragma unroll
-    for (int mt = 0; mt < MT; ++mt) a[0][mt] = *reinterpret_cast<const bf16x8*>(rp + aswz[0] + mt * rstep);
+    for (int mt = 0; mt < MT; ++mt) a[0][mt] = *reinterpret_cast<const h16x8*>(rp + aswz[0] + mt * rstep);
 #pragma unroll
     for (int it = 0; it < NKS / PF; ++it) {
 #pragma unroll
@@ -157,7 +157,7 @@ __device__ __forceinline__ void chain2_body(const ChainP& p, bf16_t* const smem,
         if (kk == 0) w_wait(slot);
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt)
-          a[(u + 1) & 1][mt] = *reinterpret_cast<const bf16x8*>(rp + aswz[(u + 1) & 3] + ((u + 1) >> 2) * 256 + mt * rstep);
+          a[(u + 1) & 1][mt] = *reinterpret_cast<const h16x8*>(rp + aswz[(u + 1) & 3] + ((u + 1) >> 2) * 256 + mt * rstep);
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
           if (swap) acc[mt] = A2P_MFMA16(a[u & 1][mt], wr[slot][kk], acc[mt]);
@@ -180,17 +180,17 @@ __device__ __forceinline__ void chain2_body(const ChainP& p, bf16_t* const smem,
   // acc[t] += P[:, 0 : 64*NKS] x stages^T for all NT tiles, k-major (stage = ks*NT + t): the A fragments of a k-step are read
   // once for the NT tiles, one k-step ahead, spread over the stages of the current k-step.  Same per-tile k-order as the
   // tile-major form: same bits.  Body = two k-steps (2*NT stages, a multiple of PF).
-  auto gemm_group = [&](f32x4(&acc)[NT][MT], const bf16_t* P, int pld, auto nks_c) __attribute__((always_inline)) {
+  auto gemm_group = [&](f32x4(&acc)[NT][MT], const h16_t* P, int pld, auto nks_c) __attribute__((always_inline)) {
     constexpr int NKS = decltype(nks_c)::value;
     static_assert(NKS % 2 == 0 && (2 * NT) % PF == 0, "ring phase");
     constexpr int RPS = (2 * MT + NT - 1) / NT;   // fragment reads per stage
     const char* rp = reinterpret_cast<const char*>(P) + l15 * pld * 2;
     const int rstep = 32 * pld;
-    bf16x8 a[2][2][MT];
+    h16x8 a[2][2][MT];
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk)
 #pragma unroll
-      for (int mt = 0; mt < MT; ++mt) a[0][kk][mt] = *reinterpret_cast<const bf16x8*>(rp + aswz[kk] + mt * rstep);
+      for (int mt = 0; mt < MT; ++mt) a[0][kk][mt] = *reinterpret_cast<const h16x8*>(rp + aswz[kk] + mt * rstep);
 #pragma unroll
     for (int it = 0; it < NKS / 2; ++it) {
 #pragma unroll
@@ -203,7 +203,7 @@ __device__ __forceinline__ void chain2_body(const ChainP& p, bf16_t* const smem,
 #pragma unroll
           for (int r = t * RPS; r < (t + 1) * RPS && r < 2 * MT; ++r) {
             const int cn = 2 * (j + 1) + r / MT;   // k-chunk of the next k-step, relative to this body's first chunk
-            a[j ^ 1][r / MT][r % MT] = *reinterpret_cast<const bf16x8*>(rp + aswz[cn & 3] + (cn >> 2) * 256 + (r % MT) * rstep);
+            a[j ^ 1][r / MT][r % MT] = *reinterpret_cast<const h16x8*>(rp + aswz[cn & 3] + (cn >> 2) * 256 + (r % MT) * rstep);
             ++nread;
           }
 #pragma unroll
@@ -386,7 +386,7 @@ __device__ __forceinline__ void chain2_body(const ChainP& p, bf16_t* const smem,
           const float r2 = fmaf(v2, c[2], -(v3 * c[3])), r3 = fmaf(v3, c[2], v2 * c[3]);
           v0 = r0; v1 = r1; v2 = r2; v3 = r3;
         }
-        *reinterpret_cast<bf16x4*>(panelA + (mt * 16 + l15) * D + t * 128 + pswz) = bf16x4{(bf16_t)v0, (bf16_t)v1, (bf16_t)v2, (bf16_t)v3};
+        *reinterpret_cast<h16x4*>(panelA + (mt * 16 + l15) * D + t * 128 + pswz) = h16x4{(h16_t)v0, (h16_t)v1, (h16_t)v2, (h16_t)v3};
       }
     }
     chain_bar();   // the panel is complete before any wave's fragment reads
@@ -416,12 +416,12 @@ __device__ __forceinline__ void chain2_body(const ChainP& p, bf16_t* const smem,
   // tiles leave in pairs as 16 rows x 64 contiguous bytes per instruction, V^T tiles as 16-byte pieces of 8 consecutive frames
   // The tile loop is unrolled (compile-time tile count): across a loop back-edge hipcc waits for ALL outstanding ring loads
   // (s_waitcnt vmcnt(0) at every loop header), i.e. one exposed L2 round trip per tile.
-  auto gemm_store = [&](auto ntiles_c, const float* bias_lds, bf16_t* out, int64_t ldo, bool transposed) __attribute__((always_inline)) {
+  auto gemm_store = [&](auto ntiles_c, const float* bias_lds, h16_t* out, int64_t ldo, bool transposed) __attribute__((always_inline)) {
     constexpr int ntiles = decltype(ntiles_c)::value;
     // V^T tiles are transposed through a wave-private slice of the idle hidden-chunk buffer and leave as 16-byte pieces (8
     // consecutive frames of one column).  Frame counts that are not a multiple of 8 take the generation-1 kernels (host).
     constexpr int VP = (CW * BM / 8 + 63) / 64;
-    bf16_t* const stg = panelH + wid * (CW * BM);
+    h16_t* const stg = panelH + wid * (CW * BM);
     uint32_t voff[VP];
     bool vok[VP];
     if (transposed) {
@@ -433,7 +433,7 @@ __device__ __forceinline__ void chain2_body(const ChainP& p, bf16_t* const smem,
         voff[i] = (uint32_t)sq * (uint32_t)p.vt_seq_stride + (uint32_t)(m - sq * p.rows_per_seq) + (uint32_t)c * (uint32_t)ldo;
       }
     }
-    bf16x4 held[MT];
+    h16x4 held[MT];
 #pragma unroll
     for (int t = 0; t < ntiles; ++t) {
       f32x4 acc[MT];
@@ -447,18 +447,18 @@ __device__ __forceinline__ void chain2_body(const ChainP& p, bf16_t* const smem,
 #pragma unroll
           for (int mt = 0; mt < MT; ++mt) {
             const f32x4 v = acc[mt];
-            held[mt] = bf16x4{(bf16_t)v[0], (bf16_t)v[1], (bf16_t)v[2], (bf16_t)v[3]};
+            held[mt] = h16x4{(h16_t)v[0], (h16_t)v[1], (h16_t)v[2], (h16_t)v[3]};
           }
         } else {
 #pragma unroll
           for (int mt = 0; mt < MT; ++mt) {
             const f32x4 v = acc[mt];
-            const bf16x4 o = {(bf16_t)v[0], (bf16_t)v[1], (bf16_t)v[2], (bf16_t)v[3]};
+            const h16x4 o = {(h16_t)v[0], (h16_t)v[1], (h16_t)v[2], (h16_t)v[3]};
             const int hsw = (l15 >> 2) & 1;   // half-row swizzle of the [16][32] staging tile (scratch/lds_probe: no 4-way conflict)
             asm volatile("ds_write_b64 %0, %2\n\tds_write_b64 %1, %3" ::"v"(lds_off(stg + l15 * 32 + hsw * 16 + g * 4)),
                          "v"(lds_off(stg + l15 * 32 + (hsw ^ 1) * 16 + g * 4)), "v"(held[mt]), "v"(o)
                          : "memory");
-            bf16x8 w;
+            h16x8 w;
             const int prow = lane >> 2, pp = lane & 3;
             asm volatile("s_waitcnt lgkmcnt(0)\n\tds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)"
                          : "=v"(w)
@@ -466,22 +466,22 @@ __device__ __forceinline__ void chain2_body(const ChainP& p, bf16_t* const smem,
                          : "memory");
             const int m = m0 + mt * 16 + (lane >> 2);
             if (m < p.M)
-              *reinterpret_cast<bf16x8*>(reinterpret_cast<char*>(out) + (((uint32_t)m * (uint32_t)ldo + (uint32_t)(obase(t - 1) + (lane & 3) * 8)) << 1)) = w;
+              *reinterpret_cast<h16x8*>(reinterpret_cast<char*>(out) + (((uint32_t)m * (uint32_t)ldo + (uint32_t)(obase(t - 1) + (lane & 3) * 8)) << 1)) = w;
           }
         }
       } else {
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
           const f32x4 v = acc[mt];
-          const bf16x4 o = {(bf16_t)v[0], (bf16_t)v[1], (bf16_t)v[2], (bf16_t)v[3]};
+          const h16x4 o = {(h16_t)v[0], (h16_t)v[1], (h16_t)v[2], (h16_t)v[3]};
           asm volatile("ds_write_b64 %0, %1" ::"v"(lds_off(stg + l15 * BM + mt * 16 + g * 4)), "v"(o) : "memory");
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
         for (int i = 0; i < VP; ++i) {
-          bf16x8 v;
+          h16x8 v;
           asm volatile("ds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(lds_off(stg + (lane + 64 * i) * 8)) : "memory");
-          if (vok[i]) *reinterpret_cast<bf16x8*>(reinterpret_cast<char*>(out) + ((voff[i] + (uint32_t)obase(t) * (uint32_t)ldo) << 1)) = v;
+          if (vok[i]) *reinterpret_cast<h16x8*>(reinterpret_cast<char*>(out) + ((voff[i] + (uint32_t)obase(t) * (uint32_t)ldo) << 1)) = v;
         }
       }
     }
@@ -570,8 +570,8 @@ __device__ __forceinline__ void chain2_body(const ChainP& p, bf16_t* const smem,
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
           const f32x4 v = acc[mt];
-          *reinterpret_cast<bf16x4*>(panelH + (mt * 16 + l15) * HLD + pswz) =
-              bf16x4{(bf16_t)act_gelu_fast(v[0]), (bf16_t)act_gelu_fast(v[1]), (bf16_t)act_gelu_fast(v[2]), (bf16_t)act_gelu_fast(v[3])};
+          *reinterpret_cast<h16x4*>(panelH + (mt * 16 + l15) * HLD + pswz) =
+              h16x4{(h16_t)act_gelu_fast(v[0]), (h16_t)act_gelu_fast(v[1]), (h16_t)act_gelu_fast(v[2]), (h16_t)act_gelu_fast(v[3])};
         }
         chain_bar();              // the hidden chunk is complete
         C2_FENCE();
@@ -607,7 +607,7 @@ __device__ __forceinline__ void chain2_stream_leader(const ChainP& p) {
 
 template <int D, int MT, int MODE>
 __global__ __launch_bounds__(512, 1) void chain2_kernel(const ChainP p) {
-  __shared__ __attribute__((aligned(16))) bf16_t smem[Chain2Lds<D, MT>::ELEMS];
+  __shared__ __attribute__((aligned(16))) h16_t smem[Chain2Lds<D, MT>::ELEMS];
   if ((int)blockIdx.x < p.n_pf) {   // workgroup-uniform
     chain2_stream_leader(p);
     return;

@@ -37,6 +37,10 @@ struct GemmP {
   int out_seq_pad;       // EPI_STORE / EPI_CONV: output row = m + (m / rows_per_seq) * out_seq_pad
   const void* skip;      // EPI_CONV: (skip[m*ld_skip + n] + y) / 2 when non-null (dtype T)
   int64_t ld_skip;
+  // split-operand rows (kernels_misc.h split3_kernel): split_third > 0 -> the 16-bit output row is [hi | lo | hi] with the pieces
+  // split_third elements apart (the A' operand of the next split GEMM); skip_lo > 0 -> the skip operand is such a row too and its
+  // value is skip[n] + skip[skip_lo + n]
+  int split_third, skip_lo;
 };
 
 template <int ACT, bool FAST>
@@ -93,7 +97,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmP& p, f32x4 (&acc)[MT][4
           if (p.skip) {
             const T* sp = reinterpret_cast<const T*>(p.skip) + (int64_t)m * p.ld_skip + n;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) v[r] = (to_f32(sp[r]) + v[r]) * 0.5f;
+            for (int r = 0; r < 4; ++r) v[r] = ((p.skip_lo ? to_f32(sp[r]) + to_f32(sp[p.skip_lo + r]) : to_f32(sp[r])) + v[r]) * 0.5f;
           }
         }
         if constexpr (EPI == EPI_STORE_T) {
@@ -105,8 +109,15 @@ __device__ __forceinline__ void gemm_epilogue(const GemmP& p, f32x4 (&acc)[MT][4
         } else {
           T* op = reinterpret_cast<T*>(p.out) + orow * p.ldo + n;
           if constexpr (sizeof(T) == 2) {
-            bf16x4 o = {(bf16_t)v[0], (bf16_t)v[1], (bf16_t)v[2], (bf16_t)v[3]};
-            *reinterpret_cast<bf16x4*>(op) = o;
+            h16x4 o = {(h16_t)v[0], (h16_t)v[1], (h16_t)v[2], (h16_t)v[3]};
+            *reinterpret_cast<h16x4*>(op) = o;
+            if (p.split_third) {
+              h16x4 lo;
+#pragma unroll
+              for (int r = 0; r < 4; ++r) lo[r] = (h16_t)(v[r] - (float)o[r]);
+              *reinterpret_cast<h16x4*>(op + p.split_third) = lo;
+              *reinterpret_cast<h16x4*>(op + 2 * p.split_third) = o;
+            }
           } else {
             *reinterpret_cast<float4*>(op) = make_float4(v[0], v[1], v[2], v[3]);
           }
@@ -185,7 +196,7 @@ __device__ __forceinline__ void gemm_mainloop_f32(const GemmP& p, f32x4 (&acc)[M
 // ---- bf16 main loop: global_load_lds (16 B / lane), 2 LDS buffers, swizzled unpadded rows -----------
 // LDS tile = [rows][64 bf16] (128-byte rows = 8 chunks of 16 B).  Chunk c of row r lives at chunk
 // position c ^ ((r >> 1) & 7): conflict-free for the 16-lane groups of ds_read_b128.
-__device__ __forceinline__ void glds16(const bf16_t* gsrc, bf16_t* lds_wave_base) {
+__device__ __forceinline__ void glds16(const h16_t* gsrc, h16_t* lds_wave_base) {
   __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
                                    (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
 }
@@ -195,17 +206,17 @@ __device__ __forceinline__ void glds16(const bf16_t* gsrc, bf16_t* lds_wave_base
 // workgroup per CU -- the 480-row forwards of BASELINE configs[0] -- whose time is K/64 serial HBM/L2 round trips otherwise.
 template <int MT, int NB = 2>
 __device__ __forceinline__ void gemm_mainloop_bf16(const GemmP& p, f32x4 (&acc)[MT][4], int m0, int n0) {
-  using P = Prec<bf16_t>;
+  using P = Prec<h16_t>;
   constexpr int BM = 32 * MT, BN = 128, BK = 64;
   constexpr int AI = BM / 32;  // glds instructions per wave for the A tile (8 rows each, 4 waves)
   constexpr int PCS = AI + 4;  // DMA instructions per wave per k-tile
-  __shared__ __attribute__((aligned(16))) bf16_t smem[NB * (BM + BN) * BK];
-  bf16_t* const As0 = smem;
-  bf16_t* const Ws0 = smem + NB * BM * BK;
+  __shared__ __attribute__((aligned(16))) h16_t smem[NB * (BM + BN) * BK];
+  h16_t* const As0 = smem;
+  h16_t* const Ws0 = smem + NB * BM * BK;
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, l15 = lane & 15, g = lane >> 4;
   const int wm = wid >> 1, wn = wid & 1;
-  const bf16_t* __restrict__ A = reinterpret_cast<const bf16_t*>(p.A);
-  const bf16_t* __restrict__ W = reinterpret_cast<const bf16_t*>(p.W);
+  const h16_t* __restrict__ A = reinterpret_cast<const h16_t*>(p.A);
+  const h16_t* __restrict__ W = reinterpret_cast<const h16_t*>(p.W);
   const int ktiles = p.K / BK;
   const int total = ktiles * p.ntaps;
 
@@ -229,10 +240,10 @@ __device__ __forceinline__ void gemm_mainloop_bf16(const GemmP& p, f32x4 (&acc)[
   auto stage = [&](int it, int buf) {
     const int tap = it / ktiles;  // ntaps == 1 almost always: the division is off the critical path (loads in flight)
     const int k0 = (it - tap * ktiles) * BK;
-    const bf16_t* At = A + tap * p.a_tap_stride + k0;
-    const bf16_t* Wt = W + tap * p.w_tap_stride + k0;
-    bf16_t* Ab = As0 + buf * BM * BK;
-    bf16_t* Wb = Ws0 + buf * BN * BK;
+    const h16_t* At = A + tap * p.a_tap_stride + k0;
+    const h16_t* Wt = W + tap * p.w_tap_stride + k0;
+    h16_t* Ab = As0 + buf * BM * BK;
+    h16_t* Wb = Ws0 + buf * BN * BK;
 #pragma unroll
     for (int i = 0; i < AI; ++i) glds16(At + a_off[i], Ab + (i * 4 + wid) * 8 * BK);
 #pragma unroll
@@ -263,17 +274,17 @@ __device__ __forceinline__ void gemm_mainloop_bf16(const GemmP& p, f32x4 (&acc)[
       static_assert(NB == 2 || NB == 4, "ring depths 2 and 4");
     }
     if (it + NB - 1 < total) stage(it + NB - 1, nbuf);
-    const bf16_t* Ab = As0 + buf * BM * BK;
-    const bf16_t* Wb = Ws0 + buf * BN * BK;
+    const h16_t* Ab = As0 + buf * BM * BK;
+    const h16_t* Wb = Ws0 + buf * BN * BK;
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk) {
-      bf16x8 af[MT], wf[4];
+      h16x8 af[MT], wf[4];
 #pragma unroll
       for (int i = 0; i < MT; ++i)
-        af[i] = *reinterpret_cast<const bf16x8*>(Ab + a_row[i] * BK + (((kk * 4 + g) ^ ((a_row[i] >> 1) & 7)) << 3));
+        af[i] = *reinterpret_cast<const h16x8*>(Ab + a_row[i] * BK + (((kk * 4 + g) ^ ((a_row[i] >> 1) & 7)) << 3));
 #pragma unroll
       for (int j = 0; j < 4; ++j)
-        wf[j] = *reinterpret_cast<const bf16x8*>(Wb + w_row[j] * BK + (((kk * 4 + g) ^ ((w_row[j] >> 1) & 7)) << 3));
+        wf[j] = *reinterpret_cast<const h16x8*>(Wb + w_row[j] * BK + (((kk * 4 + g) ^ ((w_row[j] >> 1) & 7)) << 3));
 #pragma unroll
       for (int i = 0; i < MT; ++i)
 #pragma unroll

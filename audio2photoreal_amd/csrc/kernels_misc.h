@@ -125,6 +125,49 @@ __global__ void pack_input_kernel(const float* __restrict__ x, T* __restrict__ d
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Split operands ("x3"): an fp32 value v as the 16-bit pair hi = T(v), lo = T(v - hi) carries 2 x (mantissa bits of T) bits, and
+//     a . w  =  a_hi w_hi + a_lo w_hi + a_hi w_lo  (+ a_lo w_lo, 2^-22 relative: dropped)
+// is ONE 16-bit GEMM over a 3x longer contraction: A' = [a_hi | a_lo | a_hi], W' = [w_hi | w_hi | w_lo].  The 16-bit modes run
+// input_projection, final_layer and the pose conv tail this way: those operand classes carry the error of the sampling loop's
+// return value (profiles/r03_error_budget*.json), exact fp32 MFMA (1/16 of the 16-bit rate) cost the body model 14 %.
+// ---------------------------------------------------------------------------------------------
+// fp32 [rows][cols] (row stride lds, column stride src_col_stride) -> T [rows][3 * cpad]; weights: [hi | hi | lo]
+__global__ void split3_kernel(const float* __restrict__ src, int64_t lds, int src_col_stride, h16_t* __restrict__ dst, int64_t rows,
+                              int cols, int cpad, int weight) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= rows * cpad) return;
+  const int64_t r = i / cpad;
+  const int c = (int)(i - r * cpad);
+  const float v = c < cols ? src[r * lds + (int64_t)c * src_col_stride] : 0.f;
+  const h16_t hi = (h16_t)v, lo = (h16_t)(v - (float)hi);
+  h16_t* d = dst + r * 3 * cpad + c;
+  d[0] = hi;
+  d[cpad] = weight ? hi : lo;
+  d[2 * cpad] = weight ? lo : hi;
+}
+
+// x [B, C, T] fp32 -> A' [B*T, 3 * Cpad] split operand rows (the permute of model/diffusion.py:345-346 fused with the split)
+__global__ void pack_input_split3_kernel(const float* __restrict__ x, h16_t* __restrict__ dst, int B, int C, int Tn, int Cpad) {
+  __shared__ float tile[32][33];
+  const int b = blockIdx.z, t0 = blockIdx.x * 32, c0 = blockIdx.y * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  for (int i = ty; i < 32; i += 8) {
+    const int c = c0 + i, t = t0 + tx;
+    tile[i][tx] = (c < C && t < Tn) ? x[((int64_t)b * C + c) * Tn + t] : 0.f;
+  }
+  __syncthreads();
+  for (int i = ty; i < 32; i += 8) {
+    const int t = t0 + i, c = c0 + tx;
+    if (t < Tn && c < Cpad) {
+      const float v = tile[tx][i];
+      const h16_t hi = (h16_t)v, lo = (h16_t)(v - (float)hi);
+      h16_t* d = dst + ((int64_t)b * Tn + t) * 3 * Cpad + c;
+      d[0] = hi; d[Cpad] = lo; d[2 * Cpad] = hi;
+    }
+  }
+}
+
 // mean over the token axis: src fp32 [B, S, d] -> dst [B, d]   (model/diffusion.py:380)
 __global__ void mean_tokens_kernel(const float* __restrict__ src, float* __restrict__ dst, int S, int d) {
   const int b = blockIdx.y, c = blockIdx.x * blockDim.x + threadIdx.x;

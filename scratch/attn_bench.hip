@@ -16,7 +16,7 @@ float time_it(F f, int iters = 20) {
 template <int ABL> void run(const char* name, AttnP p, int nseq, double gf) {
   p.nq = (p.Tq + 127) / 128; p.nheads = 8; p.nseq = nseq; p.xcd_remap = 1;
   dim3 grid(p.nq * 8 * nseq);
-  float us = time_it([&] { attn_kernel<bf16_t, 64, ABL><<<grid, 256>>>(p); });
+  float us = time_it([&] { attn_kernel<h16_t, 64, ABL><<<grid, 256>>>(p); });
   CK(hipDeviceSynchronize());
   printf("  abl=%2d %-34s %8.1f us  %7.1f TF\n", ABL, name, us, gf / us * 1e-3);
 }
@@ -25,7 +25,7 @@ int main() {
   for (int nseq : {16, 64}) for (int S : {600, 2000}) {
     if (nseq == 64 && S == 600) continue;
     const int Sld = (S + 63) / 64 * 64;
-    bf16_t *q, *k, *vt, *o;
+    h16_t *q, *k, *vt, *o;
     CK(hipMalloc(&q, (size_t)nseq * T * d * 2)); CK(hipMalloc(&k, ((size_t)nseq * Sld + 64) * d * 2));
     CK(hipMalloc(&vt, (size_t)nseq * d * Sld * 2)); CK(hipMalloc(&o, (size_t)nseq * T * d * 2));
     std::vector<uint16_t> h((size_t)nseq * Sld * d + 64 * d);

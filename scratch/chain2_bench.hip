@@ -20,7 +20,7 @@ __global__ void thrash_kernel(const uint4* __restrict__ p, size_t n_per_block, u
 template <int GEN, int MT, int MODE>
 void run(ChainP p, int stages, unsigned long long* st) {
   const int grid = (p.M + 16 * MT - 1) / (16 * MT);
-  const bf16_t* base = p.stream;
+  const h16_t* base = p.stream;
   hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
   double tot = 0; const int iters = 6;
   for (int it = 0; it < iters + 2; ++it) {
@@ -53,7 +53,7 @@ void run(ChainP p, int stages, unsigned long long* st) {
 }
 int main(int argc, char** argv) {
   const int D = 512, Mmax = 38400;
-  float *x, *aux, *vec, *film; bf16_t *ain, *stream, *qk, *vt; float2* cs;
+  float *x, *aux, *vec, *film; h16_t *ain, *stream, *qk, *vt; float2* cs;
   CK(hipMalloc(&x, (size_t)Mmax * D * 4)); CK(hipMalloc(&ain, (size_t)Mmax * D * 2)); CK(hipMalloc(&stream, (size_t)(8 * (256 + 8) + 64) * 16384));
   CK(hipMalloc(&aux, 16384)); CK(hipMalloc(&vec, 8192 * 4)); CK(hipMalloc(&film, (size_t)64 * 4 * D * 4));
   CK(hipMalloc(&qk, (size_t)Mmax * 2 * D * 2)); CK(hipMalloc(&vt, (size_t)Mmax * D * 2 + (1 << 20))); CK(hipMalloc(&cs, (size_t)640 * 256 * 8));

@@ -33,7 +33,7 @@ static int g_cycle = 1;  // number of distinct weight streams cycled through (1 
 template <int MT, int MODE, int ABL, int NW = 4>
 void run(const char* name, ChainP p, int stages) {
   const int grid = (p.M + 16 * MT - 1) / (16 * MT);
-  const bf16_t* base = p.stream;
+  const h16_t* base = p.stream;
   hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
   double tot = 0; const int iters = 8;
   for (int it = 0; it < iters + 2; ++it) {
@@ -74,7 +74,7 @@ void all(ChainP p) {
 int main(int argc, char** argv) {
   for (int M : {9600}) {
     const int D = 512;
-    float *x, *aux, *vec, *film; bf16_t *ain, *stream, *qk, *vt; float2* cs;
+    float *x, *aux, *vec, *film; h16_t *ain, *stream, *qk, *vt; float2* cs;
     CK(hipMalloc(&x, (size_t)M * D * 4)); CK(hipMalloc(&ain, (size_t)M * D * 2)); CK(hipMalloc(&stream, (size_t)(16 * (256 + 8) + 64) * 16384));
     CK(hipMalloc(&aux, 16384)); CK(hipMalloc(&vec, 8192 * 4)); CK(hipMalloc(&film, (size_t)64 * 4 * D * 4));
     CK(hipMalloc(&qk, (size_t)M * 2 * D * 2)); CK(hipMalloc(&vt, (size_t)M * D * 2 + (1 << 20))); CK(hipMalloc(&cs, (size_t)640 * 256 * 8));

@@ -11,7 +11,7 @@
 static uint16_t f2bf(float f) { uint32_t u; memcpy(&u, &f, 4); u += 0x7fff + ((u >> 16) & 1); return (uint16_t)(u >> 16); }
 constexpr int D = 256;
 template <int MT, int MODE, int ABL, int NW>
-std::vector<float> run(ChainP p, const float* x0, size_t xbytes, const bf16_t* s4, const bf16_t* s8) {
+std::vector<float> run(ChainP p, const float* x0, size_t xbytes, const h16_t* s4, const h16_t* s8) {
   CK(hipMemcpy(p.x, x0, xbytes, hipMemcpyDeviceToDevice));
   p.stream = NW == 8 ? s8 : s4;
   const int grid = (p.M + 16 * MT - 1) / (16 * MT);
@@ -41,7 +41,7 @@ int main() {
   std::vector<uint16_t> hain((size_t)M * D), hw((size_t)nst * 128 * 64);
   for (auto& v : hain) v = f2bf(nd(rng));
   for (auto& v : hw) v = f2bf(0.06f * nd(rng));
-  float *x, *x0, *aux, *vec, *film; bf16_t *ain, *w, *s4, *s8, *qk, *vt; float2* cs; ChainPackDesc* dd;
+  float *x, *x0, *aux, *vec, *film; h16_t *ain, *w, *s4, *s8, *qk, *vt; float2* cs; ChainPackDesc* dd;
   CK(hipMalloc(&x, hx.size() * 4)); CK(hipMalloc(&x0, hx.size() * 4)); CK(hipMalloc(&aux, haux.size() * 4)); CK(hipMalloc(&vec, hv.size() * 4));
   CK(hipMalloc(&film, hf.size() * 4)); CK(hipMalloc(&ain, hain.size() * 2)); CK(hipMalloc(&w, hw.size() * 2));
   CK(hipMalloc(&s4, (size_t)(nst + 8) * 16384)); CK(hipMalloc(&s8, (size_t)(nst + 8) * 16384));

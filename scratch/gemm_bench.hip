@@ -23,7 +23,7 @@ __device__ __forceinline__ void lds_store16(T* dst, uint4 v) { *reinterpret_cast
 // VARIANT bits: 1 = no epilogue stores, 2 = no global loads in loop, 4 = no MFMA, 8 = no LDS traffic in loop
 template <int VARIANT>
 __global__ __launch_bounds__(256) void gemm_abl(GemmP p) {
-  using T = bf16_t;
+  using T = h16_t;
   using P = Prec<T>;
   using G = GemmTile<T>;
   constexpr int BM = G::BM, BN = G::BN, BK = G::BK, LS = G::LS, VEC = G::VEC;
@@ -93,8 +93,8 @@ __global__ __launch_bounds__(256) void gemm_abl(GemmP p) {
       if (n >= p.N) continue;
       f32x4 v = acc[i][j];
       T* op = reinterpret_cast<T*>(p.out) + (int64_t)m * p.ldo + n;
-      bf16x4 o = {(bf16_t)v[0], (bf16_t)v[1], (bf16_t)v[2], (bf16_t)v[3]};
-      *reinterpret_cast<bf16x4*>(op) = o;
+      h16x4 o = {(h16_t)v[0], (h16_t)v[1], (h16_t)v[2], (h16_t)v[3]};
+      *reinterpret_cast<h16x4*>(op) = o;
     }
   }
 }
@@ -116,7 +116,7 @@ int main() {
   const int shapes[][3] = {{9600, 512, 512}, {9600, 1024, 512}, {9600, 512, 1024}, {38400, 512, 512}, {38400, 1024, 512}};
   for (auto& sh : shapes) {
     const int M = sh[0], N = sh[1], K = sh[2];
-    bf16_t *A, *W, *O; float *X, *bias, *film;
+    h16_t *A, *W, *O; float *X, *bias, *film;
     CK(hipMalloc(&A, (size_t)M * K * 2)); CK(hipMalloc(&W, (size_t)N * K * 2)); CK(hipMalloc(&O, (size_t)M * N * 2 * 2));
     CK(hipMalloc(&X, (size_t)M * N * 4)); CK(hipMalloc(&bias, N * 4)); CK(hipMalloc(&film, (size_t)64 * 2 * N * 4));
     std::vector<uint16_t> h((size_t)M * K);
@@ -134,15 +134,15 @@ int main() {
     printf("M=%d N=%d K=%d (%.1f GF, %d blocks)\n", M, N, K, gf, grid.x * grid.y);
     dim3 g4((N + 127) / 128, (M + 127) / 128), g2((N + 127) / 128, (M + 63) / 64);
     p.epi = EPI_STORE;
-    rep("v2 MT4 STORE", time_it([&] { gemm_kernel<bf16_t, 4, EPI_STORE, ACT_NONE, false><<<g4, 256>>>(p); }));
-    rep("v2 MT2 STORE", time_it([&] { gemm_kernel<bf16_t, 2, EPI_STORE, ACT_NONE, false><<<g2, 256>>>(p); }));
-    rep("v2 MT4 STORE+GELU", time_it([&] { gemm_kernel<bf16_t, 4, EPI_STORE, ACT_GELU, false><<<g4, 256>>>(p); }));
-    rep("v2 MT2 STORE+GELU", time_it([&] { gemm_kernel<bf16_t, 2, EPI_STORE, ACT_GELU, false><<<g2, 256>>>(p); }));
+    rep("v2 MT4 STORE", time_it([&] { gemm_kernel<h16_t, 4, EPI_STORE, ACT_NONE, false><<<g4, 256>>>(p); }));
+    rep("v2 MT2 STORE", time_it([&] { gemm_kernel<h16_t, 2, EPI_STORE, ACT_NONE, false><<<g2, 256>>>(p); }));
+    rep("v2 MT4 STORE+GELU", time_it([&] { gemm_kernel<h16_t, 4, EPI_STORE, ACT_GELU, false><<<g4, 256>>>(p); }));
+    rep("v2 MT2 STORE+GELU", time_it([&] { gemm_kernel<h16_t, 2, EPI_STORE, ACT_GELU, false><<<g2, 256>>>(p); }));
     p.resid = X; p.ldx = N; p.film = film; p.film_seq_stride = 2 * N; p.film_shift_off = N; p.epi = EPI_FILM_RES;
-    rep("v2 MT4 FILM_RES", time_it([&] { gemm_kernel<bf16_t, 4, EPI_FILM_RES, ACT_NONE, false><<<g4, 256>>>(p); }));
-    rep("v2 MT2 FILM_RES", time_it([&] { gemm_kernel<bf16_t, 2, EPI_FILM_RES, ACT_NONE, false><<<g2, 256>>>(p); }));
+    rep("v2 MT4 FILM_RES", time_it([&] { gemm_kernel<h16_t, 4, EPI_FILM_RES, ACT_NONE, false><<<g4, 256>>>(p); }));
+    rep("v2 MT2 FILM_RES", time_it([&] { gemm_kernel<h16_t, 2, EPI_FILM_RES, ACT_NONE, false><<<g2, 256>>>(p); }));
     p.epi = EPI_STORE_T; p.t_seq_stride = (int64_t)N * 640; p.ldo = 640;
-    rep("v2 MT2 STORE_T", time_it([&] { gemm_kernel<bf16_t, 2, EPI_STORE_T, ACT_NONE, false><<<g2, 256>>>(p); }));
+    rep("v2 MT2 STORE_T", time_it([&] { gemm_kernel<h16_t, 2, EPI_STORE_T, ACT_NONE, false><<<g2, 256>>>(p); }));
     p.epi = EPI_STORE; p.ldo = N;
     rep("abl full", time_it([&] { gemm_abl<0><<<grid, 256>>>(p); }));
     rep("abl no-epilogue", time_it([&] { gemm_abl<1><<<grid, 256>>>(p); }));
