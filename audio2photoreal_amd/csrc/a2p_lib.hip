@@ -127,8 +127,35 @@ struct ArenaScope {  // RAII: route buf_alloc to a context's arena for the durat
 };
 static inline int rup(int v, int m) { return (v + m - 1) / m * m; }
 
+// Run-time switches of the forward (A/B runs, tests, diagnostics), read from the environment ONCE per context -- and again when
+// the host asks (a2p_reload_env; the Python mirror calls it when an A2P_* variable changed) -- instead of ~10 getenv calls per forward.
+struct A2POpts {
+  int kv_cached = 0;        // A2P_KV_CACHED=1: default cache policy for the cached audio K/V (A/B)
+  int no_chain = 0;         // A2P_NO_CHAIN=1: per-op kernels instead of the chain kernels
+  int chain_nw = 0;         // A2P_CHAIN_NW=4|8: force the generation-1 workgroup shape (0: measured per box)
+  int chain_mt = 0;         // A2P_CHAIN_MT=n: force the panel height 16*n (also takes the chain path below 960 rows)
+  int chain_v = 0;          // A2P_CHAIN_V=1|2: chain kernel generation (0: default)
+  int chain_no_mix = 0;     // A2P_CHAIN_NO_MIX=1: uniform panel heights
+  int tune_verbose = 0;     // A2P_TUNE_VERBOSE=1: print the per-box shape decision
+  int side_join = 3;        // A2P_SIDE_JOIN: where the main stream joins the side stream (1 PRE, 2 self attention, 3 MID)
+  int x_rowmajor = 0;       // A2P_CHAIN_X_ROWMAJOR=1: residual stream row-major between chain kernels (A/B)
+  int no_side_stream = 0;   // A2P_NO_SIDE_STREAM=1: time path on the main stream
+  int side_early_join = 0;  // A2P_SIDE_EARLY_JOIN=1: side stream without overlap (diagnostic)
+  int no_shared_half = 0;   // A2P_NO_SHARED_HALF=1: layer 0 computed for both guidance halves
+};
+static void load_opts(A2POpts& o) {
+  auto flag = [](const char* n) { return getenv(n) != nullptr ? 1 : 0; };
+  auto num = [](const char* n, int dflt) { const char* v = getenv(n); return v ? atoi(v) : dflt; };
+  o.kv_cached = flag("A2P_KV_CACHED"); o.no_chain = flag("A2P_NO_CHAIN");
+  o.chain_nw = num("A2P_CHAIN_NW", 0); o.chain_mt = num("A2P_CHAIN_MT", 0); o.chain_v = num("A2P_CHAIN_V", 0);
+  o.chain_no_mix = flag("A2P_CHAIN_NO_MIX"); o.tune_verbose = flag("A2P_TUNE_VERBOSE"); o.side_join = num("A2P_SIDE_JOIN", 3);
+  o.x_rowmajor = flag("A2P_CHAIN_X_ROWMAJOR"); o.no_side_stream = flag("A2P_NO_SIDE_STREAM");
+  o.side_early_join = flag("A2P_SIDE_EARLY_JOIN"); o.no_shared_half = flag("A2P_NO_SHARED_HALF");
+}
+
 struct a2p_ctx {
   a2p_config cfg;
+  A2POpts opt;
   Arena arena;
   bool use_arena = true;
   int d, H, DH, L, C, Cpad, ff, F, Fc, FcPad, Kd, KdPad, Tmax, Tld, S0max, Sld, Bmax, Nmax, KFmax;
@@ -451,6 +478,7 @@ extern "C" int a2p_ctx_create(const a2p_config* cfg, a2p_ctx** out) {
   ARG(cfg->precision == A2P_PREC_F32 || cfg->precision == A2P_PREC_BF16, "bad precision");
   a2p_ctx* c = new a2p_ctx();
   c->cfg = *cfg;
+  load_opts(c->opt);
   c->use_arena = !getenv("A2P_NO_ARENA");
   ArenaScope scope(c->use_arena ? &c->arena : nullptr);
   c->d = cfg->latent_dim; c->H = cfg->num_heads; c->DH = dh; c->L = cfg->num_layers; c->C = cfg->nfeats;
@@ -494,7 +522,7 @@ extern "C" int a2p_ctx_create(const a2p_config* cfg, a2p_ctx** out) {
     A(c->kf_pack, (size_t)B * c->KFmax * c->KdPad * c->esz); A(c->kf_tok, (size_t)B * c->KFmax * d * 4);
   }
   A(c->slot_cond, B * 4); A(c->slot_unc, B * 4); A(c->slot_cfg, N * 4);
-  if (getenv("A2P_CHAIN_CLK")) A(c->clk, 64 * 32 * 8);
+  if (getenv("A2P_CHAIN_CLK")) A(c->clk, 64 * 32 * 8 + 2 * 64 * 8);   // + phase stamps of the diagnostic build (-DA2P_STAMPS)
   if (rc == 0 && hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking) != hipSuccess) rc = A2P_ERR_HIP;
   for (int i = 0; i < 8 && rc == 0; ++i)
     if (hipEventCreateWithFlags(&c->ev_fork_pool[i], hipEventDisableTiming) != hipSuccess ||
@@ -506,6 +534,12 @@ extern "C" int a2p_ctx_create(const a2p_config* cfg, a2p_ctx** out) {
     return rc;
   }
   *out = c;
+  return 0;
+}
+
+extern "C" int a2p_reload_env(a2p_ctx* c) {
+  ARG(c, "null ctx");
+  load_opts(c->opt);
   return 0;
 }
 

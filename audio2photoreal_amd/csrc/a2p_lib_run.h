@@ -79,7 +79,7 @@ static int cross_attn_block(a2p_ctx* c, const std::string& p, const std::string&
   a.O = c->ao.p; a.o_seq_stride = (int64_t)T * d; a.ldo = d;
   a.ktail = kv.ktail; a.vtail = kv.vtail; a.tail_sample_stride = kv.tail_sample_stride; a.tail_row_stride = kv.tail_row_stride;
   a.kv_slot = kv.slots; a.tail_mod = kv.tail_mod; a.Tq = T; a.S_main = kv.S_main; a.S_tail = kv.S_tail;
-  a.kv_stream = kv.slots && !getenv("A2P_KV_CACHED") ? 1 : 0;  // A2P_KV_CACHED=1: default cache policy for A/B runs
+  a.kv_stream = kv.slots && !c->opt.kv_cached ? 1 : 0;
   a.scale_log2e = 1.4426950408889634f / sqrtf((float)c->DH);
   CHK(launch_attn(c, a, N, A2P_KERNEL_ATTN_CROSS, s));
   return film_gemm(c, c->ao.p, d, p + ".out_proj.weight", W32(c, p + ".out_proj.bias"), d, fr, film_idx, M, T, s);
@@ -99,7 +99,7 @@ static int ffn_block(a2p_ctx* c, const std::string& p, const std::string& norm, 
 // bf16 throughput mode: the decoder layer as row-panel chain kernels (kernels_chain.h) around the attentions
 // ------------------------------------------------------------------------------------------------
 static bool chain_supported(const a2p_ctx* c) {
-  return c->bf16 && (c->d == 512 || c->d == 256) && c->ff == 1024 && !c->ch_stream.empty() && !getenv("A2P_NO_CHAIN");
+  return c->bf16 && (c->d == 512 || c->d == 256) && c->ff == 1024 && !c->ch_stream.empty() && !c->opt.no_chain;
 }
 
 enum { CH_PRE = 0, CH_MID = 1, CH_MID2 = 2, CH_POST = 3 };
@@ -226,6 +226,10 @@ static void chain_base(a2p_ctx* c, ChainP& p, int N, int T, int idx, int aux_flo
     p.n_pf = leaders; p.pf_waves = pfw; p.n_stages = c->ch_nstages[idx];
   }
   if (c->clk.p) {  // A2P_CHAIN_CLK=1: every chain launch of a forward gets its own 8 x 4 slot (a2p_debug_read "clk")
+#ifdef A2P_STAMPS   // diagnostic build (scratch/phase_probe.py): launch A2P_STAMP_LAUNCH of every forward writes its phase stamps behind the clk slots
+    static const int sel = getenv("A2P_STAMP_LAUNCH") ? atoi(getenv("A2P_STAMP_LAUNCH")) : 4;
+    p.fin_out = reinterpret_cast<float*>(reinterpret_cast<unsigned long long*>(c->clk.p) + 64 * 32 + ((int)c->clk_turn == sel ? 0 : 64));
+#endif
     p.clk = reinterpret_cast<unsigned long long*>(c->clk.p) + (size_t)(c->clk_turn++ % 64) * 32;
   }
 }
@@ -259,9 +263,9 @@ static void chain_set_out_proj(a2p_ctx* c, ChainP& p, const std::string& attn, c
 static const int kTuneForwards = 5;
 static int chain_pick_nw(a2p_ctx* c, int64_t rows, hipEvent_t* e0, hipEvent_t* e1) {
   *e0 = *e1 = nullptr;
-  if (const char* f = getenv("A2P_CHAIN_NW")) return atoi(f) == 8 ? 8 : 4;
-  if (const char* m = getenv("A2P_CHAIN_MT")) {  // a forced panel height the 8-wave kernels do not have
-    const int mt = atoi(m);
+  if (c->opt.chain_nw) return c->opt.chain_nw == 8 ? 8 : 4;
+  if (c->opt.chain_mt) {  // a forced panel height the 8-wave kernels do not have
+    const int mt = c->opt.chain_mt;
     if ((mt > 4 && c->d == 512) || mt > 5) return 4;
   }
   auto& t = c->ch_tune[rows];
@@ -286,7 +290,7 @@ static int chain_pick_nw(a2p_ctx* c, int64_t rows, hipEvent_t* e0, hipEvent_t* e
   }
   t.samples.clear();
   t.choice = (cnt[0] && cnt[1] && sum[1] / cnt[1] < sum[0] / cnt[0]) ? 8 : 4;
-  if (getenv("A2P_TUNE_VERBOSE"))
+  if (c->opt.tune_verbose)
     fprintf(stderr, "[a2p] chain workgroup shape for %lld rows: NW=4 %.3f ms, NW=8 %.3f ms -> %d\n", (long long)rows,
             cnt[0] ? sum[0] / cnt[0] : -1.0, cnt[1] ? sum[1] / cnt[1] : -1.0, t.choice);
   return t.choice;
@@ -297,8 +301,7 @@ static int chain_pick_nw(a2p_ctx* c, int64_t rows, hipEvent_t* e0, hipEvent_t* e
 // drain) + a per-stage part that is flat up to 64 rows (the 64 B/clk weight path: 256 cycles per stage) and MFMA-bound beyond
 // (64 cycles per 16 rows) + epilogues that grow with the rows (scratch/tall_probe, profiles/r03_tall_probe.txt).
 static int launch_chain2(a2p_ctx* c, int mode, const ChainP& p, hipStream_t s) {
-  const char* env_mt = getenv("A2P_CHAIN_MT");
-  int mt = env_mt ? atoi(env_mt) : 0;
+  int mt = c->opt.chain_mt;
   const int lo = 2, hi = c->d == 512 ? 5 : 6;
   if (mt < lo || mt > hi) {
     float best = 1e30f;
@@ -339,14 +342,13 @@ static int launch_chain2(a2p_ctx* c, int mode, const ChainP& p, hipStream_t s) {
 // which does not implement final_layer fused into the last POST kernel (A2P_TAIL16) nor frame counts that are not a multiple
 // of 8 (only the staged V^T store: 8 frames per 16-byte piece)
 static int chain_pick_ver(const a2p_ctx* c, int T) {
-  const char* v = getenv("A2P_CHAIN_V");
-  return (!(v && atoi(v) == 2) || (!c->tail32 && !c->pose) || (T & 7)) ? 1 : 2;
+  return (c->opt.chain_v != 2 || (!c->tail32 && !c->pose) || (T & 7)) ? 1 : 2;
 }
 
 static int launch_chain(a2p_ctx* c, int mode, const ChainP& p, hipStream_t s) {
   if (c->ch_ver == 2) return launch_chain2(c, mode, p, s);
-  const char* env_mt = getenv("A2P_CHAIN_MT");  // tuning / test override of the panel height (rows = 16 * MT)
-  int mt = env_mt ? atoi(env_mt) : 0;
+  const bool env_mt = c->opt.chain_mt != 0;  // tuning / test override of the panel height (rows = 16 * MT)
+  int mt = c->opt.chain_mt;
   // panel heights instantiated per width (LDS: the [16*MT][d] bf16 panel + hidden chunk + >= 3 ring slots must fit 160 KiB)
   static const int kMt512[] = {4, 3, 2}, kMt256[] = {6, 5, 4, 3, 2};
   static const int kMt512w8[] = {4, 3, 2}, kMt256w8[] = {5, 4, 3, 2};  // 8 waves: 256 registers per wave bound the panel height (d = 256, 96 rows: 46 spilled)
@@ -373,7 +375,7 @@ static int launch_chain(a2p_ctx* c, int mode, const ChainP& p, hipStream_t s) {
   // instead of 3.125 -> 4).  A2P_CHAIN_NO_MIX=1 keeps the uniform launch for A/B runs.
   // Only for the 8-wave shape: 64-row panels of 512-register waves live half in AGPRs and run 1.6-1.9x the 48-row time
   // (scratch/chain_bench, POST: 143 vs 89 us), with 8 waves 1.26-1.37x (102 vs 75 us) for 1.33x the rows.
-  if (w8 && c->d == 512 && mt == 3 && !env_mt && grid > 256 && grid % 256 != 0 && !getenv("A2P_CHAIN_NO_MIX")) {
+  if (w8 && c->d == 512 && mt == 3 && !env_mt && grid > 256 && grid % 256 != 0 && !c->opt.chain_no_mix) {
     const int W = 256 * ((grid + 255) / 256 - 1);
     const int n_tall = (p.M - 48 * W + 15) / 16;
     if (n_tall > 0 && n_tall <= W) {
@@ -391,11 +393,16 @@ static int launch_chain(a2p_ctx* c, int mode, const ChainP& p, hipStream_t s) {
       return 0;
     }
   }
-#define A2P_CHAIN_W(D, MT, NW)                                                                                  \
-  do {                                                                                                          \
-    if (mode == CHAIN_PRE) A2P_LAUNCH(kt, (chain_kernel<D, MT, CHAIN_PRE, 0, NW>), grid, 64 * NW, s, p);        \
-    else if (mode == CHAIN_MID) A2P_LAUNCH(kt, (chain_kernel<D, MT, CHAIN_MID, 0, NW>), grid, 64 * NW, s, p);   \
-    else A2P_LAUNCH(kt, (chain_kernel<D, MT, CHAIN_POST, 0, NW>), grid, 64 * NW, s, p);                         \
+#ifdef A2P_STAMPS
+#define A2P_CHAIN_ABL 64
+#else
+#define A2P_CHAIN_ABL 0
+#endif
+#define A2P_CHAIN_W(D, MT, NW)                                                                                              \
+  do {                                                                                                                      \
+    if (mode == CHAIN_PRE) A2P_LAUNCH(kt, (chain_kernel<D, MT, CHAIN_PRE, A2P_CHAIN_ABL, NW>), grid, 64 * NW, s, p);        \
+    else if (mode == CHAIN_MID) A2P_LAUNCH(kt, (chain_kernel<D, MT, CHAIN_MID, A2P_CHAIN_ABL, NW>), grid, 64 * NW, s, p);   \
+    else A2P_LAUNCH(kt, (chain_kernel<D, MT, CHAIN_POST, A2P_CHAIN_ABL, NW>), grid, 64 * NW, s, p);                         \
   } while (0)
 #define A2P_CHAIN(D, MT) A2P_CHAIN_W(D, MT, 4)
   if (w8) {
@@ -449,7 +456,7 @@ static int launch_cross_attention(a2p_ctx* c, int N, int T, const CrossKV& kv, h
   a.O = c->ao.p; a.o_seq_stride = (int64_t)T * d; a.ldo = d;
   a.ktail = kv.ktail; a.vtail = kv.vtail; a.tail_sample_stride = kv.tail_sample_stride; a.tail_row_stride = kv.tail_row_stride;
   a.kv_slot = kv.slots; a.tail_mod = kv.tail_mod; a.Tq = T; a.S_main = kv.S_main; a.S_tail = kv.S_tail;
-  a.kv_stream = kv.slots && !getenv("A2P_KV_CACHED") ? 1 : 0;  // A2P_KV_CACHED=1: default cache policy for A/B runs
+  a.kv_stream = kv.slots && !c->opt.kv_cached ? 1 : 0;
   a.scale_log2e = 1.4426950408889634f / sqrtf((float)c->DH);
   return launch_attn(c, a, N, A2P_KERNEL_ATTN_CROSS, s);
 }
@@ -464,11 +471,10 @@ static int decoder_layer_chain(a2p_ctx* c, int l, int N, int T, const CrossKV& k
   const int d = c->d;
   const std::string pf = "seqTransDecoder.stack." + std::to_string(l) + ".";
   ChainP p;
-  const char* jp = getenv("A2P_SIDE_JOIN");  // diagnostic: where the main stream joins the side stream (1 PRE, 2 self attention, default MID)
-  const int join_at = jp ? atoi(jp) : 3;
+  const int join_at = c->opt.side_join;  // diagnostic: where the main stream joins the side stream (1 PRE, 2 self attention, default MID)
   if (film_ready && join_at <= 1) HIPCHK(hipStreamWaitEvent(s, film_ready, 0));
   const int Nsa = shared_half ? N / 2 : N;
-  const bool tiled = !getenv("A2P_CHAIN_X_ROWMAJOR");   // A/B switch: keep the residual stream row-major between chain kernels
+  const bool tiled = !c->opt.x_rowmajor;   // A/B switch: keep the residual stream row-major between chain kernels
   // shared_half: the input projection wrote the (N/2)*T rows both halves start from into c->hff (unused by the chain path, fp32
   // here); PRE reads them there, MID reads them there for BOTH halves and writes all N*T rows of c->x -- never in place: a
   // second-half workgroup may start after the first-half workgroup of the same source rows has stored its result
@@ -672,14 +678,14 @@ static int run_forward(a2p_ctx* c, const float* x_in, const int64_t* t_orig, int
   // Row panels pay off once there are enough of them: every workgroup streams the whole weight set of its chain, so a
   // forward of < ~1000 rows (config 0: B=1, T=240 -> 480 rows = 10 panels) is faster as many small 2-D tiles
   // (measured: 0.99 vs 1.10 ms per step at 480 rows, equal at 1200, chain ahead from 2400 rows on).
-  const bool use_chain = chain_supported(c) && ((int64_t)N * T >= 960 || getenv("A2P_CHAIN_MT"));
+  const bool use_chain = chain_supported(c) && ((int64_t)N * T >= 960 || c->opt.chain_mt);
   // The time path (7 latency-bound launches, ~70 us at B=8) is not needed before the first out_proj epilogue and can run on
   // the side stream next to input projection / norm1+QKV / self attention of layer 0 (-2..3 % step time).  On by default since
   // round 2 (A2P_NO_SIDE_STREAM=1 turns it off): in round 1, with the two queues active, 1-30 % of forwards on some boxes
   // differed for one sample; that was traced to tpath_post_kernel consuming a load right behind its s_waitcnt (kernels_misc.h,
   // DESIGN.md "Reproducibility") and fixed there -- 0 / 1500 differing forwards in round 1, 0 / 600 + identical 60-step
   // trajectories in both 16-bit modes in round 2 (scratch/side_stress.py).
-  const bool overlap_tpath = use_chain && !getenv("A2P_NO_SIDE_STREAM");
+  const bool overlap_tpath = use_chain && !c->opt.no_side_stream;
   if (overlap_tpath) {
     c->ev_fork = c->ev_fork_pool[c->ev_turn & 7];
     c->ev_join = c->ev_join_pool[c->ev_turn & 7];
@@ -688,7 +694,7 @@ static int run_forward(a2p_ctx* c, const float* x_in, const int64_t* t_orig, int
     HIPCHK(hipStreamWaitEvent(c->side, c->ev_fork, 0));
     CHK(time_path(c, t_orig, N, slots, c->side));
     HIPCHK(hipEventRecord(c->ev_join, c->side));
-    if (getenv("A2P_SIDE_EARLY_JOIN")) HIPCHK(hipStreamWaitEvent(s, c->ev_join, 0));  // diagnostic: side stream without overlap
+    if (c->opt.side_early_join) HIPCHK(hipStreamWaitEvent(s, c->ev_join, 0));  // diagnostic: side stream without overlap
   } else {
     CHK(time_path(c, t_orig, N, slots, s));
   }
@@ -700,7 +706,7 @@ static int run_forward(a2p_ctx* c, const float* x_in, const int64_t* t_orig, int
     if (c->tail_x3) pack_input_split3_kernel<<<grid, 256, 0, s>>>(x_in, (h16_t*)c->inpack.p, B, c->C, T, c->Cpad);
     else if (c->bf16) pack_input_kernel<h16_t><<<grid, 256, 0, s>>>(x_in, (h16_t*)c->inpack.p, B, c->C, T, c->Cpad);
     else pack_input_kernel<float><<<grid, 256, 0, s>>>(x_in, (float*)c->inpack.p, B, c->C, T, c->Cpad);
-    const bool shared_half = use_chain && N == 2 * B && !getenv("A2P_NO_SHARED_HALF");
+    const bool shared_half = use_chain && N == 2 * B && !c->opt.no_shared_half;
     GemmP p = gemm_base(c->inpack.p, X * c->Cpad, c->wt.at("input_projection.weight").p, X * c->Cpad, W32(c, "input_projection.bias"),
                         shared_half ? c->hff.p : c->x.p, d, B * T, d, X * c->Cpad);
     p.out_f32 = c->bf16 ? 1 : 0;   // gemm_kernel<float> stores fp32 either way; the flag only selects a 16-bit kernel instance
@@ -736,7 +742,7 @@ static int run_forward(a2p_ctx* c, const float* x_in, const int64_t* t_orig, int
     fr.seq_stride = (int64_t)L * F * 2 * d;
     if (use_chain)
       CHK(decoder_layer_chain(c, l, N, T, kv, c->pose ? &kv2 : nullptr, fr, l == 0, l + 1 < L, s, (overlap_tpath && l == 0) ? c->ev_join : nullptr,
-                              /*fuse_final=*/!c->pose && !c->tail32, /*shared_half=*/l == 0 && N == 2 * B && !getenv("A2P_NO_SHARED_HALF")));
+                              /*fuse_final=*/!c->pose && !c->tail32, /*shared_half=*/l == 0 && N == 2 * B && !c->opt.no_shared_half));
     else CHK(decoder_layer(c, l, N, T, kv, c->pose ? &kv2 : nullptr, fr, s));
   }
   if (tune1) HIPCHK(hipEventRecord(tune1, s));

@@ -67,7 +67,7 @@ __device__ __forceinline__ void chain2_body(const ChainP& p, h16_t* const smem, 
   float* const aux = red + 16 * BM;                                   // [AUX_F] per-tile biases
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, l15 = lane & 15, g = lane >> 4;
   const int W4 = wid >> 1, J0 = wid & 1;
-#ifdef C2_STAMPS   // scratch/chain2_bench.hip: 100 MHz phase stamps of workgroups 0 and 101 into p.fin_out
+#if defined(C2_STAMPS) || defined(A2P_STAMPS)   // scratch/chain2_bench.hip, scratch/phase_probe.py: 100 MHz phase stamps of workgroups 0 and 101 into p.fin_out
   auto stamp = [&](int i) __attribute__((always_inline)) {
     const int cb = (int)blockIdx.x - p.n_pf;
     if (tid == 0 && (cb == 0 || cb == 101)) reinterpret_cast<unsigned long long*>(p.fin_out)[(cb ? 32 : 0) + i] = wall_clock64();

@@ -245,6 +245,7 @@ class FiLMTransformer(nn.Module):
         with torch.cuda.device(device):
             _lib.check(lib.a2p_ctx_create(C.byref(cfg), C.byref(ctx)), "a2p_ctx_create")
         self._ctx, self._ctx_key, self._weights_key, self._ctx_lib = ctx, key, None, lib
+        self._env_sig = _lib.env_signature()      # the context read the A2P_* switches just now
         self.invalidate_cond()
         return lib
 
@@ -328,6 +329,10 @@ class FiLMTransformer(nn.Module):
         _lib.require_gpu_tensor(x, "x")
         B, T = x.shape[0], x.shape[-1] if x.dim() == 4 else x.shape[1]
         lib = self._ensure_ctx(x.device, B)
+        sig = _lib.env_signature()
+        if sig != self._env_sig:                   # an A2P_* switch changed since the context cached them (tests, A/B runs)
+            _lib.check(lib.a2p_reload_env(self._ctx), "a2p_reload_env")
+            self._env_sig = sig
         self._ensure_weights(lib, x.device)
         src = self._cond_source(y)
         kf = mask = None

@@ -185,6 +185,10 @@ int a2p_attention(a2p_ctx* ctx, const float* q, const float* k, const float* v, 
 int a2p_kernel_timing(a2p_ctx* ctx, int32_t kind, int32_t enable);
 int a2p_kernel_time_ms(a2p_ctx* ctx, double* total_ms, int64_t* launches);
 
+/* ---- run-time switches: the A2P_* environment variables that steer a forward (INTEGRATION.md "Environment switches") are read
+ * when the context is created; a host that changes one afterwards calls this (the Python mirror does, model/diffusion.py). */
+int a2p_reload_env(a2p_ctx* ctx);
+
 /* ---- debugging aid: copies an internal buffer ("film", "ktail", "vtail", "tvec", "x", "qk", "vt", "ao", "mo") to host
  * memory after a device synchronise (race hunts, scratch/stress*.py); not part of the reference's interface. */
 int a2p_debug_read(a2p_ctx* ctx, const char* name, void* host, int64_t bytes);
