@@ -29,6 +29,7 @@
 #include "kernels_chain2.h"
 #include "kernels_gemm.h"
 #include "kernels_misc.h"
+#include "kernels_small.h"
 
 static thread_local char g_err[1024] = "";
 static void set_err(const char* fmt, ...) {
@@ -142,6 +143,7 @@ struct A2POpts {
   int no_side_stream = 0;   // A2P_NO_SIDE_STREAM=1: time path on the main stream
   int side_early_join = 0;  // A2P_SIDE_EARLY_JOIN=1: side stream without overlap (diagnostic)
   int no_shared_half = 0;   // A2P_NO_SHARED_HALF=1: layer 0 computed for both guidance halves
+  int no_small = 0;         // A2P_NO_SMALL=1: per-op kernels for forwards below 960 rows instead of kernels_small.h
 };
 static void load_opts(A2POpts& o) {
   auto flag = [](const char* n) { return getenv(n) != nullptr ? 1 : 0; };
@@ -151,6 +153,7 @@ static void load_opts(A2POpts& o) {
   o.chain_no_mix = flag("A2P_CHAIN_NO_MIX"); o.tune_verbose = flag("A2P_TUNE_VERBOSE"); o.side_join = num("A2P_SIDE_JOIN", 3);
   o.x_rowmajor = flag("A2P_CHAIN_X_ROWMAJOR"); o.no_side_stream = flag("A2P_NO_SIDE_STREAM");
   o.side_early_join = flag("A2P_SIDE_EARLY_JOIN"); o.no_shared_half = flag("A2P_NO_SHARED_HALF");
+  o.no_small = flag("A2P_NO_SMALL");
 }
 
 struct a2p_ctx {

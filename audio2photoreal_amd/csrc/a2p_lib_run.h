@@ -535,6 +535,83 @@ static int decoder_layer(a2p_ctx* c, int l, int N, int T, const CrossKV& kv, con
 }
 
 // ------------------------------------------------------------------------------------------------
+// small forwards (16-bit modes, < 960 rows, face model): whole-K-resident small-tile GEMMs with the LayerNorm fused into the A
+// load (kernels_small.h): 8 launches per decoder layer instead of 12
+// ------------------------------------------------------------------------------------------------
+static bool small_supported(const a2p_ctx* c) {
+  return c->bf16 && c->d == 512 && c->ff == 1024 && !c->pose && !c->opt.no_small;
+}
+
+template <int K, int BN, int PRO, int EPI>
+static int launch_small(a2p_ctx* c, const SmallP& p, hipStream_t s) {
+  KernelTimer kt(c, A2P_KERNEL_GEMM);
+  dim3 grid((p.N + BN - 1) / BN, (p.M + 31) / 32);
+  A2P_LAUNCH(kt, (small_gemm_kernel<K, BN, PRO, EPI>), grid, 256, s, p);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+static int decoder_layer_small(a2p_ctx* c, int l, int N, int T, const CrossKV& kv, const FilmRef& fr, hipStream_t s) {
+  const int d = c->d, ff = c->ff, M = N * T, Tld = rup(T, 64);
+  const std::string pf = "seqTransDecoder.stack." + std::to_string(l) + ".";
+  SmallP base;
+  memset(&base, 0, sizeof(base));
+  base.M = M; base.rows_per_seq = T; base.cs = reinterpret_cast<const float2*>(c->rope_cs.p);
+  auto ln = [&](SmallP& p, const std::string& norm) {
+    p.x = c->x.f(); p.gamma = W32(c, pf + norm + ".weight"); p.beta = W32(c, pf + norm + ".bias");
+  };
+  auto film = [&](SmallP& p, int idx) {
+    p.resid = c->x.f(); p.film = fr.base + (int64_t)idx * 2 * d; p.film_seq_stride = fr.seq_stride; p.film_shift_off = d;
+  };
+  {  // norm1 -> rotary -> [Q|K] ; norm1 -> V^T : one launch over the 3d output columns
+    SmallP p = base;
+    ln(p, "norm1");
+    p.n_rope = 2 * d; p.W = reinterpret_cast<const h16_t*>(c->wt.at(pf + "self_attn.in_proj_weight").p); p.bias = W32(c, pf + "self_attn.in_proj_bias");
+    p.N = 3 * d; p.out = reinterpret_cast<h16_t*>(c->qk.p); p.ldo = 2 * d; p.n_store = 2 * d;
+    p.out_t = reinterpret_cast<h16_t*>(c->vt.p); p.ld_t = Tld; p.t_seq_stride = (int64_t)d * Tld;
+    CHK((launch_small<512, 64, 1, SMALL_STORE>(c, p, s)));
+  }
+  CHK(launch_self_attention(c, N, T, s));
+  {  // out_proj + FiLM + residual
+    SmallP p = base;
+    p.a = reinterpret_cast<const h16_t*>(c->ao.p); p.lda = d; p.W = reinterpret_cast<const h16_t*>(c->wt.at(pf + "self_attn.out_proj.weight").p);
+    p.bias = W32(c, pf + "self_attn.out_proj.bias"); p.N = d;
+    film(p, 0);
+    CHK((launch_small<512, 64, 0, SMALL_FILM_RES>(c, p, s)));
+  }
+  {  // norm2 -> rotary -> Q of the cross attention
+    SmallP p = base;
+    ln(p, "norm2");
+    p.n_rope = d; p.W = reinterpret_cast<const h16_t*>(c->wt.at(pf + "multihead_attn.in_proj_weight").p); p.bias = W32(c, pf + "multihead_attn.in_proj_bias");
+    p.N = d; p.out = reinterpret_cast<h16_t*>(c->qk.p); p.ldo = d; p.n_store = d;
+    CHK((launch_small<512, 64, 1, SMALL_STORE>(c, p, s)));
+  }
+  CHK(launch_cross_attention(c, N, T, kv, s));
+  {
+    SmallP p = base;
+    p.a = reinterpret_cast<const h16_t*>(c->ao.p); p.lda = d; p.W = reinterpret_cast<const h16_t*>(c->wt.at(pf + "multihead_attn.out_proj.weight").p);
+    p.bias = W32(c, pf + "multihead_attn.out_proj.bias"); p.N = d;
+    film(p, 1);
+    CHK((launch_small<512, 64, 0, SMALL_FILM_RES>(c, p, s)));
+  }
+  {  // norm3 -> linear1 + GELU
+    SmallP p = base;
+    ln(p, "norm3");
+    p.n_rope = 0; p.W = reinterpret_cast<const h16_t*>(c->wt.at(pf + "linear1.weight").p); p.bias = W32(c, pf + "linear1.bias");
+    p.N = ff; p.out = reinterpret_cast<h16_t*>(c->hff.p); p.ldo = ff; p.n_store = ff; p.gelu = 1;
+    CHK((launch_small<512, 64, 1, SMALL_STORE>(c, p, s)));
+  }
+  {  // linear2 + FiLM + residual (K = ff)
+    SmallP p = base;
+    p.a = reinterpret_cast<const h16_t*>(c->hff.p); p.lda = ff; p.W = reinterpret_cast<const h16_t*>(c->wt.at(pf + "linear2.weight").p);
+    p.bias = W32(c, pf + "linear2.bias"); p.N = d;
+    film(p, 2);
+    CHK((launch_small<1024, 32, 0, SMALL_FILM_RES>(c, p, s)));
+  }
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
 // hoisted conditioning
 // ------------------------------------------------------------------------------------------------
 // K/V slot of every sequence of a pass: slot 1 + b = sample b's conditioning, slot 0 = the batch-invariant unconditional branch
@@ -743,6 +820,7 @@ static int run_forward(a2p_ctx* c, const float* x_in, const int64_t* t_orig, int
     if (use_chain)
       CHK(decoder_layer_chain(c, l, N, T, kv, c->pose ? &kv2 : nullptr, fr, l == 0, l + 1 < L, s, (overlap_tpath && l == 0) ? c->ev_join : nullptr,
                               /*fuse_final=*/!c->pose && !c->tail32, /*shared_half=*/l == 0 && N == 2 * B && !c->opt.no_shared_half));
+    else if (small_supported(c)) CHK(decoder_layer_small(c, l, N, T, kv, fr, s));
     else CHK(decoder_layer(c, l, N, T, kv, c->pose ? &kv2 : nullptr, fr, s));
   }
   if (tune1) HIPCHK(hipEventRecord(tune1, s));

@@ -138,3 +138,35 @@ def test_device_tensor_all_gather_over_rccl(tmp_path):
            "--master-port", str(port), str(script)]
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+# ----------------------------------------------------------------------------- small forwards (BASELINE configs[0] shape)
+@pytest.mark.parametrize("precision", ["bf16", "fp16"])
+@pytest.mark.parametrize("B,T", [(1, 240), (1, 150), (2, 100), (1, 30)])
+def test_small_forward_kernels_match_the_per_op_kernels_and_the_oracle(dev, B, T, precision, monkeypatch):
+    """Forwards below 960 rows (config 0: B=1, T=240 -> 480 rows) run the decoder layers as whole-K-resident small-tile GEMMs with the
+    LayerNorm fused into the A load and [Q|K] + V^T in one launch (csrc/kernels_small.h).  Same operands, same MFMA shape and
+    k-order as the per-op kernels they replace: the two paths must agree to operand rounding (they are bit-identical where the
+    compiler contracts the LayerNorm arithmetic alike), and both sit at the precision's distance from the fp32 oracle.  T = 150 and
+    T = 30 exercise the row-by-row V^T store and ragged row blocks."""
+    from oracle import a2p_oracle as O
+    spec, model = _model("face", precision, dev, B)
+    cfg = ClassifierFreeSampleModel(model)
+    x, t, y = _inputs(spec, "face", B, T, dev)
+    assert 2 * B * T < 960
+    monkeypatch.delenv("A2P_NO_SMALL", raising=False)
+    small = cfg(x, t, y).cpu()
+    monkeypatch.setenv("A2P_NO_SMALL", "1")
+    per_op = cfg(x, t, y).cpu()
+    monkeypatch.delenv("A2P_NO_SMALL")
+    inp = synthetic_inputs(spec, B, T, SEED)
+    den = O.OracleDenoiser(synthetic_state_dict(spec, SEED), "face", spec.num_layers, spec.num_heads)
+    with torch.no_grad():
+        want = den.forward_cfg(inp["x_T"], t.cpu(), inp["cond_embed"], torch.full((B,), 10.0))
+    rel = lambda a, b: float((a - b).norm() / b.norm())
+    e_pair, e_small, e_old = rel(small, per_op), rel(small, want), rel(per_op, want)
+    record(f"small_vs_perop/{precision}/B{B}_T{T}", pair=e_pair, small_vs_oracle=e_small, perop_vs_oracle=e_old)
+    k = 1.0 if precision == "bf16" else 1.0 / 6.0
+    assert torch.isfinite(small).all()
+    assert e_pair < k * 6.5e-3 and e_small < k * 9e-3 and e_small < 1.2 * e_old + k * 1e-3, (e_pair, e_small, e_old)
+    model.release()
