@@ -63,6 +63,27 @@ __device__ __forceinline__ float wave_sum(float v) {
   return v;
 }
 
+// Sum over the 64 lanes without the LDS crossbar: four DPP steps inside each row of 16 lanes (quad_perm xor 1, xor 2, then
+// row_half_mirror / row_mirror, which pair every lane with one of the OTHER quad / half once quads / halves are uniform), then
+// gfx950's v_permlane16_swap / v_permlane32_swap across the rows.  ~10 VALU instructions against 6 ds_bpermute round trips; the
+// summation tree differs from wave_sum's butterfly (fp32 rounding may differ in the last bit).
+template <int CTRL>
+__device__ __forceinline__ float dpp_mov(float x) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), CTRL, 0xF, 0xF, true));
+}
+__device__ __forceinline__ float wave_sum_valu(float v) {
+  v += dpp_mov<0xB1>(v);    // quad_perm [1,0,3,2]
+  v += dpp_mov<0x4E>(v);    // quad_perm [2,3,0,1]
+  v += dpp_mov<0x141>(v);   // row_half_mirror
+  v += dpp_mov<0x140>(v);   // row_mirror: every lane of a row now holds the row's sum
+  const unsigned u = __float_as_uint(v);
+  const auto a = __builtin_amdgcn_permlane16_swap(u, u, false, false);   // rows {0,0,2,2} and {1,1,3,3}
+  const float w = __uint_as_float(a[0]) + __uint_as_float(a[1]);
+  const unsigned x = __float_as_uint(w);
+  const auto b = __builtin_amdgcn_permlane32_swap(x, x, false, false);   // halves {lo, lo} and {hi, hi}
+  return __uint_as_float(b[0]) + __uint_as_float(b[1]);
+}
+
 // activations (torch definitions)
 __device__ __forceinline__ float act_gelu(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
 // bf16-mode GELU: erf by Abramowitz-Stegun 7.1.26 (|abs err| <= 1.5e-7), v_rcp/v_exp instead of ocml erff

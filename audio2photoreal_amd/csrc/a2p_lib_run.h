@@ -542,16 +542,17 @@ static bool small_supported(const a2p_ctx* c) {
   return c->bf16 && c->d == 512 && c->ff == 1024 && !c->pose && !c->opt.no_small;
 }
 
-template <int K, int BN, int PRO, int EPI>
+template <int K, int BN, int PRO, int EPI, int BM = 32>
 static int launch_small(a2p_ctx* c, const SmallP& p, hipStream_t s) {
   KernelTimer kt(c, A2P_KERNEL_GEMM);
-  dim3 grid((p.N + BN - 1) / BN, (p.M + 31) / 32);
-  A2P_LAUNCH(kt, (small_gemm_kernel<K, BN, PRO, EPI>), grid, 256, s, p);
+  dim3 grid((p.N + BN - 1) / BN, (p.M + BM - 1) / BM);
+  A2P_LAUNCH(kt, (small_gemm_kernel<K, BN, PRO, EPI, BM>), grid, 256, s, p);
   HIPCHK(hipGetLastError());
   return 0;
 }
 
-static int decoder_layer_small(a2p_ctx* c, int l, int N, int T, const CrossKV& kv, const FilmRef& fr, hipStream_t s) {
+static int decoder_layer_small(a2p_ctx* c, int l, int N, int T, const CrossKV& kv, const FilmRef& fr, hipStream_t s,
+                               hipEvent_t film_ready = nullptr) {
   const int d = c->d, ff = c->ff, M = N * T, Tld = rup(T, 64);
   const std::string pf = "seqTransDecoder.stack." + std::to_string(l) + ".";
   SmallP base;
@@ -572,6 +573,7 @@ static int decoder_layer_small(a2p_ctx* c, int l, int N, int T, const CrossKV& k
     CHK((launch_small<512, 64, 1, SMALL_STORE>(c, p, s)));
   }
   CHK(launch_self_attention(c, N, T, s));
+  if (film_ready) HIPCHK(hipStreamWaitEvent(s, film_ready, 0));   // FiLM / time-token K,V of this step come from the side stream
   {  // out_proj + FiLM + residual
     SmallP p = base;
     p.a = reinterpret_cast<const h16_t*>(c->ao.p); p.lda = d; p.W = reinterpret_cast<const h16_t*>(c->wt.at(pf + "self_attn.out_proj.weight").p);
@@ -762,6 +764,9 @@ static int run_forward(a2p_ctx* c, const float* x_in, const int64_t* t_orig, int
   // differed for one sample; that was traced to tpath_post_kernel consuming a load right behind its s_waitcnt (kernels_misc.h,
   // DESIGN.md "Reproducibility") and fixed there -- 0 / 1500 differing forwards in round 1, 0 / 600 + identical 60-step
   // trajectories in both 16-bit modes in round 2 (scratch/side_stress.py).
+  const bool use_small = !use_chain && small_supported(c);
+  // (the small path keeps the time path on the main stream: on the side stream it measured 1430 against 1497 steps/s at 480 rows --
+  // the fork / join costs more than the 7 launches it hides)
   const bool overlap_tpath = use_chain && !c->opt.no_side_stream;
   if (overlap_tpath) {
     c->ev_fork = c->ev_fork_pool[c->ev_turn & 7];
@@ -820,7 +825,7 @@ static int run_forward(a2p_ctx* c, const float* x_in, const int64_t* t_orig, int
     if (use_chain)
       CHK(decoder_layer_chain(c, l, N, T, kv, c->pose ? &kv2 : nullptr, fr, l == 0, l + 1 < L, s, (overlap_tpath && l == 0) ? c->ev_join : nullptr,
                               /*fuse_final=*/!c->pose && !c->tail32, /*shared_half=*/l == 0 && N == 2 * B && !c->opt.no_shared_half));
-    else if (small_supported(c)) CHK(decoder_layer_small(c, l, N, T, kv, fr, s));
+    else if (use_small) CHK(decoder_layer_small(c, l, N, T, kv, fr, s, (overlap_tpath && l == 0) ? c->ev_join : nullptr));
     else CHK(decoder_layer(c, l, N, T, kv, c->pose ? &kv2 : nullptr, fr, s));
   }
   if (tune1) HIPCHK(hipEventRecord(tune1, s));

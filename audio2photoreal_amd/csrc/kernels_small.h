@@ -44,13 +44,16 @@ struct SmallP {
   int film_shift_off;
 };
 
-template <int K, int BN, int PRO, int EPI>
+// BM: 32 rows.  (64-row tiles for the wide LayerNorm-prologue GEMMs -- one round of workgroups instead of 1.4 at 480 rows, half the
+// weight traffic -- were measured and lose: 14.8 us per launch against 12.5: the prologue of a workgroup is a serial chain of
+// latencies, twice as long with twice the rows.)
+template <int K, int BN, int PRO, int EPI, int BM = 32>
 __global__ __launch_bounds__(256) void small_gemm_kernel(const SmallP p) {
-  constexpr int BM = 32, CPR = K / 8;                 // 16-byte chunks per row
+  constexpr int CPR = K / 8;                          // 16-byte chunks per row
   constexpr int WR = BN == 64 ? 1 : 2;                // wave grid: WR row groups x (4 / WR) column groups of 16 columns
   constexpr int MT = BM / 16 / WR;                    // 16-row tiles per wave
   constexpr int KC = K / 32;                          // MFMA k-chunks
-  static_assert((BN == 64 || BN == 32) && (K == 512 || K == 1024), "tile shapes");
+  static_assert((BN == 64 || BN == 32) && (K == 512 || K == 1024) && (BM == 32 || BM == 64), "tile shapes");
   __shared__ __attribute__((aligned(16))) h16_t smem[(BM + BN) * K];
   h16_t* const As = smem;
   h16_t* const Ws = smem + BM * K;
@@ -95,11 +98,13 @@ __global__ __launch_bounds__(256) void small_gemm_kernel(const SmallP p) {
     float4 be0 = *reinterpret_cast<const float4*>(p.beta + e0), be1 = *reinterpret_cast<const float4*>(p.beta + e0 + 4);
     const float gam[8] = {ga0.x, ga0.y, ga0.z, ga0.w, ga1.x, ga1.y, ga1.z, ga1.w};
     const float bet[8] = {be0.x, be0.y, be0.z, be0.w, be1.x, be1.y, be1.z, be1.w};
+#pragma unroll 1
+    for (int rb = 0; rb < BM; rb += 32) {   // 8 rows per wave and batch
     float v[8][8];
     float4 rc[8][2];   // the rows' rotary entries (cos, sin) x 4 pairs, requested with the rows: one round trip, not two
 #pragma unroll
     for (int rr = 0; rr < 8; ++rr) {   // all loads of the wave's rows first
-      int gm = m0 + wid * 8 + rr;
+      int gm = m0 + rb + wid * 8 + rr;
       gm = gm < p.M ? gm : p.M - 1;
       const float4 t0 = *reinterpret_cast<const float4*>(p.x + (int64_t)gm * K + e0);
       const float4 t1 = *reinterpret_cast<const float4*>(p.x + (int64_t)gm * K + e0 + 4);
@@ -111,20 +116,37 @@ __global__ __launch_bounds__(256) void small_gemm_kernel(const SmallP p) {
         rc[rr][1] = c4[1];
       }
     }
+    // The two reductions of the 8 rows are independent chains of VALU cross-lane steps (DPP + permlane swaps, a2p_common.h): as
+    // __shfl_xor butterflies (ds_bpermute: an LDS round trip of ~120 cycles per step) done row by row they were 8 us of a 14 us launch
+    auto wave_sum8 = [&](float(&t)[8]) __attribute__((always_inline)) {
+#pragma unroll
+      for (int rr = 0; rr < 8; ++rr) t[rr] = wave_sum_valu(t[rr]);
+    };
+    float red[8];
 #pragma unroll
     for (int rr = 0; rr < 8; ++rr) {
-      const int r = wid * 8 + rr;
       float s = 0.f;
 #pragma unroll
       for (int i = 0; i < 8; ++i) s += v[rr][i];
-      const float mean = wave_sum(s) * (1.0f / K);
+      red[rr] = s;
+    }
+    wave_sum8(red);
+#pragma unroll
+    for (int rr = 0; rr < 8; ++rr) {
+      const float mean = red[rr] * (1.0f / K);
       float q = 0.f;
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
         v[rr][i] -= mean;
         q += v[rr][i] * v[rr][i];
       }
-      const float rstd = 1.0f / sqrtf(wave_sum(q) * (1.0f / K) + 1e-5f);
+      red[rr] = q;
+    }
+    wave_sum8(red);
+#pragma unroll
+    for (int rr = 0; rr < 8; ++rr) {
+      const int r = rb + wid * 8 + rr;
+      const float rstd = 1.0f / sqrtf(red[rr] * (1.0f / K) + 1e-5f);
 #pragma unroll
       for (int i = 0; i < 8; ++i) v[rr][i] = v[rr][i] * rstd * gam[i] + bet[i];
       h16x8 o;
@@ -141,6 +163,7 @@ __global__ __launch_bounds__(256) void small_gemm_kernel(const SmallP p) {
         for (int i = 0; i < 8; ++i) o[i] = (h16_t)v[rr][i];
       }
       *reinterpret_cast<h16x8*>(As + r * K + ((lane ^ (r & 15)) << 3)) = o;
+    }
     }
   }
   // ---- MFMA: wave (wr, wc) owns rows wr*16*MT .. and columns wc*16 .. +15 of the tile ------------------------------------------
