@@ -144,6 +144,8 @@ struct A2POpts {
   int side_early_join = 0;  // A2P_SIDE_EARLY_JOIN=1: side stream without overlap (diagnostic)
   int no_shared_half = 0;   // A2P_NO_SHARED_HALF=1: layer 0 computed for both guidance halves
   int no_small = 0;         // A2P_NO_SMALL=1: per-op kernels for forwards below 960 rows instead of kernels_small.h
+  int chain_rows = 1280;    // A2P_CHAIN_ROWS=n: forwards of at least n rows take the chain kernels (measured crossover against the small-forward
+                            // GEMMs of kernels_small.h: 1192 vs 1002 steps/s at 960 rows, 804 vs 1018 at 1920)
 };
 static void load_opts(A2POpts& o) {
   auto flag = [](const char* n) { return getenv(n) != nullptr ? 1 : 0; };
@@ -153,7 +155,7 @@ static void load_opts(A2POpts& o) {
   o.chain_no_mix = flag("A2P_CHAIN_NO_MIX"); o.tune_verbose = flag("A2P_TUNE_VERBOSE"); o.side_join = num("A2P_SIDE_JOIN", 3);
   o.x_rowmajor = flag("A2P_CHAIN_X_ROWMAJOR"); o.no_side_stream = flag("A2P_NO_SIDE_STREAM");
   o.side_early_join = flag("A2P_SIDE_EARLY_JOIN"); o.no_shared_half = flag("A2P_NO_SHARED_HALF");
-  o.no_small = flag("A2P_NO_SMALL");
+  o.no_small = flag("A2P_NO_SMALL"); o.chain_rows = num("A2P_CHAIN_ROWS", 1280);
 }
 
 struct a2p_ctx {
@@ -196,6 +198,7 @@ struct a2p_ctx {
   Buf clk;               // A2P_CHAIN_CLK=1: 64 chain launches x 8 blocks x {memtime, realtime} x {begin, end}
   unsigned clk_turn = 0;
   int pB = 0, pS0 = 0, pT = 0, pK = 0;
+  int batch_hint = 0;    // a2p_set_batch_hint: samples of the UNSHARDED batch this context's batch is a block of (0: unknown)
   // workspaces
   Buf x, xn, xr, qk, vt, ao, hff, inpack, mo, cb[4], t3;
   Buf emb, th, tct, tvec, mt, tokn, tokr, film, ktail, vtail;
@@ -537,6 +540,12 @@ extern "C" int a2p_ctx_create(const a2p_config* cfg, a2p_ctx** out) {
     return rc;
   }
   *out = c;
+  return 0;
+}
+
+extern "C" int a2p_set_batch_hint(a2p_ctx* c, int32_t global_batch) {
+  ARG(c && global_batch >= 0, "bad arguments");
+  c->batch_hint = global_batch;
   return 0;
 }
 

@@ -535,7 +535,7 @@ static int decoder_layer(a2p_ctx* c, int l, int N, int T, const CrossKV& kv, con
 }
 
 // ------------------------------------------------------------------------------------------------
-// small forwards (16-bit modes, < 960 rows, face model): whole-K-resident small-tile GEMMs with the LayerNorm fused into the A
+// small forwards (16-bit modes, below A2POpts::chain_rows = 1280 rows, face model): whole-K-resident small-tile GEMMs with the LayerNorm fused into the A
 // load (kernels_small.h): 8 launches per decoder layer instead of 12
 // ------------------------------------------------------------------------------------------------
 static bool small_supported(const a2p_ctx* c) {
@@ -757,7 +757,10 @@ static int run_forward(a2p_ctx* c, const float* x_in, const int64_t* t_orig, int
   // Row panels pay off once there are enough of them: every workgroup streams the whole weight set of its chain, so a
   // forward of < ~1000 rows (config 0: B=1, T=240 -> 480 rows = 10 panels) is faster as many small 2-D tiles
   // (measured: 0.99 vs 1.10 ms per step at 480 rows, equal at 1200, chain ahead from 2400 rows on).
-  const bool use_chain = chain_supported(c) && ((int64_t)N * T >= 960 || c->opt.chain_mt);
+  // The kernel family is chosen from the row count of the UNSHARDED batch when the host names it (a2p_set_batch_hint;
+  // sample_parallel does): the families differ in rounding, and a sharded run must reproduce the single-process samples bit for bit
+  const int64_t rows_eff = (int64_t)(c->batch_hint > B ? (N / B) * c->batch_hint : N) * T;
+  const bool use_chain = chain_supported(c) && (rows_eff >= c->opt.chain_rows || c->opt.chain_mt);
   // The time path (7 latency-bound launches, ~70 us at B=8) is not needed before the first out_proj epilogue and can run on
   // the side stream next to input projection / norm1+QKV / self attention of layer 0 (-2..3 % step time).  On by default since
   // round 2 (A2P_NO_SIDE_STREAM=1 turns it off): in round 1, with the two queues active, 1-30 % of forwards on some boxes

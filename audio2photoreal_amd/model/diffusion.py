@@ -133,6 +133,7 @@ class FiLMTransformer(nn.Module):
         self.audio_frontend = audio_frontend          # None | callable(audio) -> cond_embed | "native" (set up below)
         self.precision = precision
         self.max_batch = max_batch
+        self.global_batch_hint = 0                   # set by sample_parallel: size of the unsharded batch (a2p_set_batch_hint)
         d = latent_dim
         self.latent_dim, self.ff_size, self.num_layers, self.num_heads = d, ff_size, num_layers, num_heads
 
@@ -246,6 +247,7 @@ class FiLMTransformer(nn.Module):
             _lib.check(lib.a2p_ctx_create(C.byref(cfg), C.byref(ctx)), "a2p_ctx_create")
         self._ctx, self._ctx_key, self._weights_key, self._ctx_lib = ctx, key, None, lib
         self._env_sig = _lib.env_signature()      # the context read the A2P_* switches just now
+        self._hint_sent = 0
         self.invalidate_cond()
         return lib
 
@@ -329,6 +331,10 @@ class FiLMTransformer(nn.Module):
         _lib.require_gpu_tensor(x, "x")
         B, T = x.shape[0], x.shape[-1] if x.dim() == 4 else x.shape[1]
         lib = self._ensure_ctx(x.device, B)
+        hint = int(getattr(self, "global_batch_hint", 0) or 0)
+        if hint != self._hint_sent:                # sample_parallel: the size of the batch this call's block belongs to
+            _lib.check(lib.a2p_set_batch_hint(self._ctx, hint), "a2p_set_batch_hint")
+            self._hint_sent = hint
         sig = _lib.env_signature()
         if sig != self._env_sig:                   # an A2P_* switch changed since the context cached them (tests, A/B runs)
             _lib.check(lib.a2p_reload_env(self._ctx), "a2p_reload_env")

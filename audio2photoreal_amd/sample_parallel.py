@@ -87,6 +87,19 @@ def gather_samples(local: torch.Tensor, total: int, group=None) -> torch.Tensor:
     return torch.cat([bufs[r][: hi - lo] for r, (lo, hi) in enumerate(sizes)], dim=0)
 
 
+def _set_batch_hint(model, total: int):
+    """Tell the denoiser(s) behind `model` (a FiLMTransformer, possibly inside ClassifierFreeSampleModel-style wrappers) how large the
+    unsharded batch is: the HIP library picks its kernel family from that, not from the shard (include/a2p_hip.h a2p_set_batch_hint)."""
+    seen, out, m = set(), [], model
+    while m is not None and id(m) not in seen:
+        seen.add(id(m))
+        if hasattr(m, "global_batch_hint"):
+            m.global_batch_hint = total
+            out.append(m)
+        m = getattr(m, "model", None)
+    return out
+
+
 def sample_parallel(sample_fn: Callable, model, shape: Sequence[int], model_kwargs: Dict,
                     noise: Optional[torch.Tensor] = None, step_noise=None, group=None, **kw) -> torch.Tensor:
     """Run `sample_fn` (e.g. diffusion.ddim_sample_loop / p_sample_loop) on this rank's block of the
@@ -106,7 +119,12 @@ def sample_parallel(sample_fn: Callable, model, shape: Sequence[int], model_kwar
             local_step = [s[lo:hi].contiguous() for s in step_noise]
     if hi > lo:
         extra = {} if local_step is None else {"step_noise": local_step}
-        local = sample_fn(model, local_shape, noise=local_noise, model_kwargs=kwargs, **extra, **kw)
+        hinted = _set_batch_hint(model, total if world > 1 else 0)   # every shard takes the kernel family of the unsharded run
+        try:
+            local = sample_fn(model, local_shape, noise=local_noise, model_kwargs=kwargs, **extra, **kw)
+        finally:
+            for m in hinted:
+                m.global_batch_hint = 0
     else:
         ref = noise if noise is not None else torch.zeros(1)
         local = torch.zeros((0,) + tuple(shape[1:]), dtype=torch.float32, device=ref.device)

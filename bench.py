@@ -550,7 +550,8 @@ def main():
             cfg0 = Case("face", 1, 240, a.precision, dev, [0], respacing="ddim10", sampler="ddim")
             legs["cfg0"] = leg_record(cfg0, 50, 5, a.repeats)
             legs["cfg0"]["note"] = ("BASELINE configs[0] shape: face, batch 1, 240 frames, ddim10 step.  480 rows: below the chain kernels' "
-                                    "break-even, ~110 dependent launches of 4-12 us back to back (no gaps): launch-count bound, not compute bound")
+                                    "break-even; the small-forward GEMMs of csrc/kernels_small.h (LayerNorm fused into the A load, whole K "
+                                    "resident) make it ~80 dependent launches of 5-17 us: latency bound, not compute bound")
 
     if rank == 0:
         value = world * a.steps / dt

@@ -185,6 +185,12 @@ int a2p_attention(a2p_ctx* ctx, const float* q, const float* k, const float* v, 
 int a2p_kernel_timing(a2p_ctx* ctx, int32_t kind, int32_t enable);
 int a2p_kernel_time_ms(a2p_ctx* ctx, double* total_ms, int64_t* launches);
 
+/* ---- sample-parallel runs: which kernel family a forward takes (fused row-panel chains for large forwards, small-tile GEMMs for
+ * small ones) depends on its row count, and the families differ in operand rounding.  A rank that denoises a BLOCK of a larger
+ * batch names the size of the whole batch here, so that every shard takes the family the unsharded run takes and the gathered
+ * samples equal the single-process samples bit for bit (sample_parallel.py does this; 0 = no hint). */
+int a2p_set_batch_hint(a2p_ctx* ctx, int32_t global_batch);
+
 /* ---- run-time switches: the A2P_* environment variables that steer a forward (INTEGRATION.md "Environment switches") are read
  * when the context is created; a host that changes one afterwards calls this (the Python mirror does, model/diffusion.py). */
 int a2p_reload_env(a2p_ctx* ctx);

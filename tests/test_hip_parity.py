@@ -292,8 +292,10 @@ def test_chain_kernels_match_the_per_op_kernels_16bit(dev, golden, fmt, mt, prec
     monkeypatch.delenv("A2P_NO_CHAIN", raising=False)
     chained = cfg(x, times, y).cpu()
     monkeypatch.setenv("A2P_NO_CHAIN", "1")
+    monkeypatch.setenv("A2P_NO_SMALL", "1")            # the per-op kernels are the counterpart (960 rows would take the small-forward GEMMs)
     per_op = cfg(x, times, y).cpu()
     monkeypatch.delenv("A2P_NO_CHAIN")
+    monkeypatch.delenv("A2P_NO_SMALL")
     ref = golden[f"{fmt}/fwd_cfg"]
     e_pair, e_gold, e_old = rel_l2(chained, per_op), rel_l2(chained, ref), rel_l2(per_op, ref)
     record(f"chain_vs_perop/{precision}/{fmt}/MT{mt}", pair=e_pair, chain_vs_golden=e_gold, perop_vs_golden=e_old)
@@ -318,10 +320,14 @@ def test_chain_kernels_with_frame_counts_that_are_not_a_multiple_of_4(dev, fmt, 
     x = inp["x_T"].to(dev)
     cfg = ClassifierFreeSampleModel(model)
     monkeypatch.delenv("A2P_NO_CHAIN", raising=False)
+    monkeypatch.setenv("A2P_CHAIN_ROWS", "1")          # 1200 / 2100 rows: below the default chain threshold for the face model
     chained = cfg(x, times, y).cpu()
     monkeypatch.setenv("A2P_NO_CHAIN", "1")
+    monkeypatch.setenv("A2P_NO_SMALL", "1")            # ... and the per-op kernels, not the small-forward GEMMs, as the counterpart
     per_op = cfg(x, times, y).cpu()
     monkeypatch.delenv("A2P_NO_CHAIN")
+    monkeypatch.delenv("A2P_NO_SMALL")
+    monkeypatch.delenv("A2P_CHAIN_ROWS")
     den = O.OracleDenoiser(synthetic_state_dict(spec, SEED), fmt, spec.num_layers, spec.num_heads, torch.float32)
     ref = den.forward_cfg(inp["x_T"][:2], times[:2].cpu(), inp["cond_embed"][:2], torch.full((2,), scale),
                           inp.get("keyframes", [None])[:2] if spec.is_pose else None, inp["mask"][:2] if spec.is_pose else None)
