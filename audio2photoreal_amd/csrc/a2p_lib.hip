@@ -143,6 +143,10 @@ struct A2POpts {
   int no_side_stream = 0;   // A2P_NO_SIDE_STREAM=1: time path on the main stream
   int side_early_join = 0;  // A2P_SIDE_EARLY_JOIN=1: side stream without overlap (diagnostic)
   int no_shared_half = 0;   // A2P_NO_SHARED_HALF=1: layer 0 computed for both guidance halves
+  int no_ksplit = 0;        // A2P_NO_KSPLIT=1: small forwards use attn_kernel instead of the key-split attention (A/B)
+  int ksplit_nw = 0;        // A2P_KSPLIT_NW=4|8: waves of the key-split attention
+  int ksplit_qt = 0;        // A2P_KSPLIT_QT=1|2: 16-query tiles per wave of the key-split attention
+  int force_ksplit = 0;     // A2P_ATTN_KSPLIT=1: every 16-bit attention launch takes the key-split kernel (tests)
   int no_small = 0;         // A2P_NO_SMALL=1: per-op kernels for forwards below 960 rows instead of kernels_small.h
   int chain_rows = 1280;    // A2P_CHAIN_ROWS=n: forwards of at least n rows take the chain kernels (measured crossover against the small-forward
                             // GEMMs of kernels_small.h: 1192 vs 1002 steps/s at 960 rows, 804 vs 1018 at 1920)
@@ -155,6 +159,7 @@ static void load_opts(A2POpts& o) {
   o.chain_no_mix = flag("A2P_CHAIN_NO_MIX"); o.tune_verbose = flag("A2P_TUNE_VERBOSE"); o.side_join = num("A2P_SIDE_JOIN", 3);
   o.x_rowmajor = flag("A2P_CHAIN_X_ROWMAJOR"); o.no_side_stream = flag("A2P_NO_SIDE_STREAM");
   o.side_early_join = flag("A2P_SIDE_EARLY_JOIN"); o.no_shared_half = flag("A2P_NO_SHARED_HALF");
+  o.no_ksplit = flag("A2P_NO_KSPLIT"); o.force_ksplit = flag("A2P_ATTN_KSPLIT"); o.ksplit_nw = num("A2P_KSPLIT_NW", 0); o.ksplit_qt = num("A2P_KSPLIT_QT", 0);
   o.no_small = flag("A2P_NO_SMALL"); o.chain_rows = num("A2P_CHAIN_ROWS", 1280);
 }
 
@@ -320,6 +325,29 @@ static int launch_skinny(const float* A, int64_t lda, const float* W, int64_t ld
   return 0;
 }
 
+struct SkinnyArgs {
+  const float* A; int64_t lda; const float* W; int64_t ldw; const float* bias; float* out; int64_t ldo; int M, N, K, act;
+};
+// three independent skinny GEMMs of at most 64 rows each in one launch (kernels_gemm.h skinny_gemm_group_kernel)
+static int launch_skinny3(const SkinnyArgs (&a)[3], hipStream_t s) {
+  bool one = true;
+  for (const SkinnyArgs& q : a) one = one && q.M <= 64 && q.K % 64 == 0 && q.N % 16 == 0;
+  if (!one) {
+    for (const SkinnyArgs& q : a) CHK(launch_skinny(q.A, q.lda, q.W, q.ldw, q.bias, q.out, q.ldo, q.M, q.N, q.K, q.act, s));
+    return 0;
+  }
+  SkinnyG3 g;
+  for (int i = 0; i < 3; ++i) {
+    SkinnyP& p = g.p[i];
+    p.A = a[i].A; p.W = a[i].W; p.bias = a[i].bias; p.out = a[i].out; p.lda = a[i].lda; p.ldw = a[i].ldw; p.ldo = a[i].ldo;
+    p.M = a[i].M; p.N = a[i].N; p.K = a[i].K; p.act = a[i].act;
+  }
+  g.nb0 = a[0].N / 16; g.nb1 = g.nb0 + a[1].N / 16;
+  skinny_gemm_group_kernel<<<g.nb1 + a[2].N / 16, 256, 0, s>>>(g);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
 static int launch_ln_rope(a2p_ctx* c, bool as_f32, const float* x, int64_t ldx, const float* gamma, const float* beta,
                           void* out_n, void* out_r, int64_t ldo, int rows, int rows_per_seq, int pos_off, hipStream_t s) {
   LnRopeP p;
@@ -339,8 +367,32 @@ static int launch_ln_rope(a2p_ctx* c, bool as_f32, const float* x, int64_t ldx, 
   return 0;
 }
 
-static int launch_attn(a2p_ctx* c, const AttnP& p0, int nseq, int kind, hipStream_t s) {
+static int launch_attn(a2p_ctx* c, const AttnP& p0, int nseq, int kind, hipStream_t s, bool ksplit = false) {
   AttnP p = p0;
+  // small forwards (decoder_layer_small): the waves of a workgroup split the keys instead of the queries (kernels_attn.h)
+  if ((ksplit || c->opt.force_ksplit) && c->bf16 && !c->opt.no_ksplit && (c->DH == 64 || c->DH == 32) && p.ldvt % 8 == 0 && p.S_tail <= 2) {
+    // waves x query tiles per wave: A2P_KSPLIT_NW / A2P_KSPLIT_QT (experiment switches)
+    const int ntiles = (p.S_main + p.S_tail + 63) / 64;
+    // measured at 2 x 240 frames (profiles/r03_ksplit_ab.txt): 16 queries per wave beat 32 (the tile arithmetic of a lone wave per
+    // SIMD is serial), 8 waves beat 4 once a 4-wave workgroup would walk more than two tiles per wave (800 keys = 13 tiles)
+    const bool w8 = c->opt.ksplit_nw == 8 || (c->opt.ksplit_nw == 0 && ntiles > 8);
+    const int qt = c->opt.ksplit_qt == 2 ? 2 : 1;
+    p.nq = (p.Tq + 16 * qt - 1) / (16 * qt); p.nheads = c->H; p.nseq = nseq; p.xcd_remap = 0;
+    dim3 grid(p.nq * c->H * nseq);
+    KernelTimer kt(c, kind);
+#define A2P_KS(DH_) \
+    do { \
+      if (w8 && qt == 1) A2P_LAUNCH(kt, (attn_ksplit_kernel<DH_, 8, 1>), grid, 512, s, p); \
+      else if (w8) A2P_LAUNCH(kt, (attn_ksplit_kernel<DH_, 8, 2>), grid, 512, s, p); \
+      else if (qt == 1) A2P_LAUNCH(kt, (attn_ksplit_kernel<DH_, 4, 1>), grid, 256, s, p); \
+      else A2P_LAUNCH(kt, (attn_ksplit_kernel<DH_, 4, 2>), grid, 256, s, p); \
+    } while (0)
+    if (c->DH == 64) A2P_KS(64);
+    else A2P_KS(32);
+#undef A2P_KS
+    HIPCHK(hipGetLastError());
+    return 0;
+  }
   // A2P_ATTN_WAVES=2 (16-bit modes): 2-wave workgroups of 64 queries -- a perfectly even 5 workgroups per CU at B=8, but every K/V
   // tile then feeds half as many queries: measured 97 vs 70 us for the cross attention (experiment switch, kernels_attn.h NWV)
   static const bool two = getenv("A2P_ATTN_WAVES") && atoi(getenv("A2P_ATTN_WAVES")) == 2;

@@ -10,6 +10,7 @@ struct CrossKV {
   const void* VT = nullptr;
   int64_t k_slot_stride = 0, ldk = 0, vt_slot_stride = 0, ldvt = 0;
   const int* slots = nullptr;
+  int slot_rule = 0, slot_b = 0;   // the table's contents as a formula (AttnP::slot_rule): saves the kernels a dependent load
   int S_main = 0;
   const float* ktail = nullptr;
   const float* vtail = nullptr;
@@ -79,6 +80,7 @@ static int cross_attn_block(a2p_ctx* c, const std::string& p, const std::string&
   a.O = c->ao.p; a.o_seq_stride = (int64_t)T * d; a.ldo = d;
   a.ktail = kv.ktail; a.vtail = kv.vtail; a.tail_sample_stride = kv.tail_sample_stride; a.tail_row_stride = kv.tail_row_stride;
   a.kv_slot = kv.slots; a.tail_mod = kv.tail_mod; a.Tq = T; a.S_main = kv.S_main; a.S_tail = kv.S_tail;
+  a.slot_rule = kv.slot_rule; a.slot_b = kv.slot_b;
   a.kv_stream = kv.slots && !c->opt.kv_cached ? 1 : 0;
   a.scale_log2e = 1.4426950408889634f / sqrtf((float)c->DH);
   CHK(launch_attn(c, a, N, A2P_KERNEL_ATTN_CROSS, s));
@@ -433,7 +435,7 @@ static int launch_chain(a2p_ctx* c, int mode, const ChainP& p, hipStream_t s) {
   return 0;
 }
 
-static int launch_self_attention(a2p_ctx* c, int N, int T, hipStream_t s) {
+static int launch_self_attention(a2p_ctx* c, int N, int T, hipStream_t s, bool ksplit = false) {
   const int d = c->d, Tld = rup(T, 64);
   AttnP a;
   memset(&a, 0, sizeof(a));
@@ -443,10 +445,10 @@ static int launch_self_attention(a2p_ctx* c, int N, int T, hipStream_t s) {
   a.O = c->ao.p; a.o_seq_stride = (int64_t)T * d; a.ldo = d;
   a.tail_mod = 1; a.Tq = T; a.S_main = T; a.S_tail = 0;
   a.scale_log2e = 1.4426950408889634f / sqrtf((float)c->DH);
-  return launch_attn(c, a, N, A2P_KERNEL_ATTN_SELF, s);
+  return launch_attn(c, a, N, A2P_KERNEL_ATTN_SELF, s, ksplit);
 }
 
-static int launch_cross_attention(a2p_ctx* c, int N, int T, const CrossKV& kv, hipStream_t s) {
+static int launch_cross_attention(a2p_ctx* c, int N, int T, const CrossKV& kv, hipStream_t s, bool ksplit = false) {
   const int d = c->d;
   AttnP a;
   memset(&a, 0, sizeof(a));
@@ -456,9 +458,10 @@ static int launch_cross_attention(a2p_ctx* c, int N, int T, const CrossKV& kv, h
   a.O = c->ao.p; a.o_seq_stride = (int64_t)T * d; a.ldo = d;
   a.ktail = kv.ktail; a.vtail = kv.vtail; a.tail_sample_stride = kv.tail_sample_stride; a.tail_row_stride = kv.tail_row_stride;
   a.kv_slot = kv.slots; a.tail_mod = kv.tail_mod; a.Tq = T; a.S_main = kv.S_main; a.S_tail = kv.S_tail;
+  a.slot_rule = kv.slot_rule; a.slot_b = kv.slot_b;
   a.kv_stream = kv.slots && !c->opt.kv_cached ? 1 : 0;
   a.scale_log2e = 1.4426950408889634f / sqrtf((float)c->DH);
-  return launch_attn(c, a, N, A2P_KERNEL_ATTN_CROSS, s);
+  return launch_attn(c, a, N, A2P_KERNEL_ATTN_CROSS, s, ksplit);
 }
 
 // FiLMTransformerDecoderLayer.forward as PRE? | self attention | MID | cross attention | (MID | cross attention 2) | POST
@@ -572,7 +575,7 @@ static int decoder_layer_small(a2p_ctx* c, int l, int N, int T, const CrossKV& k
     p.out_t = reinterpret_cast<h16_t*>(c->vt.p); p.ld_t = Tld; p.t_seq_stride = (int64_t)d * Tld;
     CHK((launch_small<512, 64, 1, SMALL_STORE>(c, p, s)));
   }
-  CHK(launch_self_attention(c, N, T, s));
+  CHK(launch_self_attention(c, N, T, s, true));
   if (film_ready) HIPCHK(hipStreamWaitEvent(s, film_ready, 0));   // FiLM / time-token K,V of this step come from the side stream
   {  // out_proj + FiLM + residual
     SmallP p = base;
@@ -588,7 +591,7 @@ static int decoder_layer_small(a2p_ctx* c, int l, int N, int T, const CrossKV& k
     p.N = d; p.out = reinterpret_cast<h16_t*>(c->qk.p); p.ldo = d; p.n_store = d;
     CHK((launch_small<512, 64, 1, SMALL_STORE>(c, p, s)));
   }
-  CHK(launch_cross_attention(c, N, T, kv, s));
+  CHK(launch_cross_attention(c, N, T, kv, s, true));
   {
     SmallP p = base;
     p.a = reinterpret_cast<const h16_t*>(c->ao.p); p.lda = d; p.W = reinterpret_cast<const h16_t*>(c->wt.at(pf + "multihead_attn.out_proj.weight").p);
@@ -701,9 +704,12 @@ static int time_path(a2p_ctx* c, const int64_t* t_orig, int N, const int* slots,
   tp.tok_n = c->tokn.f(); tp.tok_r = c->tokr.f(); tp.B = B; tp.nseq = N; tp.d = d; tp.pos0 = c->pS0;
   if (d == 512) tpath_post_kernel<8><<<N + B, 256, 0, s>>>(tp);
   else tpath_post_kernel<4><<<N + B, 256, 0, s>>>(tp);
-  CHK(launch_skinny(c->mt.f(), d, c->film_w.f(), d, c->film_b.f(), c->film.f(), (int64_t)L * F * 2 * d, N, L * F * 2 * d, d, ACT_NONE, s));
-  CHK(launch_skinny(c->tokr.f(), d, c->cak_w32.f(), d, c->cak_b.f(), c->ktail.f(), (int64_t)L * d, 2 * B, L * d, d, ACT_NONE, s));
-  CHK(launch_skinny(c->tokn.f(), d, c->cav_w32.f(), d, c->cav_b.f(), c->vtail.f(), (int64_t)L * d, 2 * B, L * d, d, ACT_NONE, s));
+  // FiLM generators of every layer | K rows of the time tokens | V rows: independent of each other, one launch
+  const SkinnyArgs g3[3] = {
+      {c->mt.f(), d, c->film_w.f(), d, c->film_b.f(), c->film.f(), (int64_t)L * F * 2 * d, N, L * F * 2 * d, d, ACT_NONE},
+      {c->tokr.f(), d, c->cak_w32.f(), d, c->cak_b.f(), c->ktail.f(), (int64_t)L * d, 2 * B, L * d, d, ACT_NONE},
+      {c->tokn.f(), d, c->cav_w32.f(), d, c->cav_b.f(), c->vtail.f(), (int64_t)L * d, 2 * B, L * d, d, ACT_NONE}};
+  CHK(launch_skinny3(g3, s));
   HIPCHK(hipGetLastError());
   return 0;
 }
@@ -795,8 +801,13 @@ static int run_forward(a2p_ctx* c, const float* x_in, const int64_t* t_orig, int
     GemmP p = gemm_base(c->inpack.p, X * c->Cpad, c->wt.at("input_projection.weight").p, X * c->Cpad, W32(c, "input_projection.bias"),
                         shared_half ? c->hff.p : c->x.p, d, B * T, d, X * c->Cpad);
     p.out_f32 = c->bf16 ? 1 : 0;   // gemm_kernel<float> stores fp32 either way; the flag only selects a 16-bit kernel instance
+    // guidance without the shared layer-0 half (per-op and small-forward paths): the second half's copy of the rows is written by
+    // the same epilogue (16-bit modes: the fp32-output store) instead of a copy kernel behind the GEMM
+    const bool dup = N == 2 * B && !shared_half;
+    const bool dup_in_epilogue = dup && c->bf16;
+    if (dup_in_epilogue) p.dup_off = (int64_t)B * T * d;
     CHK(launch_gemm(c, p, s));
-    if (N == 2 * B && !shared_half) {   // chain path under guidance: layer 0 reads the one copy for both halves (decoder_layer_chain)
+    if (dup && !dup_in_epilogue) {
       const int64_t n4 = (int64_t)B * T * d / 4;
       dup_rows_kernel<<<(int)((n4 + 255) / 256), 256, 0, s>>>(reinterpret_cast<const float4*>(c->x.p),
                                                              reinterpret_cast<float4*>(c->x.f() + (size_t)B * T * d), n4);
@@ -815,12 +826,14 @@ static int run_forward(a2p_ctx* c, const float* x_in, const int64_t* t_orig, int
     kv.K = c->offT(c->kc, (int64_t)l * d); kv.k_slot_stride = (int64_t)c->Sld * L * d; kv.ldk = (int64_t)L * d;
     kv.VT = c->offT(c->vtc, (int64_t)l * d * c->Sld); kv.vt_slot_stride = (int64_t)L * d * c->Sld; kv.ldvt = c->Sld;
     kv.slots = slots; kv.S_main = c->pS0;
+    kv.slot_rule = pass == A2P_PASS_CFG ? 3 : (pass == A2P_PASS_COND ? 1 : 2); kv.slot_b = B;   // slot_tables_kernel's contents
     kv.ktail = c->ktail.f() + (size_t)l * d; kv.vtail = c->vtail.f() + (size_t)l * d;
     kv.tail_row_stride = (int64_t)L * d; kv.tail_sample_stride = (int64_t)2 * L * d; kv.S_tail = 2; kv.tail_mod = B;
     if (c->pose) {
       kv2.K = c->offT(c->k2c, (int64_t)l * d); kv2.k_slot_stride = (int64_t)64 * L * d; kv2.ldk = (int64_t)L * d;
       kv2.VT = c->offT(c->vt2c, (int64_t)l * d * 64); kv2.vt_slot_stride = (int64_t)L * d * 64; kv2.ldvt = 64;
       kv2.slots = slots; kv2.S_main = c->pK; kv2.S_tail = 0; kv2.tail_mod = 1;
+      kv2.slot_rule = kv.slot_rule; kv2.slot_b = B;
     }
     FilmRef fr;
     fr.base = c->film.f() + (size_t)l * F * 2 * d;

@@ -35,6 +35,8 @@ struct AttnP {
   const float* vtail;
   int64_t tail_sample_stride, tail_row_stride;
   const int* kv_slot;  // per-sequence slot index, NULL -> slot = seq
+  int slot_rule, slot_b;  // != 0: the table's contents as a formula (no dependent load in front of the first K/V request):
+                          // 1 = 1 + seq (conditional pass), 2 = 0 (unconditional), 3 = seq < slot_b ? 1 + seq : 0 (guidance: both)
   int tail_mod;        // sample = seq % tail_mod
   int kv_stream;       // 1: K/V slots other than 0 are read once per step (cached audio K/V): DMA them non-temporal so that
                        // they do not evict the chain kernels' weight streams from L2 / MALL
@@ -46,6 +48,13 @@ struct AttnP {
   // through ONE L2 instead of five (T = 600: 5 query blocks per pair, each of which used to pull the pair's K/V from HBM)
   int nq, nheads, nseq, xcd_remap;
 };
+
+__device__ __forceinline__ int attn_slot(const AttnP& p, int seq) {
+  if (p.slot_rule == 1) return 1 + seq;
+  if (p.slot_rule == 2) return 0;
+  if (p.slot_rule == 3) return seq < p.slot_b ? 1 + seq : 0;
+  return p.kv_slot ? p.kv_slot[seq] : seq;
+}
 
 // LDS tile geometry: K tile [64 keys][DH], V^T tile [DH][64 keys]
 template <typename T, int DH>
@@ -140,7 +149,7 @@ __global__ __launch_bounds__(64 * NWV, 3) void attn_kernel(AttnP p) {
   // waves of the last query block whose whole range lies past Tq (T=600: 1 of 20 waves) still take part in the tile DMA and
   // the barriers but skip the MFMA / softmax work: their issue slots go to the co-resident waves
   const bool wave_active = __builtin_amdgcn_readfirstlane(q0) < p.Tq;
-  const int slot = p.kv_slot ? p.kv_slot[seq] : seq;
+  const int slot = attn_slot(p, seq);
   const bool kv_nt = p.kv_stream && slot != 0;  // slot 0 (null conditioning) is shared by the whole unconditional half: keep it cached
   const int S_total = p.S_main + p.S_tail;
   const int ntiles = (S_total + KV - 1) / KV;
@@ -462,5 +471,297 @@ __global__ __launch_bounds__(64 * NWV, 3) void attn_kernel(AttnP p) {
         *reinterpret_cast<float4*>(Op + dv * 16 + g * 4) = make_float4(v[0] * inv, v[1] * inv, v[2] * inv, v[3] * inv);
       }
     }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Key-split attention for small forwards (16-bit modes; kernels_small.h's regime: BASELINE configs[0] is 2 sequences x 240
+// frames).  attn_kernel gives such a forward 32 workgroups that each walk their 4-10 key tiles one after the other -- a serial
+// chain of (tile load, QK^T, softmax, PV) round trips on an eighth of the chip, 12 us per launch.  Here a workgroup owns 32
+// queries of one (sequence, head) and its four waves split the KEYS: wave w takes tiles w, w + 4, ... (one tile each at 240
+// keys), with the fragments read straight from global memory into registers (no LDS ring, no barriers: nothing is shared between
+// the waves but the queries), and the four partial (max, sum, O) states are merged through LDS at the end -- the usual
+// log-sum-exp combine.  4x the workgroups, a quarter of the dependent tile steps.
+// Same per-tile arithmetic as attn_kernel (S^T = K Q^T, lane-local online softmax, O^T += V^T P^T, fragment / key mapping of
+// AttnLds::krow); the summation ORDER over keys differs (per-wave partial sums), so results agree with attn_kernel to fp32
+// rounding of the softmax sums, not bit for bit.  Host contract: ldvt % 8 == 0 (16-byte V^T fragment loads), S_tail <= 2; any S_main.
+// ------------------------------------------------------------------------------------------------
+template <int DH, int NW = 4, int QT = 2>
+__global__ __launch_bounds__(64 * NW) void attn_ksplit_kernel(AttnP p) {
+  using T = h16_t;
+  using P = Prec<T>;
+  using L = AttnLds<T, DH>;
+  constexpr int KV = 64;
+  constexpr int KC = DH / P::KCH, DVT = DH / 16;
+  typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+  __shared__ __attribute__((aligned(16))) float so[NW][QT][DVT][64][4];
+  __shared__ float sm[NW][QT][16], sl[NW][QT][16];
+
+  const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l15 = lane & 15, g = lane >> 4;
+  const int b = blockIdx.x;
+  const int qb = b % p.nq, head = (b / p.nq) % p.nheads, seq = b / (p.nq * p.nheads);
+  const int q0 = qb * (QT * 16);
+  const int slot = attn_slot(p, seq);
+  const int S_total = p.S_main + p.S_tail;
+  const int ntiles = (S_total + KV - 1) / KV;
+
+  const T* Qb = reinterpret_cast<const T*>(p.Q) + (int64_t)seq * p.q_seq_stride + head * DH;
+  const T* Kb = reinterpret_cast<const T*>(p.K) + (int64_t)slot * p.k_slot_stride + head * DH;
+  const T* Vb = reinterpret_cast<const T*>(p.VT) + (int64_t)slot * p.vt_slot_stride + (int64_t)head * DH * p.ldvt;
+  // time-token rows (at most two, host contract); with none, the K base serves as a harmless in-bounds address for the loads every
+  // lane issues on the straight-line path below
+  const int n_tail = p.S_tail;
+  const int64_t tail_off = (int64_t)(seq % (p.tail_mod > 0 ? p.tail_mod : 1)) * p.tail_sample_stride + head * DH;
+  const float* ksrc = n_tail > 0 ? p.ktail + tail_off : reinterpret_cast<const float*>(Kb);
+  const float* vsrc = n_tail > 0 ? p.vtail + tail_off : reinterpret_cast<const float*>(Kb);
+  const int64_t trs = n_tail > 0 ? p.tail_row_stride : 0;
+
+  h16x8 qf[QT][KC];
+#pragma unroll
+  for (int qt = 0; qt < QT; ++qt) {
+    int q = q0 + qt * 16 + l15;
+    if (q >= p.Tq) q = p.Tq - 1;
+#pragma unroll
+    for (int kc = 0; kc < KC; ++kc) qf[qt][kc] = P::load(Qb + (int64_t)q * p.ldq + kc * P::KCH + g * P::EPL);
+  }
+  f32x4 o[QT][DVT];
+  float mrun[QT], lsum[QT];
+#pragma unroll
+  for (int qt = 0; qt < QT; ++qt) {
+    mrun[qt] = -INFINITY;
+    lsum[qt] = 0.f;
+#pragma unroll
+    for (int dv = 0; dv < DVT; ++dv) o[qt][dv] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+
+  // fragments of a tile that lies wholly inside the main cache: plain 16-byte loads
+  auto load_main = [&](int kv0, h16x8(&kf)[4][KC], h16x8(&vf)[2][DVT]) __attribute__((always_inline)) {
+#pragma unroll
+    for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+      for (int kc = 0; kc < KC; ++kc)
+        kf[kt][kc] = *reinterpret_cast<const h16x8*>(Kb + (int64_t)(kv0 + L::krow(kt, l15)) * p.ldk + kc * P::KCH + g * P::EPL);
+#pragma unroll
+    for (int c = 0; c < 2; ++c)
+#pragma unroll
+      for (int dv = 0; dv < DVT; ++dv)
+        vf[c][dv] = *reinterpret_cast<const h16x8*>(Vb + (int64_t)(dv * 16 + l15) * p.ldvt + kv0 + c * 32 + g * 8);
+  };
+  // the tile(s) with the end of the main cache, the time tokens and the padding -- STRAIGHT-LINE code: this wave is the one the
+  // merge waits for, and per-lane branches around element loads (or a uniform branch per fragment: hipcc drains vmcnt at each)
+  // turn its one memory round trip into a dozen.  Every lane issues every load: main-cache fragments from a row / column clamped
+  // into the cache (masked keys: finite real data for K; V^T's padding columns are unwritten memory and are bit-masked to zero),
+  // the time-token rows from a clamped token index, and selects put them in place.
+  auto load_edge = [&](int kv0, h16x8(&kf)[4][KC], h16x8(&vf)[2][DVT]) __attribute__((always_inline)) {
+    // a lane's four key rows (one per S^T tile) lie 4 or more keys apart and the time tokens are adjacent keys: at most ONE of the
+    // four is a time-token row, so one candidate row is loaded per lane (not one per tile: 48 registers less)
+    int jsel = 0, ktsel = -1;
+#pragma unroll
+    for (int kt = 0; kt < 4; ++kt) {
+      const int kr = kv0 + L::krow(kt, l15);
+      const int krc = kr < p.S_main ? kr : p.S_main - 1;
+      const int j = kr - p.S_main;
+      const bool is_tail = j >= 0 && j < n_tail;
+      jsel = is_tail ? j : jsel;
+      ktsel = is_tail ? kt : ktsel;
+#pragma unroll
+      for (int kc = 0; kc < KC; ++kc)
+        kf[kt][kc] = *reinterpret_cast<const h16x8*>(Kb + (int64_t)krc * p.ldk + kc * P::KCH + g * P::EPL);
+    }
+    float4 kt0[KC], kt1[KC];
+#pragma unroll
+    for (int kc = 0; kc < KC; ++kc) {
+      const float4* tp = reinterpret_cast<const float4*>(ksrc + jsel * trs + kc * P::KCH + g * P::EPL);
+      kt0[kc] = tp[0];
+      kt1[kc] = tp[1];
+    }
+    u32x4 vm[2][DVT];
+    float tv[2][DVT];
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+      const int kk = kv0 + c * 32 + g * 8;
+      const int kkc = kk <= (int)p.ldvt - 8 ? kk : (int)p.ldvt - 8;
+#pragma unroll
+      for (int dv = 0; dv < DVT; ++dv) vm[c][dv] = *reinterpret_cast<const u32x4*>(Vb + (int64_t)(dv * 16 + l15) * p.ldvt + kkc);
+    }
+#pragma unroll
+    for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+      for (int dv = 0; dv < DVT; ++dv) tv[jj][dv] = vsrc[(jj < n_tail ? jj : 0) * trs + dv * 16 + l15];
+#pragma unroll
+    for (int kc = 0; kc < KC; ++kc) {
+      const float4 t0 = kt0[kc], t1 = kt1[kc];
+      const h16x8 tf = {from_f32<T>(t0.x), from_f32<T>(t0.y), from_f32<T>(t0.z), from_f32<T>(t0.w),
+                        from_f32<T>(t1.x), from_f32<T>(t1.y), from_f32<T>(t1.z), from_f32<T>(t1.w)};
+      const u32x4 a = __builtin_bit_cast(u32x4, tf);
+#pragma unroll
+      for (int kt = 0; kt < 4; ++kt) {
+        const u32x4 m = __builtin_bit_cast(u32x4, kf[kt][kc]);
+        u32x4 r;
+#pragma unroll
+        for (int d2 = 0; d2 < 4; ++d2) r[d2] = kt == ktsel ? a[d2] : m[d2];
+        kf[kt][kc] = __builtin_bit_cast(h16x8, r);
+      }
+    }
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+      const int kk = kv0 + c * 32 + g * 8;
+      const int nvalid = p.S_main - kk;                  // elements [0, nvalid) of the group are main-cache keys
+      const int e0 = n_tail > 0 ? p.S_main - kk : -1, e1 = n_tail > 1 ? p.S_main + 1 - kk : -1;   // where the time tokens go
+#pragma unroll
+      for (int dv = 0; dv < DVT; ++dv) {
+        const unsigned b0 = (unsigned)__builtin_bit_cast(unsigned short, from_f32<T>(tv[0][dv]));
+        const unsigned b1 = (unsigned)__builtin_bit_cast(unsigned short, from_f32<T>(tv[1][dv]));
+        u32x4 f = vm[c][dv];
+#pragma unroll
+        for (int d2 = 0; d2 < 4; ++d2) {
+          const unsigned msk = nvalid >= 2 * d2 + 2 ? 0xffffffffu : (nvalid == 2 * d2 + 1 ? 0x0000ffffu : 0u);
+          unsigned w = f[d2] & msk;
+          w = e0 == 2 * d2 ? ((w & 0xffff0000u) | b0) : w;
+          w = e0 == 2 * d2 + 1 ? ((w & 0x0000ffffu) | (b0 << 16)) : w;
+          w = e1 == 2 * d2 ? ((w & 0xffff0000u) | b1) : w;
+          w = e1 == 2 * d2 + 1 ? ((w & 0x0000ffffu) | (b1 << 16)) : w;
+          f[d2] = w;
+        }
+        vf[c][dv] = __builtin_bit_cast(h16x8, f);
+      }
+    }
+  };
+  // one 64-key tile: S^T = K Q^T, lane-local online softmax, O^T += V^T P^T (attn_kernel's arithmetic)
+  auto consume = [&](int kv0, const h16x8(&kf)[4][KC], const h16x8(&vf)[2][DVT]) __attribute__((always_inline)) {
+    f32x4 s[4][QT];
+#pragma unroll
+    for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+      for (int qt = 0; qt < QT; ++qt) s[kt][qt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int kc = 0; kc < KC; ++kc)
+#pragma unroll
+      for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+        for (int qt = 0; qt < QT; ++qt) s[kt][qt] = P::mfma(kf[kt][kc], qf[qt][kc], s[kt][qt]);
+    if (kv0 + KV > S_total) {
+#pragma unroll
+      for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const bool dead = kv0 + L::krow(kt, g * 4 + r) >= S_total;
+#pragma unroll
+          for (int qt = 0; qt < QT; ++qt) s[kt][qt][r] = dead ? -INFINITY : s[kt][qt][r];
+        }
+    }
+#pragma unroll
+    for (int qt = 0; qt < QT; ++qt) {
+      float mx = s[0][qt][0];
+#pragma unroll
+      for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) mx = fmaxf(mx, s[kt][qt][r]);
+      mx = attn_rowgroup_max(mx);
+      const float mnew = fmaxf(mrun[qt], mx * p.scale_log2e);
+      const float alpha = __builtin_amdgcn_exp2f(mrun[qt] - mnew);
+      mrun[qt] = mnew;
+      float ps = 0.f;
+#pragma unroll
+      for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float v = __builtin_amdgcn_exp2f(fmaf(s[kt][qt][r], p.scale_log2e, -mnew));
+          ps += v;
+          s[kt][qt][r] = v;
+        }
+      lsum[qt] = lsum[qt] * alpha + ps;
+#pragma unroll
+      for (int dv = 0; dv < DVT; ++dv)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) o[qt][dv][r] *= alpha;
+    }
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+      h16x8 pf[QT];
+#pragma unroll
+      for (int qt = 0; qt < QT; ++qt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          pf[qt][r] = (h16_t)s[2 * c][qt][r];
+          pf[qt][4 + r] = (h16_t)s[2 * c + 1][qt][r];
+        }
+#pragma unroll
+      for (int dv = 0; dv < DVT; ++dv)
+#pragma unroll
+        for (int qt = 0; qt < QT; ++qt) o[qt][dv] = P::mfma(vf[c][dv], pf[qt], o[qt][dv]);
+    }
+  };
+
+  // wave w: tiles w, w + NW, ...; the NEXT tile's fragments are requested before the current tile is consumed (the loop is a chain
+  // of memory round trips otherwise: ~2 us per tile against ~0.7 us of arithmetic).  Each arm of the (wave-uniform) branch holds its
+  // loads AND the consume, so that the vmcnt in front of the MFMAs is exact for that arm instead of the join's conservative 0.
+  if (wid < ntiles) {
+    h16x8 kf[4][KC], vf[2][DVT];
+    if (wid * KV + KV <= p.S_main) load_main(wid * KV, kf, vf);
+    else load_edge(wid * KV, kf, vf);
+    for (int tile = wid; tile < ntiles; tile += NW) {
+      const int kv0 = tile * KV, nxt = tile + NW;
+      if (nxt >= ntiles) {   // last tile of this wave: nothing to request
+        consume(kv0, kf, vf);
+        break;
+      }
+      h16x8 kn[4][KC], vn[2][DVT];
+      if (nxt * KV + KV <= p.S_main) {
+        load_main(nxt * KV, kn, vn);
+        consume(kv0, kf, vf);
+      } else {
+        load_edge(nxt * KV, kn, vn);
+        consume(kv0, kf, vf);
+      }
+#pragma unroll
+      for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+        for (int kc = 0; kc < KC; ++kc) kf[kt][kc] = kn[kt][kc];
+#pragma unroll
+      for (int c = 0; c < 2; ++c)
+#pragma unroll
+        for (int dv = 0; dv < DVT; ++dv) vf[c][dv] = vn[c][dv];
+    }
+  }
+
+  // ---- merge the NW key ranges: wave w normalises and stores the (query tile, head-dim tile) pairs w, w + NW, ... ----
+#pragma unroll
+  for (int qt = 0; qt < QT; ++qt) {
+    float l = lsum[qt];
+    l += __shfl_xor(l, 16, 64);
+    l += __shfl_xor(l, 32, 64);
+    if (g == 0) {
+      sm[wid][qt][l15] = mrun[qt];
+      sl[wid][qt][l15] = l;
+    }
+#pragma unroll
+    for (int dv = 0; dv < DVT; ++dv) *reinterpret_cast<f32x4*>(&so[wid][qt][dv][lane][0]) = o[qt][dv];
+  }
+  __syncthreads();
+  T* Ob = reinterpret_cast<T*>(p.O) + (int64_t)seq * p.o_seq_stride + head * DH;
+  for (int pr = wid; pr < QT * DVT; pr += NW) {
+    const int qt = pr / DVT, dv = pr % DVT;
+    float m[NW], mall = -INFINITY;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) {
+      m[w] = sm[w][qt][l15];
+      mall = fmaxf(mall, m[w]);
+    }
+    float lall = 0.f;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int w = 0; w < NW; ++w) {
+      const float a = __builtin_amdgcn_exp2f(m[w] - mall);   // a wave without tiles: m = -inf -> weight 0
+      lall += a * sl[w][qt][l15];
+      const f32x4 ow = *reinterpret_cast<const f32x4*>(&so[w][qt][dv][lane][0]);
+      acc += ow * a;
+    }
+    const float inv = 1.0f / lall;
+    const int q = q0 + qt * 16 + l15;
+    if (q < p.Tq)
+      *reinterpret_cast<h16x4*>(Ob + (int64_t)q * p.ldo + dv * 16 + g * 4) =
+          h16x4{(h16_t)(acc[0] * inv), (h16_t)(acc[1] * inv), (h16_t)(acc[2] * inv), (h16_t)(acc[3] * inv)};
   }
 }

@@ -41,6 +41,8 @@ struct GemmP {
   // split_third elements apart (the A' operand of the next split GEMM); skip_lo > 0 -> the skip operand is such a row too and its
   // value is skip[n] + skip[skip_lo + n]
   int split_third, skip_lo;
+  int64_t dup_off;   // fp32 EPI_STORE: != 0 -> every value is stored a second time dup_off elements further (both guidance halves of the
+                     // input projection in one launch instead of a copy kernel behind it)
 };
 
 template <int ACT, bool FAST>
@@ -105,7 +107,9 @@ __device__ __forceinline__ void gemm_epilogue(const GemmP& p, f32x4 (&acc)[MT][4
 #pragma unroll
           for (int r = 0; r < 4; ++r) op[(int64_t)r * p.ldo] = from_f32<T>(v[r]);
         } else if constexpr (OUTF32) {
-          *reinterpret_cast<float4*>(reinterpret_cast<float*>(p.out) + orow * p.ldo + n) = make_float4(v[0], v[1], v[2], v[3]);
+          float* op = reinterpret_cast<float*>(p.out) + orow * p.ldo + n;
+          *reinterpret_cast<float4*>(op) = make_float4(v[0], v[1], v[2], v[3]);
+          if (p.dup_off) *reinterpret_cast<float4*>(op + p.dup_off) = make_float4(v[0], v[1], v[2], v[3]);
         } else {
           T* op = reinterpret_cast<T*>(p.out) + orow * p.ldo + n;
           if constexpr (sizeof(T) == 2) {
@@ -324,11 +328,11 @@ struct SkinnyP {
   int act;
 };
 
-__global__ __launch_bounds__(256) void skinny_gemm_kernel(SkinnyP p) {
+__device__ __forceinline__ void skinny_gemm_body(const SkinnyP& p, int block) {
   __shared__ float red[4][4][64][4];  // [wave][mtile][lane][reg]
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int l15 = lane & 15, g = lane >> 4;
-  const int n0 = blockIdx.x * 16;
+  const int n0 = block * 16;
   const int mt = (p.M + 15) >> 4;  // 1..4 row tiles
   f32x4 acc[4];
 #pragma unroll
@@ -342,6 +346,8 @@ __global__ __launch_bounds__(256) void skinny_gemm_kernel(SkinnyP p) {
     if (m >= p.M) m = p.M - 1;  // clamped rows are never stored
     Ar[i] = p.A + (int64_t)m * p.lda + wid * kper + g * 4;
   }
+  // (unrolled: a wave's K slice is a chain of dependent 16-byte loads otherwise -- 32 round trips for time_mlp's K = 2048)
+#pragma unroll 4
   for (int k = 0; k < kper; k += 16) {
     const float4 w = *reinterpret_cast<const float4*>(Wr + k);
     const float wv[4] = {w.x, w.y, w.z, w.w};
@@ -375,4 +381,20 @@ __global__ __launch_bounds__(256) void skinny_gemm_kernel(SkinnyP p) {
       *reinterpret_cast<float4*>(p.out + (int64_t)m * p.ldo + n) = make_float4(v[0], v[1], v[2], v[3]);
     }
   }
+}
+
+__global__ __launch_bounds__(256) void skinny_gemm_kernel(SkinnyP p) { skinny_gemm_body(p, blockIdx.x); }
+
+// Up to three independent skinny GEMMs as ONE launch (the FiLM generators and the time tokens' K / V rows of the per-step time path
+// all read tpath_post_kernel's outputs and nothing of each other): block ranges [0, nb0), [nb0, nb1), [nb1, grid).  A launch is
+// ~4.6 us of dispatch floor on this part whatever it computes; same arithmetic per output element as three launches.
+struct SkinnyG3 {
+  SkinnyP p[3];
+  int nb0, nb1;
+};
+__global__ __launch_bounds__(256) void skinny_gemm_group_kernel(SkinnyG3 g) {
+  const int b = blockIdx.x;
+  if (b < g.nb0) skinny_gemm_body(g.p[0], b);
+  else if (b < g.nb1) skinny_gemm_body(g.p[1], b - g.nb0);
+  else skinny_gemm_body(g.p[2], b - g.nb1);
 }

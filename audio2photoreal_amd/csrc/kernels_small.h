@@ -47,21 +47,27 @@ struct SmallP {
 // BM: 32 rows.  (64-row tiles for the wide LayerNorm-prologue GEMMs -- one round of workgroups instead of 1.4 at 480 rows, half the
 // weight traffic -- were measured and lose: 14.8 us per launch against 12.5: the prologue of a workgroup is a serial chain of
 // latencies, twice as long with twice the rows.)
+// LayerNorm-prologue launches (PRO = 1) keep their weight tile in REGISTERS (WREG): a wave's 16 columns x K = 512 are 16 x 16 bytes
+// per lane, requested straight from global memory behind the residual rows.  Only the A panel is in LDS then (32 KiB instead of
+// 96), so two workgroups share a CU and the 360 workgroups of the [Q|K|V] launch at 480 rows are one round instead of 1.4, each
+// hiding the other's LayerNorm round trips.
 template <int K, int BN, int PRO, int EPI, int BM = 32>
-__global__ __launch_bounds__(256) void small_gemm_kernel(const SmallP p) {
+__global__ __launch_bounds__(256, PRO == 1 ? 2 : 1) void small_gemm_kernel(const SmallP p) {
   constexpr int CPR = K / 8;                          // 16-byte chunks per row
   constexpr int WR = BN == 64 ? 1 : 2;                // wave grid: WR row groups x (4 / WR) column groups of 16 columns
   constexpr int MT = BM / 16 / WR;                    // 16-row tiles per wave
   constexpr int KC = K / 32;                          // MFMA k-chunks
+  constexpr bool WREG = PRO == 1;
   static_assert((BN == 64 || BN == 32) && (K == 512 || K == 1024) && (BM == 32 || BM == 64), "tile shapes");
-  __shared__ __attribute__((aligned(16))) h16_t smem[(BM + BN) * K];
+  static_assert(!WREG || (BN == 64 && K == 512), "register-resident weight tile: one 16-column slice per wave");
+  __shared__ __attribute__((aligned(16))) h16_t smem[(BM + (WREG ? 0 : BN)) * K];
   h16_t* const As = smem;
   h16_t* const Ws = smem + BM * K;
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, l15 = lane & 15, g = lane >> 4;
   const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
 
   // ---- weight tile: BN rows of K values, one burst.  LDS chunk position q of row r holds global chunk q ^ (r & 15) ------------
-  {
+  if constexpr (!WREG) {
     constexpr int RPI = 64 / CPR > 0 ? 64 / CPR : 1;   // rows per wave instruction (K = 512: 1)
     constexpr int IPR = CPR / 64 > 0 ? CPR / 64 : 1;   // instructions per row (K = 1024: 2)
     static_assert(RPI == 1, "K >= 512");
@@ -76,6 +82,7 @@ __global__ __launch_bounds__(256) void small_gemm_kernel(const SmallP p) {
       }
     }
   }
+  [[maybe_unused]] h16x8 wreg[WREG ? KC : 1];
   // ---- A panel ------------------------------------------------------------------------------------------------------------
   if constexpr (PRO == 0) {
     constexpr int IPR = CPR / 64;
@@ -114,6 +121,15 @@ __global__ __launch_bounds__(256) void small_gemm_kernel(const SmallP p) {
         const float4* c4 = reinterpret_cast<const float4*>(p.cs + (int64_t)(gm % p.rows_per_seq) * (K / 2) + e0 / 2);
         rc[rr][0] = c4[0];
         rc[rr][1] = c4[1];
+      }
+    }
+    if constexpr (WREG) {   // the wave's weight slice, behind the rows (vmcnt is in order: the LayerNorm does not wait for it)
+      if (rb == 0) {
+        int gn = n0 + (WR == 1 ? wid : (wid & 1)) * 16 + l15;
+        gn = gn < p.N ? gn : p.N - 1;
+        const h16_t* wg = p.W + (int64_t)gn * K + g * 8;
+#pragma unroll
+        for (int c = 0; c < KC; ++c) wreg[c] = *reinterpret_cast<const h16x8*>(wg + c * 32);
       }
     }
     // The two reductions of the 8 rows are independent chains of VALU cross-lane steps (DPP + permlane swaps, a2p_common.h): as
@@ -195,13 +211,13 @@ __global__ __launch_bounds__(256) void small_gemm_kernel(const SmallP p) {
   // fragments of 8 k-chunks are requested ahead of the MFMAs that consume them: the kernel is a chain of latencies (launch, one
   // memory round trip, this loop, the stores), an un-pipelined loop pays one LDS round trip per k-chunk
   constexpr int CB = 8;
-#pragma unroll 1
-  for (int c0 = 0; c0 < KC; c0 += CB) {
+  auto ksteps = [&](int c0) __attribute__((always_inline)) {
     h16x8 wf[CB], af[CB][MT];
 #pragma unroll
     for (int i = 0; i < CB; ++i) {
       const int pos = (((c0 + i) * 4 + g) ^ l15) << 3;
-      wf[i] = *reinterpret_cast<const h16x8*>(wrow + pos);
+      if constexpr (WREG) wf[i] = wreg[c0 + i];
+      else wf[i] = *reinterpret_cast<const h16x8*>(wrow + pos);
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt) af[i][mt] = *reinterpret_cast<const h16x8*>(arow + mt * 16 * K + pos);
     }
@@ -212,6 +228,13 @@ __global__ __launch_bounds__(256) void small_gemm_kernel(const SmallP p) {
         if (transposed) acc[mt] = A2P_MFMA16(af[i][mt], wf[i], acc[mt]);   // D = C: lane holds rows g*4 + r of column l15
         else acc[mt] = A2P_MFMA16(wf[i], af[i][mt], acc[mt]);              // D = C^T: lane holds columns g*4 + r of row l15
       }
+  };
+  if constexpr (WREG) {   // register-resident weights: compile-time chunk indices
+#pragma unroll
+    for (int c0 = 0; c0 < KC; c0 += CB) ksteps(c0);
+  } else {
+#pragma unroll 1
+    for (int c0 = 0; c0 < KC; c0 += CB) ksteps(c0);
   }
 
   // ---- epilogue ---------------------------------------------------------------------------------------------------------------

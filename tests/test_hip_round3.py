@@ -170,3 +170,62 @@ def test_small_forward_kernels_match_the_per_op_kernels_and_the_oracle(dev, B, T
     assert torch.isfinite(small).all()
     assert e_pair < k * 6.5e-3 and e_small < k * 9e-3 and e_small < 1.2 * e_old + k * 1e-3, (e_pair, e_small, e_old)
     model.release()
+
+
+@pytest.mark.parametrize("precision", ["bf16", "fp16"])
+@pytest.mark.parametrize("fmt", ["face", "pose"])
+def test_key_split_attention_matches_softmax_and_the_query_split_kernel(dev, fmt, precision, monkeypatch):
+    """Small forwards run attention with the KEYS split over a workgroup's waves and an LDS log-sum-exp merge
+    (csrc/kernels_attn.h attn_ksplit_kernel).  Through a2p_attention (A2P_ATTN_KSPLIT=1 forces it): against float64 softmax
+    attention at the precision's bar, and against attn_kernel to the rounding of the softmax sums.  Sizes: fewer tiles than waves
+    (20 keys), ragged last tiles (77, 150), several tiles per wave (800), a spiked key (rescale across the merge)."""
+    from audio2photoreal_amd import _lib
+    spec, model = _model(fmt, precision, dev, 1)
+    model._ensure_ctx(dev, 1)
+    lib = model._lib()
+    d, H = spec.latent_dim, spec.num_heads
+    g = torch.Generator().manual_seed(5)
+    rel = lambda a, b: float((a.double() - b.double()).norm() / b.double().norm())
+    for (N, Tq, S) in [(2, 100, 77), (1, 240, 800), (3, 33, 20), (2, 240, 240), (1, 150, 150)]:
+        q, k, v = (torch.randn(N, L, d, generator=g) for L in (Tq, S, S))
+        k[0, S // 3] *= 6.0
+        dh = d // H
+        qh, kh, vh = (t.view(N, -1, H, dh).transpose(1, 2).double() for t in (q, k, v))
+        ref = (torch.softmax(qh @ kh.transpose(-1, -2) / dh ** 0.5, -1) @ vh).transpose(1, 2).reshape(N, Tq, d)
+        qd, kd, vd = q.to(dev), k.to(dev), v.to(dev)
+        outs = {}
+        for name, val in (("split", "1"), ("query", None)):
+            if val is None:
+                monkeypatch.delenv("A2P_ATTN_KSPLIT", raising=False)
+            else:
+                monkeypatch.setenv("A2P_ATTN_KSPLIT", val)
+            _lib.check(lib.a2p_reload_env(model._ctx), "a2p_reload_env")
+            out = torch.empty(N, Tq, d, device=dev)
+            _lib.check(lib.a2p_attention(model._ctx, _lib.ptr(qd), _lib.ptr(kd), _lib.ptr(vd), _lib.ptr(out), N, Tq, S,
+                                         _lib.current_stream()), "a2p_attention")
+            outs[name] = out.cpu()
+        e_ref, e_pair = rel(outs["split"], ref), rel(outs["split"], outs["query"])
+        record(f"attn_ksplit/{fmt}/{precision}/{N}x{Tq}x{S}", rel_l2=e_ref, vs_query_split=e_pair)
+        assert torch.isfinite(outs["split"]).all()
+        assert e_ref < {"bf16": 2e-2, "fp16": 3e-3}[precision], (N, Tq, S, e_ref)
+        assert e_pair < {"bf16": 6e-3, "fp16": 8e-4}[precision], (N, Tq, S, e_pair)
+    model.release()
+
+
+@pytest.mark.parametrize("precision", ["bf16", "fp16"])
+def test_small_forward_with_and_without_key_split_attention(dev, precision, monkeypatch):
+    """The whole small forward (config 0 shape: time-token tail in the cross attention) with the key-split attention and with
+    attn_kernel (A2P_NO_KSPLIT=1): the same result to the rounding of the softmax sums."""
+    B, T = 1, 240
+    spec, model = _model("face", precision, dev, B)
+    cfg = ClassifierFreeSampleModel(model)
+    x, t, y = _inputs(spec, "face", B, T, dev)
+    monkeypatch.delenv("A2P_NO_KSPLIT", raising=False)
+    split = cfg(x, t, y).cpu()
+    monkeypatch.setenv("A2P_NO_KSPLIT", "1")
+    query = cfg(x, t, y).cpu()
+    monkeypatch.delenv("A2P_NO_KSPLIT")
+    err = float((split - query).norm() / query.norm())
+    record(f"small_ksplit_vs_query/{precision}/B{B}_T{T}", rel_l2=err)
+    assert torch.isfinite(split).all() and err < {"bf16": 4e-3, "fp16": 5e-4}[precision], err
+    model.release()
