@@ -147,6 +147,8 @@ struct A2POpts {
   int ksplit_nw = 0;        // A2P_KSPLIT_NW=4|8: waves of the key-split attention
   int ksplit_qt = 0;        // A2P_KSPLIT_QT=1|2: 16-query tiles per wave of the key-split attention
   int force_ksplit = 0;     // A2P_ATTN_KSPLIT=1: every 16-bit attention launch takes the key-split kernel (tests)
+  int graph = 0;            // A2P_GRAPH=1: non-chain forwards replay a captured graph instead of stream launches (measured: same GPU
+                            // time per step -- the launches are not host-bound -- at a tenth of the host time; off by default)
   int no_small = 0;         // A2P_NO_SMALL=1: per-op kernels for forwards below 960 rows instead of kernels_small.h
   int chain_rows = 1280;    // A2P_CHAIN_ROWS=n: forwards of at least n rows take the chain kernels (measured crossover against the small-forward
                             // GEMMs of kernels_small.h: 1192 vs 1002 steps/s at 960 rows, 804 vs 1018 at 1920)
@@ -159,6 +161,7 @@ static void load_opts(A2POpts& o) {
   o.chain_no_mix = flag("A2P_CHAIN_NO_MIX"); o.tune_verbose = flag("A2P_TUNE_VERBOSE"); o.side_join = num("A2P_SIDE_JOIN", 3);
   o.x_rowmajor = flag("A2P_CHAIN_X_ROWMAJOR"); o.no_side_stream = flag("A2P_NO_SIDE_STREAM");
   o.side_early_join = flag("A2P_SIDE_EARLY_JOIN"); o.no_shared_half = flag("A2P_NO_SHARED_HALF");
+  o.graph = flag("A2P_GRAPH");
   o.no_ksplit = flag("A2P_NO_KSPLIT"); o.force_ksplit = flag("A2P_ATTN_KSPLIT"); o.ksplit_nw = num("A2P_KSPLIT_NW", 0); o.ksplit_qt = num("A2P_KSPLIT_QT", 0);
   o.no_small = flag("A2P_NO_SMALL"); o.chain_rows = num("A2P_CHAIN_ROWS", 1280);
 }
@@ -210,6 +213,12 @@ struct a2p_ctx {
   Buf ce_pack, pooled, tmpa, tmpb, kf_pack, kf_tok;
   // timing
   int time_kind = -1;
+  // captured forwards (a2p_lib_run.h run_forward)
+  struct GraphKey { int pass, B, T, S0, K, small, epoch; };
+  struct GraphEnt { GraphKey key; hipGraphExec_t exec; int rows; };
+  std::vector<GraphEnt> graphs;
+  hipStream_t gstream = nullptr;
+  int graph_epoch = 0;
   std::vector<std::pair<hipEvent_t, hipEvent_t>> evs;
   std::vector<hipEvent_t> ev_pool;
   // side stream: the per-step time path (t -> FiLM scale/shift, time-token K/V) overlaps the first projections / self attention
@@ -604,12 +613,16 @@ extern "C" int a2p_set_batch_hint(a2p_ctx* c, int32_t global_batch) {
 extern "C" int a2p_reload_env(a2p_ctx* c) {
   ARG(c, "null ctx");
   load_opts(c->opt);
+  ++c->graph_epoch;   // captured forwards carry the kernel choices of the switches they were captured under
   return 0;
 }
 
 extern "C" int a2p_ctx_destroy(a2p_ctx* c) {
   if (!c) return 0;
   hipDeviceSynchronize();
+  for (auto& g : c->graphs) (void)hipGraphExecDestroy(g.exec);
+  c->graphs.clear();
+  if (c->gstream) (void)hipStreamDestroy(c->gstream);
   for (auto& kv : c->w) buf_free(kv.second);
   for (auto& kv : c->wt) buf_free(kv.second);
   Buf* all[] = {&c->rope_cs, &c->rope_cst, &c->time_freq, &c->film_w, &c->film_b, &c->tct_w, &c->tct_b, &c->cak_w32, &c->cak_b, &c->cav_w32,
@@ -686,6 +699,7 @@ static int chain_build_streams(a2p_ctx* c, hipStream_t s);
 
 extern "C" int a2p_finalize_weights(a2p_ctx* c, void* stream) {
   ARG(c, "null ctx");
+  ++c->graph_epoch;   // the compute-dtype weight copies are rebuilt: captured forwards hold the old pointers
   ArenaScope scope(c->use_arena ? &c->arena : nullptr);
   hipStream_t s = (hipStream_t)stream;
   std::map<std::string, int64_t> e;

@@ -693,9 +693,9 @@ extern "C" int a2p_prepare_cond(a2p_ctx* c, const float* cond_embed, int32_t B, 
 // ------------------------------------------------------------------------------------------------
 // per-step time path (a15, a20, time-token K/V)
 // ------------------------------------------------------------------------------------------------
-static int time_path(a2p_ctx* c, const int64_t* t_orig, int N, const int* slots, hipStream_t s) {
+static int time_path(a2p_ctx* c, const int64_t* t_orig, int N, const int* slots, hipStream_t s, bool embed = true) {
   const int d = c->d, B = c->pB, L = c->L, F = c->F;
-  time_embed_kernel<<<(B * (d / 2) + 255) / 256, 256, 0, s>>>(t_orig, c->time_freq.f(), c->emb.f(), B, d / 2);
+  if (embed) time_embed_kernel<<<(B * (d / 2) + 255) / 256, 256, 0, s>>>(t_orig, c->time_freq.f(), c->emb.f(), B, d / 2);
   CHK(launch_skinny(c->emb.f(), d, W32(c, "time_mlp.1.weight"), d, W32(c, "time_mlp.1.bias"), c->th.f(), 4 * d, B, 4 * d, d, ACT_MISH, s));
   CHK(launch_skinny(c->th.f(), 4 * d, c->tct_w.f(), 4 * d, c->tct_b.f(), c->tct.f(), 3 * d, B, 3 * d, 4 * d, ACT_NONE, s));
   TPathP tp;
@@ -748,32 +748,33 @@ static int pose_conv_tail(a2p_ctx* c, int N, int T, hipStream_t s) {
   return launch_gemm(c, pf, s);
 }
 
+// The two launches of a forward that read CALLER memory (the timestep tensor, the noisy input): time embedding and input pack.
+// They are the first launch of the time path and of the main path; forward_body(ext = false) leaves them out, so that what it
+// launches touches context-owned buffers only and can be replayed as a captured graph (run_forward).
+static int forward_ext(a2p_ctx* c, const float* x_in, const int64_t* t_orig, hipStream_t s) {
+  const int d = c->d, B = c->pB, T = c->pT;
+  time_embed_kernel<<<(B * (d / 2) + 255) / 256, 256, 0, s>>>(t_orig, c->time_freq.f(), c->emb.f(), B, d / 2);
+  dim3 grid((T + 31) / 32, (c->Cpad + 31) / 32, B);
+  if (c->tail_x3) pack_input_split3_kernel<<<grid, 256, 0, s>>>(x_in, (h16_t*)c->inpack.p, B, c->C, T, c->Cpad);
+  else if (c->bf16 && !c->tail32) pack_input_kernel<h16_t><<<grid, 256, 0, s>>>(x_in, (h16_t*)c->inpack.p, B, c->C, T, c->Cpad);
+  else pack_input_kernel<float><<<grid, 256, 0, s>>>(x_in, (float*)c->inpack.p, B, c->C, T, c->Cpad);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
 // FiLMTransformer.forward for N sequences; result rows in c->mo ([N][mo_rows][C] fp32)
-static int run_forward(a2p_ctx* c, const float* x_in, const int64_t* t_orig, int pass, int* mo_seq_rows, hipStream_t s) {
-  if (!c->prepared) {
-    set_err("denoise before a2p_prepare_cond");
-    return A2P_ERR_STATE;
-  }
-  ARG(x_in && t_orig, "null argument");
-  ARG(pass >= 0 && pass <= 2, "bad pass %d", pass);
+static int forward_body(a2p_ctx* c, const float* x_in, const int64_t* t_orig, int pass, int* mo_seq_rows, hipStream_t s, bool ext,
+                        bool use_chain, bool use_small) {
   const int d = c->d, B = c->pB, T = c->pT, L = c->L, F = c->F;
   const int N = pass == A2P_PASS_CFG ? 2 * B : B;
   c->clk_turn = 0;
   const int* slots = (const int*)(pass == A2P_PASS_CFG ? c->slot_cfg.p : (pass == A2P_PASS_COND ? c->slot_cond.p : c->slot_unc.p));
-  // Row panels pay off once there are enough of them: every workgroup streams the whole weight set of its chain, so a
-  // forward of < ~1000 rows (config 0: B=1, T=240 -> 480 rows = 10 panels) is faster as many small 2-D tiles
-  // (measured: 0.99 vs 1.10 ms per step at 480 rows, equal at 1200, chain ahead from 2400 rows on).
-  // The kernel family is chosen from the row count of the UNSHARDED batch when the host names it (a2p_set_batch_hint;
-  // sample_parallel does): the families differ in rounding, and a sharded run must reproduce the single-process samples bit for bit
-  const int64_t rows_eff = (int64_t)(c->batch_hint > B ? (N / B) * c->batch_hint : N) * T;
-  const bool use_chain = chain_supported(c) && (rows_eff >= c->opt.chain_rows || c->opt.chain_mt);
   // The time path (7 latency-bound launches, ~70 us at B=8) is not needed before the first out_proj epilogue and can run on
   // the side stream next to input projection / norm1+QKV / self attention of layer 0 (-2..3 % step time).  On by default since
   // round 2 (A2P_NO_SIDE_STREAM=1 turns it off): in round 1, with the two queues active, 1-30 % of forwards on some boxes
   // differed for one sample; that was traced to tpath_post_kernel consuming a load right behind its s_waitcnt (kernels_misc.h,
   // DESIGN.md "Reproducibility") and fixed there -- 0 / 1500 differing forwards in round 1, 0 / 600 + identical 60-step
   // trajectories in both 16-bit modes in round 2 (scratch/side_stress.py).
-  const bool use_small = !use_chain && small_supported(c);
   // (the small path keeps the time path on the main stream: on the side stream it measured 1430 against 1497 steps/s at 480 rows --
   // the fork / join costs more than the 7 launches it hides)
   const bool overlap_tpath = use_chain && !c->opt.no_side_stream;
@@ -783,18 +784,19 @@ static int run_forward(a2p_ctx* c, const float* x_in, const int64_t* t_orig, int
     ++c->ev_turn;
     HIPCHK(hipEventRecord(c->ev_fork, s));  // orders the side stream behind t_orig AND behind the previous step's readers
     HIPCHK(hipStreamWaitEvent(c->side, c->ev_fork, 0));
-    CHK(time_path(c, t_orig, N, slots, c->side));
+    CHK(time_path(c, t_orig, N, slots, c->side, ext));
     HIPCHK(hipEventRecord(c->ev_join, c->side));
     if (c->opt.side_early_join) HIPCHK(hipStreamWaitEvent(s, c->ev_join, 0));  // diagnostic: side stream without overlap
   } else {
-    CHK(time_path(c, t_orig, N, slots, s));
+    CHK(time_path(c, t_orig, N, slots, s, ext));
   }
   // input permute + projection (model/diffusion.py:345-346,364); exact fp32 in every mode (a2p_ctx::tail32)
   {
     Fp32Scope f32(c, c->tail32 && !c->tail_x3);
     dim3 grid((T + 31) / 32, (c->Cpad + 31) / 32, B);
     const int X = c->tail_x3 ? 3 : 1;
-    if (c->tail_x3) pack_input_split3_kernel<<<grid, 256, 0, s>>>(x_in, (h16_t*)c->inpack.p, B, c->C, T, c->Cpad);
+    if (!ext) {   // forward_ext launched it
+    } else if (c->tail_x3) pack_input_split3_kernel<<<grid, 256, 0, s>>>(x_in, (h16_t*)c->inpack.p, B, c->C, T, c->Cpad);
     else if (c->bf16) pack_input_kernel<h16_t><<<grid, 256, 0, s>>>(x_in, (h16_t*)c->inpack.p, B, c->C, T, c->Cpad);
     else pack_input_kernel<float><<<grid, 256, 0, s>>>(x_in, (float*)c->inpack.p, B, c->C, T, c->Cpad);
     const bool shared_half = use_chain && N == 2 * B && !c->opt.no_shared_half;
@@ -877,6 +879,71 @@ static int run_forward(a2p_ctx* c, const float* x_in, const int64_t* t_orig, int
     CHK(pose_conv_tail(c, N, T, s));
     *mo_seq_rows = T + 24;
   }
+  return 0;
+}
+
+
+// Opt-in (A2P_GRAPH=1): forwards that are not chain-kernel forwards (config 0: 76 launches of 4-12 us) replayed as a captured graph.
+// Everything behind the two launches that read caller memory is captured ONCE per (pass, prepared geometry, kernel family) on a
+// context-owned stream and replayed with hipGraphLaunch on the caller's stream; replays are bit-identical to stream launches
+// (tests/test_hip_round3.py).  Measured (profiles/r03_ksplit_ab.txt): a dependent stream launch of an EMPTY kernel costs 2.8 us and is
+// host-bound, a graph node 1.6 us (scratch/launch_floor.hip) -- but the step's kernels are longer than the host's enqueue time, the
+// host runs ahead either way, and the step takes the same time (1742 vs 1757 steps/s); what the graph saves is ~200 us of host time per
+// step.  Graphs die with the state they captured: a2p_finalize_weights / a2p_reload_env bump graph_epoch.  Never while a kernel class
+// is being timed (dispatch-packet events are not capturable).
+static void graphs_drop(a2p_ctx* c) {
+  for (auto& g : c->graphs) (void)hipGraphExecDestroy(g.exec);
+  c->graphs.clear();
+}
+
+static int run_forward(a2p_ctx* c, const float* x_in, const int64_t* t_orig, int pass, int* mo_seq_rows, hipStream_t s) {
+  if (!c->prepared) {
+    set_err("denoise before a2p_prepare_cond");
+    return A2P_ERR_STATE;
+  }
+  ARG(x_in && t_orig, "null argument");
+  ARG(pass >= 0 && pass <= 2, "bad pass %d", pass);
+  const int B = c->pB, T = c->pT;
+  const int N = pass == A2P_PASS_CFG ? 2 * B : B;
+  // Row panels pay off once there are enough of them: every workgroup streams the whole weight set of its chain, so a
+  // forward of < ~1000 rows (config 0: B=1, T=240 -> 480 rows = 10 panels) is faster as many small 2-D tiles
+  // (measured: 0.99 vs 1.10 ms per step at 480 rows, equal at 1200, chain ahead from 2400 rows on).
+  // The kernel family is chosen from the row count of the UNSHARDED batch when the host names it (a2p_set_batch_hint;
+  // sample_parallel does): the families differ in rounding, and a sharded run must reproduce the single-process samples bit for bit
+  const int64_t rows_eff = (int64_t)(c->batch_hint > B ? (N / B) * c->batch_hint : N) * T;
+  const bool use_chain = chain_supported(c) && (rows_eff >= c->opt.chain_rows || c->opt.chain_mt);
+  const bool use_small = !use_chain && small_supported(c);
+  if (use_chain || !c->opt.graph || c->time_kind >= 0) return forward_body(c, x_in, t_orig, pass, mo_seq_rows, s, true, use_chain, use_small);
+  CHK(forward_ext(c, x_in, t_orig, s));
+  const a2p_ctx::GraphKey key = {pass, B, T, c->pS0, c->pK, use_small ? 1 : 0, c->graph_epoch};
+  for (auto& g : c->graphs)
+    if (memcmp(&g.key, &key, sizeof(key)) == 0) {
+      HIPCHK(hipGraphLaunch(g.exec, s));
+      *mo_seq_rows = g.rows;
+      return 0;
+    }
+  if (c->graphs.size() >= 16) graphs_drop(c);   // a long-lived context walking through many geometries
+  if (!c->gstream) HIPCHK(hipStreamCreateWithFlags(&c->gstream, hipStreamNonBlocking));
+  HIPCHK(hipStreamBeginCapture(c->gstream, hipStreamCaptureModeThreadLocal));
+  int rows = 0;
+  const int rc = forward_body(c, x_in, t_orig, pass, &rows, c->gstream, false, use_chain, use_small);
+  hipGraph_t graph = nullptr;
+  const hipError_t ce = hipStreamEndCapture(c->gstream, &graph);
+  if (rc != 0 || ce != hipSuccess || !graph) {
+    if (graph) (void)hipGraphDestroy(graph);
+    if (rc == 0) set_err("graph capture of the forward failed: %s", hipGetErrorString(ce));
+    return rc != 0 ? rc : A2P_ERR_HIP;
+  }
+  hipGraphExec_t exec = nullptr;
+  const hipError_t ie = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+  (void)hipGraphDestroy(graph);
+  if (ie != hipSuccess) {
+    set_err("hipGraphInstantiate: %s", hipGetErrorString(ie));
+    return A2P_ERR_HIP;
+  }
+  c->graphs.push_back({key, exec, rows});
+  HIPCHK(hipGraphLaunch(exec, s));
+  *mo_seq_rows = rows;
   return 0;
 }
 

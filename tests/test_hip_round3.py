@@ -229,3 +229,34 @@ def test_small_forward_with_and_without_key_split_attention(dev, precision, monk
     record(f"small_ksplit_vs_query/{precision}/B{B}_T{T}", rel_l2=err)
     assert torch.isfinite(split).all() and err < {"bf16": 4e-3, "fp16": 5e-4}[precision], err
     model.release()
+
+
+@pytest.mark.parametrize("fmt,precision,B,T", [("face", "fp16", 1, 240), ("face", "bf16", 2, 150), ("face", "fp32", 1, 96),
+                                               ("pose", "fp16", 1, 120)])
+def test_captured_forward_replays_bit_identically(dev, fmt, precision, B, T, monkeypatch):
+    """Non-chain forwards (small-forward kernels, per-op kernels, fp32 mode, body model below the chain threshold) are captured
+    once as a graph behind the two launches that read caller memory and replayed (csrc/a2p_lib_run.h run_forward).  Replays on
+    NEW inputs and timesteps (fresh tensors: other addresses) must equal the stream-launched forward bit for bit; a second
+    geometry on the same context gets its own graph.  Opt-in (A2P_GRAPH=1): it saves host time, not GPU time."""
+    spec, model = _model(fmt, precision, dev, B)
+    cfg = ClassifierFreeSampleModel(model)
+    g = torch.Generator().manual_seed(11)
+    calls = []
+    for i, tt in enumerate((T, T, T, T - 8 if T > 100 else T)):
+        x, t, y = _inputs(spec, fmt, B, tt, dev)
+        x = x + 0.1 * i * torch.randn(x.shape, generator=g).to(dev)      # a new tensor (new address) per call
+        t = torch.tensor(([901, 417, 33, 0] * 8)[i:i + B], device=dev)
+        calls.append((x, t, y))
+    monkeypatch.setenv("A2P_GRAPH", "1")
+    replayed = [cfg(x, t, y).cpu() for (x, t, y) in calls]
+    replayed2 = [cfg(x, t, y).cpu() for (x, t, y) in calls]              # every graph exists by now: pure replays
+    monkeypatch.delenv("A2P_GRAPH")
+    direct = [cfg(x, t, y).cpu() for (x, t, y) in calls]
+    worst = 0.0
+    for a, b, c in zip(replayed, replayed2, direct):
+        assert torch.isfinite(c).all()
+        worst = max(worst, float((a - c).abs().max()), float((b - c).abs().max()))
+    record(f"graph_vs_stream/{fmt}/{precision}/B{B}_T{T}", max_abs_diff=worst)
+    assert worst == 0.0
+    assert not torch.equal(direct[0], direct[1])                          # the calls really differ
+    model.release()
