@@ -313,7 +313,11 @@ static int launch_gemm(a2p_ctx* c, const GemmP& p, hipStream_t s) {
   // 2-deep ring; they take the 4-deep one (A2P_GEMM_RING2=1 keeps the 2-deep ring for A/B runs)
   static const bool ring2 = getenv("A2P_GEMM_RING2") != nullptr;
   const int64_t blocks64 = (int64_t)((p.N + 127) / 128) * ((p.M + 63) / 64);
-  if (c->bf16 && small && blocks64 <= 256 && p.ntaps == 1 && !ring2) rc = gemm_dispatch<h16_t, 2, 4>(kt, p, s);
+  // narrow tap-accumulating launches (the body model's dilated conv tail: N <= 128, i.e. one column tile; 312 workgroups of 64 rows
+  // at B=16 = 1.2 per CU, each a chain of 18 k-tile round trips): 32-row tiles double the workgroups per CU (A2P_GEMM_MT1=0|1)
+  static const int mt1 = getenv("A2P_GEMM_MT1") ? atoi(getenv("A2P_GEMM_MT1")) : 1;
+  if (c->bf16 && mt1 && p.ntaps > 1 && p.N <= 128 && blocks64 <= 3 * 256) rc = gemm_dispatch<h16_t, 1>(kt, p, s);
+  else if (c->bf16 && small && blocks64 <= 256 && p.ntaps == 1 && !ring2) rc = gemm_dispatch<h16_t, 2, 4>(kt, p, s);
   else if (c->bf16) rc = small ? gemm_dispatch<h16_t, 2>(kt, p, s) : gemm_dispatch<h16_t, 4>(kt, p, s);
   else rc = small ? gemm_dispatch<float, 2>(kt, p, s) : gemm_dispatch<float, 4>(kt, p, s);
   CHK(rc);
