@@ -148,12 +148,9 @@ def kernel_breakdown(case, ksteps):
     from audio2photoreal_amd import _lib
     lib = case.model._lib()
     flops = algorithmic_flops(case.spec, case.T, case.S0 + 2, 2 * case.B)
-    # bf16 mode runs the decoder-layer GEMMs inside the fused "chain" kernels (projections + FiLM + LayerNorm + FFN);
-    # fp32 mode (and A2P_NO_CHAIN=1) runs them as separate GEMM launches
-    chained = case.precision != "fp32" and not os.environ.get("A2P_NO_CHAIN")
-    flops["chain" if chained else "gemm"] = flops.pop("decoder_gemm") + (0.0 if chained else flops["io_gemm"])
-    if chained:
-        flops["gemm"] = flops["io_gemm"]
+    # the decoder-layer GEMMs run inside the fused "chain" kernels (16-bit modes at >= 1280 rows) or as separate GEMM launches (fp32
+    # mode, A2P_NO_CHAIN=1, the small-forward kernels below 1280 rows): the FLOPs go to whichever class actually launched (below)
+    dec_gemm = flops.pop("decoder_gemm")
     kernels = {}
     for name, kind in (("chain", _lib.KERNEL_CHAIN), ("gemm", _lib.KERNEL_GEMM), ("attn_self", _lib.KERNEL_ATTN_SELF),
                        ("attn_cross", _lib.KERNEL_ATTN_CROSS), ("ln_rope", _lib.KERNEL_LNROPE)):
@@ -166,12 +163,16 @@ def kernel_breakdown(case, ksteps):
         if n.value == 0:
             continue
         per_step_ms = ms.value / ksteps
-        ent = {"ms_per_step": round(per_step_ms, 4), "launches_per_step": n.value // ksteps,
-               "avg_launch_us": round(1e3 * ms.value / max(n.value, 1), 2)}
+        kernels[name] = {"ms_per_step": round(per_step_ms, 4), "launches_per_step": n.value // ksteps,
+                         "avg_launch_us": round(1e3 * ms.value / max(n.value, 1), 2)}
+    if "chain" in kernels:
+        flops["chain"], flops["gemm"] = dec_gemm, flops["io_gemm"]
+    else:
+        flops["gemm"] = dec_gemm + flops["io_gemm"]
+    for name, ent in kernels.items():
         if name in flops:
             ent["algorithmic_gflop_per_step"] = round(flops[name] / 1e9, 2)
-            ent["tflops"] = round(flops[name] / (per_step_ms * 1e-3) / 1e12, 2)
-        kernels[name] = ent
+            ent["tflops"] = round(flops[name] / (ent["ms_per_step"] * 1e-3) / 1e12, 2)
     # each class is timed in its own pass (dispatch-packet events serialise the launches of that class against the side stream);
     # the sum of the classes against the untimed step says how much that inflates
     kernels["_sum_of_classes_ms_per_step"] = round(sum(v["ms_per_step"] for v in kernels.values()), 4)
@@ -550,8 +551,9 @@ def main():
             cfg0 = Case("face", 1, 240, a.precision, dev, [0], respacing="ddim10", sampler="ddim")
             legs["cfg0"] = leg_record(cfg0, 50, 5, a.repeats)
             legs["cfg0"]["note"] = ("BASELINE configs[0] shape: face, batch 1, 240 frames, ddim10 step.  480 rows: below the chain kernels' "
-                                    "break-even; the small-forward GEMMs of csrc/kernels_small.h (LayerNorm fused into the A load, whole K "
-                                    "resident) make it ~80 dependent launches of 5-17 us: latency bound, not compute bound")
+                                    "break-even; the small-forward kernels (csrc/kernels_small.h: LayerNorm fused into the A load, whole K "
+                                    "resident; attn_ksplit_kernel: keys split over the waves) make it 76 dependent launches of 5-12 us: "
+                                    "latency bound, not compute bound")
 
     if rank == 0:
         value = world * a.steps / dt
