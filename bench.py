@@ -244,6 +244,17 @@ def cpu_and_parity(case, dev, want_parity=True, chain_steps=1000, chain_batch=2)
            "cores": threads, "host_cpus": ncpu, "kind": "port",
            "sample": f"oracle (torch CPU fp32 restatement of the reference algorithm, conditioning path recomputed every forward like "
                      f"the reference's decoder-only path), 1 sample x {len(t_list)} DDPM steps, T={T}, S={S0 + 2}: {cdt:.2f} s"}
+    # BASELINE.md section 3 variant (A), the reference as is, cannot run on the GPU box (its tree is not there); the build container
+    # timed it beside this port on one sample of the same workload (tests/tools/cpu_reference_vs_port.py): the ratio travels with the repo
+    try:
+        with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r03_cpu_reference_vs_port.json")) as f:
+            ab = json.load(f)
+        cpu["reference_as_is"] = {"port_over_reference_speed": ab["port_over_reference_speed"],
+                                  "estimated_value": round(cpu["value"] / ab["port_over_reference_speed"], 5),
+                                  "source": "profiles/r03_cpu_reference_vs_port.json: the reference itself vs this port, build container, "
+                                            f"{ab['threads']} threads, {ab['shape']} (NOT measured in this run)"}
+    except (OSError, KeyError, ValueError):
+        pass
     if not want_parity:
         return cpu, None
 
