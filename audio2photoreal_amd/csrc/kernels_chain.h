@@ -685,6 +685,7 @@ __device__ __forceinline__ void chain_body(const ChainP& p, h16_t* const smem, c
   // `fin`: this is the kernel's last GEMM.  Before the stores of its last tile the weight DMA is drained (the ring runs up to
   // NS-1 stages past the end of the stream and must have landed before the LDS is released), so that the kernel can end with
   // its final stores -- the last tile's and the residual rows' -- still in flight instead of waiting for their acknowledgement.
+  [[maybe_unused]] int gs_stamp = 13;   // diagnostic build: next free stamp slot for gemm_store's per-tile stamps
   auto gemm_store = [&](int ntiles, const float* bias_lds, h16_t* out, int64_t ldo, bool transposed, bool fin = false) __attribute__((always_inline)) {
     // V^T through LDS (frame count a multiple of 8): the accumulators hold 4 consecutive frames of one column per lane, i.e. an
     // 8-byte store per lane with 64 different 8-byte segments per instruction -- measured 150 issue cycles per instruction
@@ -707,6 +708,7 @@ __device__ __forceinline__ void chain_body(const ChainP& p, h16_t* const smem, c
     }
     [[maybe_unused]] h16x4 held[MT];   // 8 waves: the even tile of a pair, kept until its neighbour is done
     for (int t = 0; t < ntiles; ++t) {
+      if constexpr (ABL & 64) { if (t > 0 && gs_stamp < 31) stamp(gs_stamp++); }   // previous tile's epilogue done
       f32x4 acc[MT][NJ];
       if constexpr (NW == 8) {
         if (!transposed) init_bias_o(acc, bias_lds, t);
@@ -716,6 +718,7 @@ __device__ __forceinline__ void chain_body(const ChainP& p, h16_t* const smem, c
         else init_bias_t(acc, bias_lds + t * 128);
       }
       gemm_tile(acc, panelA, D, KS, transposed);
+      if constexpr (ABL & 64) { if (gs_stamp < 31) stamp(gs_stamp++); }   // diagnostic build: tile GEMM done / tile stored (below)
       if (fin && t == ntiles - 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       if constexpr (NW == 8) {
         if (!transposed) {

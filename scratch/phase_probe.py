@@ -12,7 +12,7 @@ G2 = {1: "prologue", 2: "out_proj", 3: "film_res", 4: "ln+park", 5: "ffn", 6: "f
 B = int(os.environ.get("PP_BATCH", "8"))
 case = bench.Case("face", B, 600, "fp16", dev, list(range(B)))
 case.setup()
-for ver, nw in (("1", "8"), ("1", "4"), ("2", "8")):
+for ver, nw in (("1", "8"), ("1", "4")):
     os.environ["A2P_CHAIN_V"], os.environ["A2P_CHAIN_NW"] = ver, nw
     with torch.no_grad():
         case.run_steps(6)
@@ -31,3 +31,8 @@ for ver, nw in (("1", "8"), ("1", "4"), ("2", "8")):
                     parts.append(f"{n}={h[i] - h[prev]:.2f}")
                     prev = i
         print(f"gen {ver} NW={nw} block {'0' if blk == 0 else '101'}: total={h[12] - h[0]:.2f} us | " + " ".join(parts))
+        if ver == "1":   # gemm_store's per-tile stamps (slots 13..30): tile GEMM done, tile stored, ...
+            e = st[blk * 32: blk * 32 + 32]
+            seq = [e[9]] + [x for x in e[13:31] if x > 0]
+            print("      [Q|K] phase from its start, per tile (gemm, epilogue) us: " +
+                  " ".join(f"({seq[i + 1] - seq[i]:.2f},{seq[i + 2] - seq[i + 1]:.2f})" for i in range(0, len(seq) - 2, 2)))
