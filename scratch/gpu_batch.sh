@@ -1,23 +1,17 @@
 #!/bin/bash
+# The command list of the current gpurun call (one evolving script; git history keeps the earlier lists).
 cd "$GRAFT_REPO_ROOT" 2>/dev/null || cd /root/repo
 mkdir -p gpurun_out
 export TMPDIR=/tmp
-B="python bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-parity --no-legs"
-run() {  # tag, env, args
-  local tag=$1; shift
-  timeout -k 5 200 env "$@" > gpurun_out/b23_$tag.json 2> gpurun_out/b23_$tag.err
-  python - <<PY
+TAG=${1:-f3}
+timeout -k 5 600 python bench.py --write-parity gpurun_out/${TAG}_parity.json > gpurun_out/${TAG}_bench.json 2> gpurun_out/${TAG}_bench.err; echo "bench rc=$?"
+python - <<PY
 import json
 try:
-    r = json.loads(open("gpurun_out/b23_$tag.json").read().strip().splitlines()[-1])
-    print("$tag", r["value"], r["ms_per_step"], {k: x["avg_launch_us"] for k, x in r.get("kernels", {}).items() if isinstance(x, dict)})
+    r = json.loads(open("gpurun_out/${TAG}_bench.json").read().strip().splitlines()[-1])
+    print("headline", r["value"], r["ms_per_step"], "roofline", r["roofline"]["frac"], "cpu", r["cpu_baseline"]["value"], r["cpu_baseline"].get("reference_as_is", {}).get("estimated_value"))
+    for k, v in r.get("legs", {}).items(): print("  leg", k, v.get("value"), v.get("ms_per_step"), (v.get("roofline") or {}).get("kernel"), (v.get("roofline") or {}).get("frac"))
 except Exception as e:
-    print("$tag failed", e); print(open("gpurun_out/b23_$tag.err").read()[-800:])
+    print("bench parse failed", e)
 PY
-}
-run b8_qt2 A2P_X=0 $B
-run b8_qt1_w4 A2P_ATTN_QT=1 $B
-run b8_qt1_w8 A2P_ATTN_QT=1 A2P_ATTN_WAVES=8 $B
-run b32_qt2 A2P_X=0 $B --batch 32 --steps 8
-run b32_qt1_w8 A2P_ATTN_QT=1 A2P_ATTN_WAVES=8 $B --batch 32 --steps 8
-A2P_ATTN_QT=1 A2P_ATTN_WAVES=8 timeout -k 5 300 python -m pytest tests/test_hip_parity.py -m gpu -q -x -k "attention_kernel or denoiser or forward" > gpurun_out/b23_tests.log 2>&1; echo "tests rc=$?"; tail -4 gpurun_out/b23_tests.log
+rocm-smi --showclocks 2>/dev/null | grep -i "sclk\|mclk" | head -4
