@@ -156,6 +156,7 @@ def test_ddim10_fp32_vs_reference_golden(dev, golden, fmt):
                                      model_kwargs={"y": y}, noise=inp["x_T"].to(dev))
     e2, em = rel_l2(res.cpu(), golden[f"{fmt}/ddim10"]), rel_max(res.cpu(), golden[f"{fmt}/ddim10"])
     print(f"ddim10 {fmt} fp32: rel L2 {e2:.3e} max-norm {em:.3e}")
+    record(f"ddim10_golden/{fmt}/fp32", rel_l2=e2, max_norm=em)
     assert e2 < 1e-3 and em < 1e-3
 
 
@@ -239,16 +240,20 @@ def test_generic_path_matches_fused(dev):
     assert float(pf["pred_xstart"].abs().max()) <= 1.0
 
 
-def test_bf16_mode_error_reported(dev, golden):
-    """Throughput mode: measured error of 10 DDIM steps vs the fp32 reference (SURVEY.md §0 fact 3 expects ~7e-3)."""
-    spec, model = get_model("face", "bf16", dev)
+@pytest.mark.parametrize("precision", ["bf16", "fp16"])
+def test_config0_ddim10_16bit_vs_reference_golden(dev, golden, precision):
+    """BASELINE configs[0] end to end (face, batch 1, 240 frames, ddim10 loop, guidance 10) in the 16-bit modes against the golden the
+    REFERENCE ITSELF produced (tests/golden/make_golden.py).  480 rows: this is the small-forward path (csrc/kernels_small.h +
+    attn_ksplit_kernel).  fp16 operands are the benchmarked mode and must meet the north-star bar (1e-3 rel-L2 on the loop's return
+    value); bf16 operands are 8x coarser (measured 3.0e-3)."""
+    spec, model = get_model("face", precision, dev)
     inp = synthetic_inputs(spec, 1, 240, SEED)
     y = y_for(spec, inp, dev, 10.0)
     res = make_diffusion("face", "ddim10").ddim_sample_loop(ClassifierFreeSampleModel(model), (1, spec.nfeats, 1, 240),
                                                             clip_denoised=False, model_kwargs={"y": y}, noise=inp["x_T"].to(dev))
     e = rel_l2(res.cpu(), golden["face/ddim10"])
-    record("ddim10_240/face/bf16", rel_l2=e)
-    assert e < 5e-2      # measured 2.5e-2 (round 1 asserted 0.1)
+    record(f"ddim10_240/face/{precision}", rel_l2=e)
+    assert e < {"bf16": 6e-3, "fp16": 1e-3}[precision], e
 
 
 def test_properties_full_size(dev):
