@@ -443,8 +443,9 @@ def run_pipeline(a, dev):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=200,
+                    help="timed steps per region (default 200: a region costs ~0.6 ms on top of its steps -- clocks and queues leaving idle -- which is 1.5 %% of a 20-step region; profiles/r03_steps_sweep.txt)")
+    ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--repeats", type=int, default=3, help="timed regions of exactly --steps steps each; the median is reported")
     ap.add_argument("--batch", type=int, default=8)
     ap.add_argument("--frames", type=int, default=600)
@@ -560,7 +561,7 @@ def main():
             legs["body"] = leg_record(body, a.steps, a.warmup, a.repeats)
             legs["body"]["note"] = "BASELINE configs[2]: body diffusion, keyframe conditioning + CFG scale 2, batch 16, 600 frames, ddim100 step"
             cfg0 = Case("face", 1, 240, a.precision, dev, [0], respacing="ddim10", sampler="ddim")
-            legs["cfg0"] = leg_record(cfg0, 50, 5, a.repeats)
+            legs["cfg0"] = leg_record(cfg0, max(500, a.steps), max(20, a.warmup), a.repeats)
             legs["cfg0"]["note"] = ("BASELINE configs[0] shape: face, batch 1, 240 frames, ddim10 step.  480 rows: below the chain kernels' "
                                     "break-even; the small-forward kernels (csrc/kernels_small.h: LayerNorm fused into the A load, whole K "
                                     "resident; attn_ksplit_kernel: keys split over the waves) make it 76 dependent launches of 5-12 us: "

@@ -1,12 +1,26 @@
-# Fingerprint of the GPU box this gpurun call landed on: the bench (with the shape the library picks) next to both forced
-# workgroup shapes and the chain microbench, to characterise the "slow" group of boxes.
-R=$GRAFT_REPO_ROOT; mkdir -p $R/gpurun_out; O=$R/gpurun_out/box_probe_$(date +%H%M%S).txt
-j='import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(sys.argv[1], d["value"], d["ms_per_step"], {k: v["avg_launch_us"] for k, v in d.get("kernels", {}).items()})'
+#!/bin/bash
+# One line per gpurun box: headline bench (short) + what rocm-smi says about the box (VERDICT weak 8: box-to-box spread)
+cd "$GRAFT_REPO_ROOT" 2>/dev/null || cd /root/repo
+mkdir -p gpurun_out
+TAG=$1
+python bench.py --steps 200 --warmup 3 --repeats 2 --no-cpu-baseline --no-parity --no-legs > gpurun_out/box_$TAG.json 2> gpurun_out/box_$TAG.err &
+BP=$!
+: > gpurun_out/box_$TAG.smi_during.txt
+while kill -0 $BP 2>/dev/null; do   # one sample per ~0.5 s while the bench runs
+  rocm-smi --showpower --showclocks 2>/dev/null | grep -E "Package Power|sclk" | tr -s '\t ' ' ' | tr '\n' ' ' >> gpurun_out/box_$TAG.smi_during.txt
+  echo >> gpurun_out/box_$TAG.smi_during.txt
+  sleep 0.3
+done
+wait $BP
 {
-  echo "== $(date)"
-  A2P_TUNE_VERBOSE=1 python $R/bench.py --no-cpu-baseline 2>&1 | grep -E "a2p|metric" | cut -c1-120
-  A2P_CHAIN_NW=4 python $R/bench.py --no-cpu-baseline 2>/dev/null | python -c "$j" "NW=4"
-  A2P_CHAIN_NW=8 python $R/bench.py --no-cpu-baseline 2>/dev/null | python -c "$j" "NW=8"
-  timeout 60 $R/scratch/chain_bench 2>&1 | grep -E "M=|abl= 0 full"
-} > $O 2>&1
-cat $O
+  python - <<PY
+import json
+r = json.loads(open("gpurun_out/box_$TAG.json").read().strip().splitlines()[-1])
+k = r["kernels"]
+print("box $TAG: %.1f steps/s  chain %.1f us  attn_cross %.1f us  attn_self %.1f us  (chain shape: %s)" % (r["value"], k["chain"]["avg_launch_us"], k["attn_cross"]["avg_launch_us"], k["attn_self"]["avg_launch_us"], r.get("config", {}).get("chain_shape", "?")))
+PY
+  echo "  during the run (samples with the highest sclk):"; awk '{m=$0; sub(/.*\(/,"",m) } { if (match($0, /\(([0-9]+)Mhz\)/)) { v=substr($0, RSTART+1, RLENGTH-5); print v, $0 } }' gpurun_out/box_$TAG.smi_during.txt | sort -n -r | head -3 | cut -d' ' -f2- | sed 's/^/    /'
+  echo "    samples: $(grep -c sclk gpurun_out/box_$TAG.smi_during.txt)"
+  echo "  idle:"; rocm-smi --showmaxpower --showuniqueid --showvbios --showperflevel 2>/dev/null | grep -E "Max Graphics|Unique ID|VBIOS|Performance Level" | sed 's/^/    /'
+  uname -r | sed 's/^/    kernel /'
+} | tee gpurun_out/box_$TAG.txt

@@ -3,15 +3,15 @@
 cd "$GRAFT_REPO_ROOT" 2>/dev/null || cd /root/repo
 mkdir -p gpurun_out
 export TMPDIR=/tmp
-TAG=${1:-f3}
-timeout -k 5 600 python bench.py --write-parity gpurun_out/${TAG}_parity.json > gpurun_out/${TAG}_bench.json 2> gpurun_out/${TAG}_bench.err; echo "bench rc=$?"
+TAG=${1:-f5}
+t0=$(date +%s)
+timeout -k 5 900 python bench.py --write-parity gpurun_out/${TAG}_parity.json > gpurun_out/${TAG}_bench.json 2> gpurun_out/${TAG}_bench.err; echo "bench rc=$? in $(( $(date +%s) - t0 )) s"
 python - <<PY
 import json
 try:
     r = json.loads(open("gpurun_out/${TAG}_bench.json").read().strip().splitlines()[-1])
-    print("headline", r["value"], r["ms_per_step"], "roofline", r["roofline"]["frac"], "cpu", r["cpu_baseline"]["value"], r["cpu_baseline"].get("reference_as_is", {}).get("estimated_value"))
+    print("headline", r["value"], r["ms_per_step"], r["steps"], r["warmup"], "roofline", r["roofline"]["frac"], "cpu", r["cpu_baseline"]["value"], r["cpu_baseline"].get("reference_as_is", {}).get("estimated_value"))
     for k, v in r.get("legs", {}).items(): print("  leg", k, v.get("value"), v.get("ms_per_step"), (v.get("roofline") or {}).get("kernel"), (v.get("roofline") or {}).get("frac"))
 except Exception as e:
     print("bench parse failed", e)
 PY
-rocm-smi --showclocks 2>/dev/null | grep -i "sclk\|mclk" | head -4
