@@ -10,6 +10,9 @@ Synthetic weights + inputs (no checkpoints/datasets offline).  One "step" = one 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B] [--precision fp16|bf16|fp32]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
+Defaults: N=1, K=200 timed steps per region behind W=20 warm-up steps, 3 regions (the median is reported); the whole default run,
+legs, parity and CPU baseline included, takes ~35 s on the GPU box.
+
 The ONE JSON line rank 0 prints carries, next to the contract fields:
   roofline      dominant kernel class, algorithmic FLOPs / measured launch time (HIP events on the launch stream) vs the bf16 peak
   cpu_baseline  the oracle (CPU port of the reference algorithm) timed on this box's host cores, bounded sample
