@@ -174,8 +174,10 @@ def mha(q_in: Tensor, k_in: Tensor, v_in: Tensor, in_w: Tensor, in_b: Tensor,
     q = q.view(B, Lq, nheads, dh).transpose(1, 2)
     k = k.view(B, Lk, nheads, dh).transpose(1, 2)
     v = v.view(B, Lk, nheads, dh).transpose(1, 2)
-    att = torch.softmax((q @ k.transpose(-1, -2)) / math.sqrt(dh), dim=-1)
-    o = (att @ v).transpose(1, 2).reshape(B, Lq, d)
+    # = softmax(q k^T / sqrt(dh)) v.  The reference's calls pass need_weights=False (transformer_modules.py:245,260), which
+    # sends nn.MultiheadAttention through torch's fused scaled_dot_product_attention; the oracle takes the same routine (same
+    # arithmetic to fp32 rounding, ~3x faster on a CPU than the spelled-out form -- it is also what bench.py times as cpu_baseline)
+    o = torch.nn.functional.scaled_dot_product_attention(q, k, v).transpose(1, 2).reshape(B, Lq, d)
     return o @ out_w.T + out_b
 
 
