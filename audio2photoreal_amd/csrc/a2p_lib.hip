@@ -150,8 +150,9 @@ struct A2POpts {
   int graph = 0;            // A2P_GRAPH=1: non-chain forwards replay a captured graph instead of stream launches (measured: same GPU
                             // time per step -- the launches are not host-bound -- at a tenth of the host time; off by default)
   int no_small = 0;         // A2P_NO_SMALL=1: per-op kernels for forwards below 960 rows instead of kernels_small.h
-  int chain_rows = 1280;    // A2P_CHAIN_ROWS=n: forwards of at least n rows take the chain kernels (measured crossover against the small-forward
-                            // GEMMs of kernels_small.h: 1192 vs 1002 steps/s at 960 rows, 804 vs 1018 at 1920)
+  int chain_rows = 1100;    // A2P_CHAIN_ROWS=n: forwards of at least n rows take the chain kernels.  Measured against the small-forward kernels
+                            // (profiles/r03_ksplit_ab.txt): 960 rows (2 x 2 x 240) small 1192 vs chain 1002 steps/s; 1200 rows (2 x 600 frames, 2000
+                            // keys) 761 vs 878; 1440 (2 x 3 x 240) 939 vs 1022; 1920: 798 vs 1020; 2400: 488 vs 870
 };
 static void load_opts(A2POpts& o) {
   auto flag = [](const char* n) { return getenv(n) != nullptr ? 1 : 0; };
@@ -163,7 +164,7 @@ static void load_opts(A2POpts& o) {
   o.side_early_join = flag("A2P_SIDE_EARLY_JOIN"); o.no_shared_half = flag("A2P_NO_SHARED_HALF");
   o.graph = flag("A2P_GRAPH");
   o.no_ksplit = flag("A2P_NO_KSPLIT"); o.force_ksplit = flag("A2P_ATTN_KSPLIT"); o.ksplit_nw = num("A2P_KSPLIT_NW", 0); o.ksplit_qt = num("A2P_KSPLIT_QT", 0);
-  o.no_small = flag("A2P_NO_SMALL"); o.chain_rows = num("A2P_CHAIN_ROWS", 1280);
+  o.no_small = flag("A2P_NO_SMALL"); o.chain_rows = num("A2P_CHAIN_ROWS", 1100);
 }
 
 struct a2p_ctx {

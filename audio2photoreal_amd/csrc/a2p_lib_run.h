@@ -538,7 +538,7 @@ static int decoder_layer(a2p_ctx* c, int l, int N, int T, const CrossKV& kv, con
 }
 
 // ------------------------------------------------------------------------------------------------
-// small forwards (16-bit modes, below A2POpts::chain_rows = 1280 rows, face model): whole-K-resident small-tile GEMMs with the LayerNorm fused into the A
+// small forwards (16-bit modes, below A2POpts::chain_rows = 1100 rows, face model): whole-K-resident small-tile GEMMs with the LayerNorm fused into the A
 // load (kernels_small.h): 8 launches per decoder layer instead of 12
 // ------------------------------------------------------------------------------------------------
 static bool small_supported(const a2p_ctx* c) {

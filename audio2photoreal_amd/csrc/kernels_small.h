@@ -1,4 +1,4 @@
-// Small-problem GEMMs of the decoder layer (16-bit modes, forwards of fewer than 1280 rows: BASELINE configs[0] is 480 rows).
+// Small-problem GEMMs of the decoder layer (16-bit modes, forwards of fewer than 1100 rows: BASELINE configs[0] is 480 rows).
 //
 // A 480-row forward does not fill the chip with row panels (10 panels of 48 rows; a chain workgroup's time does not depend on how
 // many panels there are) and as per-operation launches it is 111 dependent kernels of 4-12 us, none of which is long enough to

@@ -151,8 +151,8 @@ def kernel_breakdown(case, ksteps):
     from audio2photoreal_amd import _lib
     lib = case.model._lib()
     flops = algorithmic_flops(case.spec, case.T, case.S0 + 2, 2 * case.B)
-    # the decoder-layer GEMMs run inside the fused "chain" kernels (16-bit modes at >= 1280 rows) or as separate GEMM launches (fp32
-    # mode, A2P_NO_CHAIN=1, the small-forward kernels below 1280 rows): the FLOPs go to whichever class actually launched (below)
+    # the decoder-layer GEMMs run inside the fused "chain" kernels (16-bit modes at >= 1100 rows) or as separate GEMM launches (fp32
+    # mode, A2P_NO_CHAIN=1, the small-forward kernels below 1100 rows): the FLOPs go to whichever class actually launched (below)
     dec_gemm = flops.pop("decoder_gemm")
     kernels = {}
     for name, kind in (("chain", _lib.KERNEL_CHAIN), ("gemm", _lib.KERNEL_GEMM), ("attn_self", _lib.KERNEL_ATTN_SELF),

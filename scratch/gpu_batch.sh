@@ -1,20 +1,24 @@
 #!/bin/bash
-# The command list of the current gpurun call (one evolving script; git history keeps the earlier lists).
 cd "$GRAFT_REPO_ROOT" 2>/dev/null || cd /root/repo
 mkdir -p gpurun_out
-export TMPDIR=/tmp
-TAG=${1:-f7}
-t0=$(date +%s)
-timeout -k 5 900 python bench.py --write-parity gpurun_out/${TAG}_parity.json > gpurun_out/${TAG}_bench.json 2> gpurun_out/${TAG}_bench.err; echo "bench rc=$? in $(( $(date +%s) - t0 )) s"
-python - <<PY
+B="python bench.py --steps 100 --warmup 10 --no-cpu-baseline --no-parity --no-legs --no-kernel-timing"
+run() {
+  local tag=$1; shift
+  timeout -k 5 200 env "$@" > gpurun_out/b24_$tag.json 2> gpurun_out/b24_$tag.err
+  python - <<PY
 import json
 try:
-    r = json.loads(open("gpurun_out/${TAG}_bench.json").read().strip().splitlines()[-1])
-    print("headline", r["value"], r["ms_per_step"], r["steps"], r["warmup"], "roofline", r["roofline"]["frac"], "cpu", r["cpu_baseline"]["value"], r["cpu_baseline"].get("reference_as_is", {}))
-    for k, v in r.get("legs", {}).items(): print("  leg", k, v.get("value"), v.get("ms_per_step"), (v.get("roofline") or {}).get("kernel"), (v.get("roofline") or {}).get("frac"))
-    print("parity bar", r["parity"]["bar"])
+    r = json.loads(open("gpurun_out/b24_$tag.json").read().strip().splitlines()[-1])
+    print("$tag", r["value"], r["ms_per_step"])
 except Exception as e:
-    print("bench parse failed", e)
+    print("$tag failed", e); print(open("gpurun_out/b24_$tag.err").read()[-600:])
 PY
-timeout -k 5 800 python -m pytest tests -m gpu -q > gpurun_out/${TAG}_tests.log 2>&1; echo "tests rc=$?"; tail -3 gpurun_out/${TAG}_tests.log | cut -c1-160
-cp gpurun_out/parity_tests.json gpurun_out/${TAG}_parity_tests.json
+}
+run r1200_small A2P_X=0 $B --batch 1 --frames 600
+run r1200_chain A2P_CHAIN_ROWS=1 $B --batch 1 --frames 600
+run r1440_small A2P_CHAIN_ROWS=99999 $B --batch 3 --frames 240
+run r1440_chain A2P_X=0 $B --batch 3 --frames 240
+run r1920_small A2P_CHAIN_ROWS=99999 $B --batch 4 --frames 240
+run r1920_chain A2P_X=0 $B --batch 4 --frames 240
+run r2400_small A2P_CHAIN_ROWS=99999 $B --batch 2 --frames 600
+run r2400_chain A2P_X=0 $B --batch 2 --frames 600
