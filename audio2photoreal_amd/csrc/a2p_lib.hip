@@ -27,6 +27,7 @@
 #include "kernels_attn.h"
 #include "kernels_chain.h"
 #include "kernels_chain2.h"
+#include "kernels_chain3.h"
 #include "kernels_gemm.h"
 #include "kernels_misc.h"
 #include "kernels_small.h"

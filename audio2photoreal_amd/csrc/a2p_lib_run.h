@@ -149,6 +149,11 @@ static int chain_pack(a2p_ctx* c, int idx, const std::vector<ChainPackDesc>& des
     chain2_pack_kernel<<<(int)d2.size(), 256, 0, s>>>(dev, reinterpret_cast<h16_t*>(st.p));
     c->ch_nstages[idx] = (int)d2.size();
   }
+  {  // third-generation kernels (kernels_chain3.h): MFMA operands for direct global loads under the 4-wave column map
+    Buf& st = c->ch_stream[(size_t)3 * c->L * 4 + idx];
+    CHK(buf_alloc(st, (descs.size() + pad) * CHAIN_STAGE_ELEMS * 2));
+    chain3_pack_kernel<<<(int)descs.size(), 256, 0, s>>>(reinterpret_cast<const ChainPackDesc*>(dd.p), reinterpret_cast<h16_t*>(st.p));
+  }
   HIPCHK(hipGetLastError());
   Buf& ax = c->ch_aux[idx];
   CHK(buf_alloc(ax, 2560 * 4 + 1024));
@@ -166,8 +171,8 @@ static int chain_pack(a2p_ctx* c, int idx, const std::vector<ChainPackDesc>& des
 // pre-pack every chain's weight stream in consumption order (called from a2p_finalize_weights)
 static int chain_build_streams(a2p_ctx* c, hipStream_t s) {
   const int d = c->d, ff = c->ff, L = c->L;
-  if (c->ch_stream.size() != (size_t)L * 12) {  // first build; later builds (weight updates) refill the same buffers
-    c->ch_stream.assign((size_t)L * 12, Buf());
+  if (c->ch_stream.size() != (size_t)L * 16) {  // first build; later builds (weight updates) refill the same buffers
+    c->ch_stream.assign((size_t)L * 16, Buf());
     c->ch_aux.assign((size_t)L * 4, Buf());
     c->ch_nstages.assign((size_t)L * 4, 0);
   }
@@ -219,7 +224,7 @@ static void chain_base(a2p_ctx* c, ChainP& p, int N, int T, int idx, int aux_flo
   memset(&p, 0, sizeof(p));
   p.M = N * T; p.rows_per_seq = T; p.x = c->x.f(); p.cst = reinterpret_cast<const f32x4*>(c->rope_cst.p); p.cs_npos = c->rope_npos;
   p.ain = reinterpret_cast<const h16_t*>(c->ao.p); p.ld_ain = c->d;
-  p.stream = reinterpret_cast<const h16_t*>(c->ch_stream[(size_t)(c->ch_ver == 2 ? 2 : (c->ch_nw == 8)) * c->L * 4 + idx].p);
+  p.stream = reinterpret_cast<const h16_t*>(c->ch_stream[(size_t)(c->ch_ver >= 2 ? c->ch_ver : (c->ch_nw == 8)) * c->L * 4 + idx].p);
   p.aux = c->ch_aux[idx].f(); p.aux_kb = (aux_floats + 255) / 256;
   if (c->ch_ver == 2) {   // stream leaders (kernels_chain2.h): one workgroup per XCD walks the weight stream ahead of the consumers
     // off by default: -14 % kernel time when L2 and MALL are cold (scratch/chain2_bench), nothing inside the step
@@ -339,16 +344,46 @@ static int launch_chain2(a2p_ctx* c, int mode, const ChainP& p, hipStream_t s) {
   return 0;
 }
 
+// Third-generation chain kernels (kernels_chain3.h): 4 waves of <= 256 registers and <= 80 KiB of LDS per workgroup, TWO
+// workgroups per CU.  Panel height: 48 rows at d = 512 (the 96 linear2 accumulators of a 4-wave workgroup bound it), 64 at d = 256.
+static int launch_chain3(a2p_ctx* c, int mode, const ChainP& p, hipStream_t s) {
+  int mt = c->opt.chain_mt;
+  const int lo = 2, hi = c->d == 512 ? 3 : 5;
+  if (mt < lo || mt > hi) mt = c->d == 512 ? 3 : 4;
+  const int grid = (p.M + 16 * mt - 1) / (16 * mt);
+  KernelTimer kt(c, A2P_KERNEL_CHAIN);
+#define A2P_CHAIN3(D, MT)                                                                               \
+  do {                                                                                                  \
+    if (mode == CHAIN_PRE) A2P_LAUNCH(kt, (chain3_kernel<D, MT, CHAIN_PRE>), grid, 256, s, p);          \
+    else if (mode == CHAIN_MID) A2P_LAUNCH(kt, (chain3_kernel<D, MT, CHAIN_MID>), grid, 256, s, p);     \
+    else A2P_LAUNCH(kt, (chain3_kernel<D, MT, CHAIN_POST>), grid, 256, s, p);                           \
+  } while (0)
+  if (c->d == 512) {
+    if (mt == 2) A2P_CHAIN3(512, 2);
+    else A2P_CHAIN3(512, 3);
+  } else {
+    if (mt == 2) A2P_CHAIN3(256, 2);
+    else if (mt == 3) A2P_CHAIN3(256, 3);
+    else if (mt == 4) A2P_CHAIN3(256, 4);
+    else A2P_CHAIN3(256, 5);
+  }
+#undef A2P_CHAIN3
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
 // Chain kernel generation for a forward of T-frame sequences: 1 (kernels_chain.h) unless A2P_CHAIN_V=2 asks for the round-3
 // restructure (kernels_chain2.h: bit-identical, measured equal at 48-row panels and slower at 80 -- DESIGN.md section 4.1b),
 // which does not implement final_layer fused into the last POST kernel (A2P_TAIL16) nor frame counts that are not a multiple
 // of 8 (only the staged V^T store: 8 frames per 16-byte piece)
 static int chain_pick_ver(const a2p_ctx* c, int T) {
-  return (c->opt.chain_v != 2 || (!c->tail32 && !c->pose) || (T & 7)) ? 1 : 2;
+  if ((c->opt.chain_v != 2 && c->opt.chain_v != 3) || (!c->tail32 && !c->pose) || (T & 7)) return 1;
+  return c->opt.chain_v;
 }
 
 static int launch_chain(a2p_ctx* c, int mode, const ChainP& p, hipStream_t s) {
   if (c->ch_ver == 2) return launch_chain2(c, mode, p, s);
+  if (c->ch_ver == 3) return launch_chain3(c, mode, p, s);
   const bool env_mt = c->opt.chain_mt != 0;  // tuning / test override of the panel height (rows = 16 * MT)
   int mt = c->opt.chain_mt;
   // panel heights instantiated per width (LDS: the [16*MT][d] bf16 panel + hidden chunk + >= 3 ring slots must fit 160 KiB)

@@ -77,6 +77,39 @@ def test_generation2_chain_kernels_are_bit_identical_to_generation1(dev, fmt, B,
 
 
 @pytest.mark.parametrize("precision", ["bf16", "fp16"])
+@pytest.mark.parametrize("fmt,B,T", [("face", 2, 240), ("face", 3, 152), ("face", 8, 600), ("face", 5, 592), ("pose", 3, 208), ("pose", 16, 600),
+                                     ("pose", 4, 456)])
+def test_generation3_chain_kernels_are_bit_identical_to_generation1(dev, fmt, B, T, precision, monkeypatch):
+    """kernels_chain3.h (round 4: 4-wave workgroups of <= 256 registers and <= 80 KiB of LDS, two per CU, weights straight into
+    VGPRs through a buffer descriptor) keeps generation 1's column ownership, per-element accumulation order, 8-partial LayerNorm
+    tree and epilogue arithmetic: the guided forward must equal kernels_chain.h's to the last bit, for every panel height it is
+    instantiated for, ragged last panels and panels that straddle sequences (T = 152, 208, 592; frame counts are multiples of 8:
+    others take generation 1 on the host)."""
+    spec, model = _model(fmt, precision, dev, B)
+    cfg = ClassifierFreeSampleModel(model)
+    x, t, y = _inputs(spec, fmt, B, T, dev)
+    monkeypatch.setenv("A2P_CHAIN_MT", "3")            # both generations take the chain path at every size of this test
+    monkeypatch.setenv("A2P_CHAIN_V", "1")
+    monkeypatch.setenv("A2P_CHAIN_NW", "4")
+    want = cfg(x, t, y).clone()
+    monkeypatch.delenv("A2P_CHAIN_NW")
+    monkeypatch.setenv("A2P_CHAIN_V", "3")
+    assert torch.isfinite(want).all()
+    worst = 0.0
+    for mt in ["2", "3"] + (["4", "5"] if fmt == "pose" else []):
+        monkeypatch.setenv("A2P_CHAIN_MT", mt)
+        got = cfg(x, t, y)
+        d = float((got - want).abs().max())
+        worst = max(worst, d)
+        assert torch.equal(got, want), f"generation 3, {16 * int(mt)}-row panels: max |diff| = {d:.3e}"
+    if 2 * B * T >= 1100:                                # generation 3 at the panel height its host code picks
+        monkeypatch.delenv("A2P_CHAIN_MT")
+        assert torch.equal(cfg(x, t, y), want)
+    record(f"gen3_vs_gen1/{precision}/{fmt}_B{B}_T{T}", max_abs_diff=worst)
+    model.release()
+
+
+@pytest.mark.parametrize("precision", ["bf16", "fp16"])
 @pytest.mark.parametrize("fmt,B,T", [("face", 8, 600), ("pose", 16, 600)])
 def test_generation2_layer0_shared_half_equals_the_duplicated_path(dev, fmt, B, T, precision, monkeypatch):
     """Layer 0 under guidance runs norm1 / Q,K,V / the self attention once for both halves; the MID kernel of the second half reads
