@@ -33,7 +33,7 @@ EXPORTS = (
     "a2p_ctx_create", "a2p_ctx_destroy", "a2p_last_error", "a2p_version", "a2p_set_weight", "a2p_finalize_weights",
     "a2p_prepare_cond", "a2p_denoise_forward", "a2p_sample_step", "a2p_p_mean_variance", "a2p_ddim_update",
     "a2p_p_sample_update", "a2p_q_sample", "a2p_eps_from_xstart", "a2p_plms_update", "a2p_ddim_reverse_update", "a2p_decoder_layer_forward", "a2p_gemm", "a2p_attention",
-    "a2p_kernel_timing", "a2p_kernel_time_ms", "a2p_debug_read", "a2p_reload_env", "a2p_set_batch_hint",
+    "a2p_kernel_timing", "a2p_kernel_time_ms", "a2p_debug_read", "a2p_reload_env", "a2p_set_batch_hint", "a2p_check_finite",
     "a2p_guide_create", "a2p_guide_destroy", "a2p_guide_set_weight", "a2p_guide_finalize", "a2p_guide_prepare",
     "a2p_guide_forward", "a2p_guide_generate", "a2p_guide_debug_read", "a2p_vq_decode",
     "a2p_frontend_create", "a2p_frontend_destroy", "a2p_frontend_set_weight", "a2p_frontend_finalize",
@@ -105,6 +105,7 @@ def load(half: bool = False) -> C.CDLL:
         "a2p_debug_read": [vp, C.c_char_p, vp, i64],
         "a2p_reload_env": [vp],
         "a2p_set_batch_hint": [vp, i32],
+        "a2p_check_finite": [vp, vp],
         "a2p_guide_create": [C.POINTER(A2PGuideConfig), C.POINTER(vp)],
         "a2p_guide_destroy": [vp],
         "a2p_guide_set_weight": [vp, C.c_char_p, vp, i64, vp],
@@ -149,7 +150,7 @@ def check(rc: int, what: str) -> int:
 
 
 # the environment switches a context caches (csrc/a2p_lib.hip A2POpts); changing one after context creation takes a2p_reload_env
-ENV_SWITCHES = ("A2P_KV_CACHED", "A2P_NO_CHAIN", "A2P_CHAIN_NW", "A2P_CHAIN_MT", "A2P_CHAIN_V", "A2P_CHAIN_NO_MIX", "A2P_TUNE_VERBOSE",
+ENV_SWITCHES = ("A2P_KV_CACHED", "A2P_NO_CHAIN", "A2P_CHAIN_NW", "A2P_CHAIN_MT", "A2P_CHAIN_TUNE", "A2P_CHAIN_NO_MIX", "A2P_TUNE_VERBOSE",
                 "A2P_SIDE_JOIN", "A2P_CHAIN_X_ROWMAJOR", "A2P_NO_SIDE_STREAM", "A2P_SIDE_EARLY_JOIN", "A2P_NO_SHARED_HALF", "A2P_NO_SMALL", "A2P_CHAIN_ROWS",
                 "A2P_NO_KSPLIT", "A2P_ATTN_KSPLIT", "A2P_KSPLIT_NW", "A2P_KSPLIT_QT", "A2P_GRAPH")
 

@@ -26,8 +26,6 @@
 #include "../../include/a2p_hip.h"
 #include "kernels_attn.h"
 #include "kernels_chain.h"
-#include "kernels_chain2.h"
-#include "kernels_chain3.h"
 #include "kernels_gemm.h"
 #include "kernels_misc.h"
 #include "kernels_small.h"
@@ -135,8 +133,8 @@ struct A2POpts {
   int kv_cached = 0;        // A2P_KV_CACHED=1: default cache policy for the cached audio K/V (A/B)
   int no_chain = 0;         // A2P_NO_CHAIN=1: per-op kernels instead of the chain kernels
   int chain_nw = 0;         // A2P_CHAIN_NW=4|8: force the generation-1 workgroup shape (0: measured per box)
+  int chain_tune = 0;       // A2P_CHAIN_TUNE=1: measure the 4- vs 8-wave chain workgroup shape in situ (round 3's default); 0: 8 waves
   int chain_mt = 0;         // A2P_CHAIN_MT=n: force the panel height 16*n (also takes the chain path below 960 rows)
-  int chain_v = 0;          // A2P_CHAIN_V=1|2: chain kernel generation (0: default)
   int chain_no_mix = 0;     // A2P_CHAIN_NO_MIX=1: uniform panel heights
   int tune_verbose = 0;     // A2P_TUNE_VERBOSE=1: print the per-box shape decision
   int side_join = 3;        // A2P_SIDE_JOIN: where the main stream joins the side stream (1 PRE, 2 self attention, 3 MID)
@@ -159,8 +157,8 @@ static void load_opts(A2POpts& o) {
   auto flag = [](const char* n) { return getenv(n) != nullptr ? 1 : 0; };
   auto num = [](const char* n, int dflt) { const char* v = getenv(n); return v ? atoi(v) : dflt; };
   o.kv_cached = flag("A2P_KV_CACHED"); o.no_chain = flag("A2P_NO_CHAIN");
-  o.chain_nw = num("A2P_CHAIN_NW", 0); o.chain_mt = num("A2P_CHAIN_MT", 0); o.chain_v = num("A2P_CHAIN_V", 0);
-  o.chain_no_mix = flag("A2P_CHAIN_NO_MIX"); o.tune_verbose = flag("A2P_TUNE_VERBOSE"); o.side_join = num("A2P_SIDE_JOIN", 3);
+  o.chain_nw = num("A2P_CHAIN_NW", 0); o.chain_mt = num("A2P_CHAIN_MT", 0);
+  o.chain_no_mix = flag("A2P_CHAIN_NO_MIX"); o.chain_tune = flag("A2P_CHAIN_TUNE"); o.tune_verbose = flag("A2P_TUNE_VERBOSE"); o.side_join = num("A2P_SIDE_JOIN", 3);
   o.x_rowmajor = flag("A2P_CHAIN_X_ROWMAJOR"); o.no_side_stream = flag("A2P_NO_SIDE_STREAM");
   o.side_early_join = flag("A2P_SIDE_EARLY_JOIN"); o.no_shared_half = flag("A2P_NO_SHARED_HALF");
   o.graph = flag("A2P_GRAPH");
@@ -194,17 +192,15 @@ struct a2p_ctx {
   Buf cak_w32, cak_b, cav_w32, cav_b, cak_wt, cav_wt;
   Buf ca2k_wt, ca2v_wt, ca2k_b, ca2v_b;
   Buf conv_wt[7];
-  std::vector<Buf> ch_stream, ch_aux;  // packed weight streams [layout * L*4 + layer*4 + kind] (layout 0: 4-wave LDS slices, 1: 8-wave, 2: direct
-                                       // MFMA operands of kernels_chain2.h) / bias blocks [layer*4 + kind]
-  std::vector<int> ch_nstages;          // stages of the generation-2 stream [layer*4 + kind] (stream leaders walk exactly these)
+  std::vector<Buf> ch_stream, ch_aux;  // packed weight streams [layout * L*4 + layer*4 + kind] (layout 0: 4-wave LDS slices, 1: 8-wave) / bias blocks [layer*4 + kind]
   int ch_nw = 4;                       // waves per chain workgroup of the forward being enqueued (4 or 8; chain_pick_nw)
-  int ch_ver = 2;                      // chain kernel generation of the forward being enqueued: 2 = kernels_chain2.h, 1 = kernels_chain.h
   struct ChainTune {                   // per forward size (rows): which workgroup shape is faster ON THIS BOX, measured in situ
     int choice = 0, calls = 0;
     std::vector<std::tuple<int, hipEvent_t, hipEvent_t>> samples;
   };
   std::map<int64_t, ChainTune> ch_tune;
   Buf hidden, kc, vtc, k2c, vt2c, slot_cond, slot_unc, slot_cfg;
+  Buf nonfinite;         // device flag of a2p_check_finite (one int, OR-ed by step_tail_kernel)
   Buf clk;               // A2P_CHAIN_CLK=1: 64 chain launches x 8 blocks x {memtime, realtime} x {begin, end}
   unsigned clk_turn = 0;
   int pB = 0, pS0 = 0, pT = 0, pK = 0;
@@ -594,7 +590,7 @@ extern "C" int a2p_ctx_create(const a2p_config* cfg, a2p_ctx** out) {
     A(c->k2c, (size_t)(B + 1) * 64 * c->L * d * c->esz); A(c->vt2c, (size_t)(B + 1) * c->L * d * 64 * c->esz);
     A(c->kf_pack, (size_t)B * c->KFmax * c->KdPad * c->esz); A(c->kf_tok, (size_t)B * c->KFmax * d * 4);
   }
-  A(c->slot_cond, B * 4); A(c->slot_unc, B * 4); A(c->slot_cfg, N * 4);
+  A(c->slot_cond, B * 4); A(c->slot_unc, B * 4); A(c->slot_cfg, N * 4); A(c->nonfinite, 64);
   if (getenv("A2P_CHAIN_CLK")) A(c->clk, 64 * 32 * 8 + 2 * 64 * 8);   // + phase stamps of the diagnostic build (-DA2P_STAMPS)
   if (rc == 0 && hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking) != hipSuccess) rc = A2P_ERR_HIP;
   for (int i = 0; i < 8 && rc == 0; ++i)
@@ -636,7 +632,7 @@ extern "C" int a2p_ctx_destroy(a2p_ctx* c) {
                 &c->k2c, &c->vt2c, &c->slot_cond, &c->slot_unc, &c->slot_cfg, &c->x, &c->xn, &c->xr, &c->qk, &c->vt, &c->ao,
                 &c->hff, &c->inpack, &c->mo, &c->cb[0], &c->cb[1], &c->cb[2], &c->cb[3], &c->emb, &c->th, &c->tct, &c->tvec,
                 &c->mt, &c->tokn, &c->tokr, &c->film, &c->ktail, &c->vtail, &c->ce_pack, &c->pooled, &c->tmpa, &c->tmpb,
-                &c->kf_pack, &c->kf_tok, &c->clk, &c->t3};
+                &c->kf_pack, &c->kf_tok, &c->clk, &c->t3, &c->nonfinite};
   for (Buf* b : all) buf_free(*b);
   for (int i = 0; i < 7; ++i) buf_free(c->conv_wt[i]);
   for (auto& b : c->ch_stream) buf_free(b);

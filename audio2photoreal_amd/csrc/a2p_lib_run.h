@@ -124,7 +124,7 @@ static void pk_gemm(std::vector<ChainPackDesc>& v, const void* W, int ldw, int n
 }
 
 static int chain_pack(a2p_ctx* c, int idx, const std::vector<ChainPackDesc>& descs, const std::vector<std::pair<const float*, int>>& aux,
-                      hipStream_t s, const std::vector<ChainPackDesc>* descs_gen2 = nullptr) {
+                      hipStream_t s) {
   const size_t pad = CHAIN_STREAM_PAD;  // the DMA runs up to NS-1 (<= 5) stages past the end
   Buf dd;
   CHK(buf_alloc_tmp(dd, descs.size() * sizeof(ChainPackDesc)));
@@ -133,26 +133,6 @@ static int chain_pack(a2p_ctx* c, int idx, const std::vector<ChainPackDesc>& des
     Buf& st = c->ch_stream[(size_t)w8 * c->L * 4 + idx];
     CHK(buf_alloc(st, (descs.size() + pad) * CHAIN_STAGE_ELEMS * 2));
     chain_pack_kernel<<<(int)descs.size(), 256, 0, s>>>(reinterpret_cast<const ChainPackDesc*>(dd.p), reinterpret_cast<h16_t*>(st.p), w8 ? 8 : 4);
-  }
-  Buf dd2;
-  {  // second-generation kernels (kernels_chain2.h): the same stages (POST: in the software-pipelined order `descs_gen2`) as MFMA
-     // operands for direct global loads
-    const std::vector<ChainPackDesc>& d2 = descs_gen2 ? *descs_gen2 : descs;
-    const ChainPackDesc* dev = reinterpret_cast<const ChainPackDesc*>(dd.p);
-    if (descs_gen2) {
-      CHK(buf_alloc_tmp(dd2, d2.size() * sizeof(ChainPackDesc)));
-      HIPCHK(hipMemcpyAsync(dd2.p, d2.data(), d2.size() * sizeof(ChainPackDesc), hipMemcpyHostToDevice, s));
-      dev = reinterpret_cast<const ChainPackDesc*>(dd2.p);
-    }
-    Buf& st = c->ch_stream[(size_t)2 * c->L * 4 + idx];
-    CHK(buf_alloc(st, (d2.size() + pad) * CHAIN_STAGE_ELEMS * 2));
-    chain2_pack_kernel<<<(int)d2.size(), 256, 0, s>>>(dev, reinterpret_cast<h16_t*>(st.p));
-    c->ch_nstages[idx] = (int)d2.size();
-  }
-  {  // third-generation kernels (kernels_chain3.h): MFMA operands for direct global loads under the 4-wave column map
-    Buf& st = c->ch_stream[(size_t)3 * c->L * 4 + idx];
-    CHK(buf_alloc(st, (descs.size() + pad) * CHAIN_STAGE_ELEMS * 2));
-    chain3_pack_kernel<<<(int)descs.size(), 256, 0, s>>>(reinterpret_cast<const ChainPackDesc*>(dd.p), reinterpret_cast<h16_t*>(st.p));
   }
   HIPCHK(hipGetLastError());
   Buf& ax = c->ch_aux[idx];
@@ -164,17 +144,15 @@ static int chain_pack(a2p_ctx* c, int idx, const std::vector<ChainPackDesc>& des
   }
   HIPCHK(hipStreamSynchronize(s));  // descs is host memory of the caller
   buf_free(dd);
-  buf_free(dd2);
   return 0;
 }
 
 // pre-pack every chain's weight stream in consumption order (called from a2p_finalize_weights)
 static int chain_build_streams(a2p_ctx* c, hipStream_t s) {
   const int d = c->d, ff = c->ff, L = c->L;
-  if (c->ch_stream.size() != (size_t)L * 16) {  // first build; later builds (weight updates) refill the same buffers
-    c->ch_stream.assign((size_t)L * 16, Buf());
+  if (c->ch_stream.size() != (size_t)L * 8) {  // first build; later builds (weight updates) refill the same buffers
+    c->ch_stream.assign((size_t)L * 8, Buf());
     c->ch_aux.assign((size_t)L * 4, Buf());
-    c->ch_nstages.assign((size_t)L * 4, 0);
   }
   auto pf = [&](int l) { return "seqTransDecoder.stack." + std::to_string(l) + "."; };
   auto add_pre = [&](std::vector<ChainPackDesc>& v, int l) {  // [Q|K] then V of layer l's self attention
@@ -224,14 +202,8 @@ static void chain_base(a2p_ctx* c, ChainP& p, int N, int T, int idx, int aux_flo
   memset(&p, 0, sizeof(p));
   p.M = N * T; p.rows_per_seq = T; p.x = c->x.f(); p.cst = reinterpret_cast<const f32x4*>(c->rope_cst.p); p.cs_npos = c->rope_npos;
   p.ain = reinterpret_cast<const h16_t*>(c->ao.p); p.ld_ain = c->d;
-  p.stream = reinterpret_cast<const h16_t*>(c->ch_stream[(size_t)(c->ch_ver >= 2 ? c->ch_ver : (c->ch_nw == 8)) * c->L * 4 + idx].p);
+  p.stream = reinterpret_cast<const h16_t*>(c->ch_stream[(size_t)(c->ch_nw == 8) * c->L * 4 + idx].p);
   p.aux = c->ch_aux[idx].f(); p.aux_kb = (aux_floats + 255) / 256;
-  if (c->ch_ver == 2) {   // stream leaders (kernels_chain2.h): one workgroup per XCD walks the weight stream ahead of the consumers
-    // off by default: -14 % kernel time when L2 and MALL are cold (scratch/chain2_bench), nothing inside the step
-    static const int leaders = getenv("A2P_CHAIN_LEADERS") ? atoi(getenv("A2P_CHAIN_LEADERS")) : 0;
-    static const int pfw = getenv("A2P_CHAIN_PFW") ? atoi(getenv("A2P_CHAIN_PFW")) : 2;
-    p.n_pf = leaders; p.pf_waves = pfw; p.n_stages = c->ch_nstages[idx];
-  }
   if (c->clk.p) {  // A2P_CHAIN_CLK=1: every chain launch of a forward gets its own 8 x 4 slot (a2p_debug_read "clk")
 #ifdef A2P_STAMPS   // diagnostic build (scratch/phase_probe.py): launch A2P_STAMP_LAUNCH of every forward writes its phase stamps behind the clk slots
     static const int sel = getenv("A2P_STAMP_LAUNCH") ? atoi(getenv("A2P_STAMP_LAUNCH")) : 4;
@@ -267,10 +239,18 @@ static void chain_set_out_proj(a2p_ctx* c, ChainP& p, const std::string& attn, c
 // minority the 512-register kernels run 35 % slower inside the step (not in isolation) and NW=8 leads by 19 % (DESIGN.md
 // section 6).  So it is measured in situ: forwards 1..4 of a given size alternate the two shapes with an event pair around
 // the decoder stack (forward 0 is warm-up), forward 5 picks the faster average and the choice sticks.  A2P_CHAIN_NW=4|8 forces.
+// Round 4: the in-situ measurement is OPT-IN (A2P_CHAIN_TUNE=1).  The default is the 8-wave shape everywhere: deterministic per
+// process and per rank (round 3's tuner timed 4 forwards per size and box: run-to-run noise decided close calls, and the ranks of
+// one job could disagree), immune to the slow-box regime, and the only shape with mixed panel heights at B=32; what it gives up is
+// the 4-wave shape's 3-5 % at B=8 on the boxes where that shape runs well.
 static const int kTuneForwards = 5;
 static int chain_pick_nw(a2p_ctx* c, int64_t rows, hipEvent_t* e0, hipEvent_t* e1) {
   *e0 = *e1 = nullptr;
   if (c->opt.chain_nw) return c->opt.chain_nw == 8 ? 8 : 4;
+  if (!c->opt.chain_tune) {
+    const int mt = c->opt.chain_mt;
+    return (mt && ((mt > 4 && c->d == 512) || mt > 5)) ? 4 : 8;   // forced panel heights the 8-wave kernels do not have
+  }
   if (c->opt.chain_mt) {  // a forced panel height the 8-wave kernels do not have
     const int mt = c->opt.chain_mt;
     if ((mt > 4 && c->d == 512) || mt > 5) return 4;
@@ -303,87 +283,7 @@ static int chain_pick_nw(a2p_ctx* c, int64_t rows, hipEvent_t* e0, hipEvent_t* e
   return t.choice;
 }
 
-// Second-generation chain kernels (kernels_chain2.h): weights straight into VGPRs, 8 waves, panels of up to 96 rows.
-// Panel height: fewest rounds over the 256 CUs, then the cheaper panel.  A workgroup's time is a fixed part (prologue, barriers,
-// drain) + a per-stage part that is flat up to 64 rows (the 64 B/clk weight path: 256 cycles per stage) and MFMA-bound beyond
-// (64 cycles per 16 rows) + epilogues that grow with the rows (scratch/tall_probe, profiles/r03_tall_probe.txt).
-static int launch_chain2(a2p_ctx* c, int mode, const ChainP& p, hipStream_t s) {
-  int mt = c->opt.chain_mt;
-  const int lo = 2, hi = c->d == 512 ? 5 : 6;
-  if (mt < lo || mt > hi) {
-    float best = 1e30f;
-    for (int m = lo; m <= hi; ++m) {
-      const int blocks = (p.M + 16 * m - 1) / (16 * m);
-      const int cus = 256 - p.n_pf;   // the stream leaders hold one CU each
-      const float cost = (float)((blocks + cus - 1) / cus) * ((m > 4 ? (float)m : 4.0f) + 0.6f * (float)m + 2.0f);
-      if (cost < best) { best = cost; mt = m; }
-    }
-  }
-  const int grid = (p.M + 16 * mt - 1) / (16 * mt) + p.n_pf;   // the leaders come first: block b runs on XCD b % 8 from the start
-  KernelTimer kt(c, A2P_KERNEL_CHAIN);
-#define A2P_CHAIN2(D, MT)                                                                               \
-  do {                                                                                                  \
-    if (mode == CHAIN_PRE) A2P_LAUNCH(kt, (chain2_kernel<D, MT, CHAIN_PRE>), grid, 512, s, p);          \
-    else if (mode == CHAIN_MID) A2P_LAUNCH(kt, (chain2_kernel<D, MT, CHAIN_MID>), grid, 512, s, p);     \
-    else A2P_LAUNCH(kt, (chain2_kernel<D, MT, CHAIN_POST>), grid, 512, s, p);                           \
-  } while (0)
-  if (c->d == 512) {
-    if (mt == 2) A2P_CHAIN2(512, 2);
-    else if (mt == 3) A2P_CHAIN2(512, 3);
-    else if (mt == 4) A2P_CHAIN2(512, 4);
-    else A2P_CHAIN2(512, 5);
-  } else {
-    if (mt == 2) A2P_CHAIN2(256, 2);
-    else if (mt == 3) A2P_CHAIN2(256, 3);
-    else if (mt == 4) A2P_CHAIN2(256, 4);
-    else if (mt == 5) A2P_CHAIN2(256, 5);
-    else A2P_CHAIN2(256, 6);
-  }
-#undef A2P_CHAIN2
-  HIPCHK(hipGetLastError());
-  return 0;
-}
-
-// Third-generation chain kernels (kernels_chain3.h): 4 waves of <= 256 registers and <= 80 KiB of LDS per workgroup, TWO
-// workgroups per CU.  Panel height: 48 rows at d = 512 (the 96 linear2 accumulators of a 4-wave workgroup bound it), 64 at d = 256.
-static int launch_chain3(a2p_ctx* c, int mode, const ChainP& p, hipStream_t s) {
-  int mt = c->opt.chain_mt;
-  const int lo = 2, hi = c->d == 512 ? 3 : 5;
-  if (mt < lo || mt > hi) mt = c->d == 512 ? 3 : 4;
-  const int grid = (p.M + 16 * mt - 1) / (16 * mt);
-  KernelTimer kt(c, A2P_KERNEL_CHAIN);
-#define A2P_CHAIN3(D, MT)                                                                               \
-  do {                                                                                                  \
-    if (mode == CHAIN_PRE) A2P_LAUNCH(kt, (chain3_kernel<D, MT, CHAIN_PRE>), grid, 256, s, p);          \
-    else if (mode == CHAIN_MID) A2P_LAUNCH(kt, (chain3_kernel<D, MT, CHAIN_MID>), grid, 256, s, p);     \
-    else A2P_LAUNCH(kt, (chain3_kernel<D, MT, CHAIN_POST>), grid, 256, s, p);                           \
-  } while (0)
-  if (c->d == 512) {
-    if (mt == 2) A2P_CHAIN3(512, 2);
-    else A2P_CHAIN3(512, 3);
-  } else {
-    if (mt == 2) A2P_CHAIN3(256, 2);
-    else if (mt == 3) A2P_CHAIN3(256, 3);
-    else if (mt == 4) A2P_CHAIN3(256, 4);
-    else A2P_CHAIN3(256, 5);
-  }
-#undef A2P_CHAIN3
-  HIPCHK(hipGetLastError());
-  return 0;
-}
-
-// Chain kernel generation for a forward of T-frame sequences: 1 (kernels_chain.h) unless A2P_CHAIN_V=2 asks for the round-3
-// restructure (kernels_chain2.h: bit-identical, measured equal at 48-row panels and slower at 80 -- DESIGN.md section 4.1b),
-// which does not implement final_layer fused into the last POST kernel (A2P_TAIL16) nor frame counts that are not a multiple
-// of 8 (only the staged V^T store: 8 frames per 16-byte piece)
-static int chain_pick_ver(const a2p_ctx* c, int T) {
-  if ((c->opt.chain_v != 2 && c->opt.chain_v != 3) || (!c->tail32 && !c->pose) || (T & 7)) return 1;
-  return c->opt.chain_v;
-}
-
 static int launch_chain(a2p_ctx* c, int mode, const ChainP& p, hipStream_t s) {
-  if (c->ch_ver == 2) return launch_chain2(c, mode, p, s);
-  if (c->ch_ver == 3) return launch_chain3(c, mode, p, s);
   const bool env_mt = c->opt.chain_mt != 0;  // tuning / test override of the panel height (rows = 16 * MT)
   int mt = c->opt.chain_mt;
   // panel heights instantiated per width (LDS: the [16*MT][d] bf16 panel + hidden chunk + >= 3 ring slots must fit 160 KiB)
@@ -693,7 +593,7 @@ extern "C" int a2p_prepare_cond(a2p_ctx* c, const float* cond_embed, int32_t B, 
     }
   }
   // pooled hidden (model/diffusion.py:380-381) -> hidden slot 1+b
-  mean_tokens_kernel<<<dim3((d + 255) / 256, B), 256, 0, s>>>(c->x.f(), c->pooled.f(), S0, d);
+  mean_tokens_kernel<<<dim3((d + 63) / 64, B), 1024, 0, s>>>(c->x.f(), c->pooled.f(), S0, d);
   CHK(launch_ln_rope(c, true, c->pooled.f(), d, W32(c, "non_attn_cond_projection.0.weight"), W32(c, "non_attn_cond_projection.0.bias"),
                      c->tmpa.p, nullptr, d, B, B, 0, s));
   CHK(launch_skinny(c->tmpa.f(), d, W32(c, "non_attn_cond_projection.1.weight"), d, W32(c, "non_attn_cond_projection.1.bias"),
@@ -852,11 +752,8 @@ static int forward_body(a2p_ctx* c, const float* x_in, const int64_t* t_orig, in
   }
   hipEvent_t tune0 = nullptr, tune1 = nullptr;
   if (use_chain) {
-    c->ch_ver = chain_pick_ver(c, T);
-    if (c->ch_ver == 1) {
-      c->ch_nw = chain_pick_nw(c, (int64_t)N * T, &tune0, &tune1);
-      if (tune0) HIPCHK(hipEventRecord(tune0, s));
-    }
+    c->ch_nw = chain_pick_nw(c, (int64_t)N * T, &tune0, &tune1);
+    if (tune0) HIPCHK(hipEventRecord(tune0, s));
   }
   CrossKV kv, kv2;
   for (int l = 0; l < L; ++l) {
@@ -946,7 +843,10 @@ static int run_forward(a2p_ctx* c, const float* x_in, const int64_t* t_orig, int
   // The kernel family is chosen from the row count of the UNSHARDED batch when the host names it (a2p_set_batch_hint;
   // sample_parallel does): the families differ in rounding, and a sharded run must reproduce the single-process samples bit for bit
   const int64_t rows_eff = (int64_t)(c->batch_hint > B ? (N / B) * c->batch_hint : N) * T;
-  const bool use_chain = chain_supported(c) && (rows_eff >= c->opt.chain_rows || c->opt.chain_mt);
+  // (the 1100-row break-even was measured against the small-forward kernels, which exist for the face model only: a context
+  // without them -- the body model, d != 512 -- keeps the round-2 threshold of 960 rows against the per-op kernels)
+  const int64_t chain_thr = small_supported(c) ? c->opt.chain_rows : (c->opt.chain_rows < 960 ? c->opt.chain_rows : 960);
+  const bool use_chain = chain_supported(c) && (rows_eff >= chain_thr || c->opt.chain_mt);
   const bool use_small = !use_chain && small_supported(c);
   if (use_chain || !c->opt.graph || c->time_kind >= 0) return forward_body(c, x_in, t_orig, pass, mo_seq_rows, s, true, use_chain, use_small);
   CHK(forward_ext(c, x_in, t_orig, s));
@@ -999,7 +899,7 @@ extern "C" int a2p_denoise_forward(a2p_ctx* c, const float* x, const int64_t* t_
   StepP sp;
   memset(&sp, 0, sizeof(sp));
   sp.mo = c->mo.f(); sp.mo_seq_rows = rows; sp.mo_ld = c->C; sp.B = c->pB; sp.C = c->C; sp.Tn = c->pT;
-  sp.pass = pass; sp.scale = scale; sp.out_btc = out; sp.sampler = -1;
+  sp.pass = pass; sp.scale = scale; sp.out_btc = out; sp.sampler = -1; sp.nonfinite = reinterpret_cast<int*>(c->nonfinite.p);
   return launch_step_tail(c, sp, s);
 }
 
@@ -1026,7 +926,28 @@ extern "C" int a2p_sample_step(a2p_ctx* c, int32_t sampler, const float* x, cons
   sp.mo = c->mo.f(); sp.mo_seq_rows = rows; sp.mo_ld = c->C; sp.B = c->pB; sp.C = c->C; sp.Tn = c->pT;
   sp.pass = A2P_PASS_CFG; sp.scale = scale; sp.sampler = sampler; sp.x = x; sp.t_idx = t_idx; sp.tables = tables;
   sp.n_steps = n_steps; sp.noise = noise; sp.eta = eta; sp.clip = clip_denoised; sp.x_next = x_next; sp.x0 = pred_xstart;
+  sp.nonfinite = reinterpret_cast<int*>(c->nonfinite.p);
   return launch_step_tail(c, sp, s);
+}
+
+extern "C" int a2p_check_finite(a2p_ctx* c, void* stream) {
+  ARG(c, "null ctx");
+  hipStream_t s = (hipStream_t)stream;
+  int flag = 0;
+  HIPCHK(hipMemcpyAsync(&flag, c->nonfinite.p, sizeof(int), hipMemcpyDeviceToHost, s));
+  HIPCHK(hipStreamSynchronize(s));
+  if (!flag) return 0;
+  HIPCHK(hipMemsetAsync(c->nonfinite.p, 0, sizeof(int), s));
+  set_err("a denoiser evaluation since the last check produced inf / nan outputs (%s operands): the activations of this checkpoint "
+          "leave the operand format's range, or the inputs / weights were not finite.  precision=\"bf16\" has fp32's range, "
+          "precision=\"fp32\" is the parity mode",
+#ifdef A2P_HALF
+          c->bf16 ? "IEEE-half, |x| <= 65504" : "fp32"
+#else
+          c->bf16 ? "bfloat16" : "fp32"
+#endif
+  );
+  return A2P_ERR_NONFINITE;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1236,7 +1157,6 @@ extern "C" int a2p_decoder_layer_forward(a2p_ctx* c, int32_t layer, float* x, co
   fr.base = flm.f();
   fr.seq_stride = (int64_t)F * 2 * d;
   HIPCHK(hipMemcpyAsync(c->x.p, x, (size_t)N * T * d * 4, hipMemcpyDeviceToDevice, s));
-  c->ch_ver = chain_pick_ver(c, T);
   int rc = chain_supported(c) ? decoder_layer_chain(c, layer, N, T, kv, memory2 ? &kv2 : nullptr, fr, true, false, s)
                               : decoder_layer(c, layer, N, T, kv, memory2 ? &kv2 : nullptr, fr, s);
   if (rc == 0) hipMemcpyAsync(x, c->x.p, (size_t)N * T * d * 4, hipMemcpyDeviceToDevice, s);
@@ -1251,6 +1171,11 @@ extern "C" int a2p_decoder_layer_forward(a2p_ctx* c, int32_t layer, float* x, co
 extern "C" int a2p_debug_read(a2p_ctx* c, const char* name, void* host, int64_t bytes) {
   ARG(c && name && host && bytes > 0, "bad arguments");
   const std::string n(name);
+  if (n == "chain_nw") {   // int32: waves per chain workgroup of the last chain forward (4 | 8; bench.py reports it)
+    ARG(bytes >= 4, "chain_nw is one int32");
+    *reinterpret_cast<int32_t*>(host) = c->ch_nw;
+    return 0;
+  }
   const Buf* b = n == "film" ? &c->film : n == "ktail" ? &c->ktail : n == "vtail" ? &c->vtail : n == "tvec" ? &c->tvec
                : n == "tokr" ? &c->tokr : n == "tokn" ? &c->tokn : n == "tct" ? &c->tct
                : n == "x" ? &c->x : n == "qk" ? &c->qk : n == "vt" ? &c->vt : n == "ao" ? &c->ao : n == "mo" ? &c->mo

@@ -107,11 +107,6 @@ struct ChainP {
   float* fin_out;
   int64_t ld_fin;
   int fin_n;
-  // generation 2 only: the first n_pf workgroups of the launch (one per XCD: the dispatcher places block b on XCD b % 8) are
-  // stream LEADERS -- pf_waves of their waves walk the chain's n_stages weight stages ahead of the consumers and pull them into
-  // their XCD's L2, so that the consumers (which all walk the stream in step) take L2 hits instead of sharing one HBM miss per
-  // ring depth; they own no rows.  Consumer workgroup b owns the panel b - n_pf.
-  int n_pf, pf_waves, n_stages;
   // diagnostic (A2P_CHAIN_CLK=1): blocks 0..7 write {s_memtime, s_memrealtime} at kernel begin / end to clk[block][2][2]: the
   // shader clock the kernel actually ran at inside the step (DVFS) = d(memtime) / d(memrealtime @ 100 MHz)
   unsigned long long* clk;

@@ -302,6 +302,12 @@ class GaussianDiffusion:
                 out = step_fn(model, img, steps[i], model_kwargs=model_kwargs, noise=nz, **step_kwargs)
             yield out
             img = out["sample"]
+        # Once per sampling call: did any denoiser evaluation produce inf / nan?  (The 16-bit throughput modes can overflow where
+        # the reference's fp32 path cannot; the library ORs a device flag in its fused step tail, include/a2p_hip.h
+        # a2p_check_finite.)  Raises A2PError; a loop abandoned half way by its consumer is not checked.
+        chk = getattr(model, "a2p_check_finite", None) or getattr(model, "check_finite", None)
+        if callable(chk):
+            chk()
 
     def p_sample_loop_progressive(self, model, shape, noise=None, clip_denoised=True, denoised_fn=None, cond_fn=None,
                                   model_kwargs=None, device=None, progress=False, skip_timesteps=0, init_image=None,

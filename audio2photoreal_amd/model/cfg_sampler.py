@@ -47,6 +47,10 @@ class ClassifierFreeSampleModel(nn.Module):
     def forward(self, x, timesteps, y=None):
         return self.model.forward_cfg(x, timesteps, y)
 
+    def a2p_check_finite(self):
+        """Raise A2PError when a denoiser evaluation since the last check produced inf / nan (FiLMTransformer.check_finite)."""
+        self.model.check_finite()
+
     def a2p_sample_step(self, sampler, x, t_idx, timestep_map, tables, y, noise, eta, clip_denoised):
         """p_mean_variance + ddim_sample / p_sample in one library call; SpacedDiffusion's loops use it when present."""
         return self.model.sample_step(sampler, x, t_idx, timestep_map, tables, y, noise, eta, clip_denoised)

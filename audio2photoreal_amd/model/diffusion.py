@@ -392,6 +392,16 @@ class FiLMTransformer(nn.Module):
         """Both guidance passes batched as 2B sequences + the lerp (model/cfg_sampler.py:30-33)."""
         return self._run(x, times, y, _lib.PASS_CFG, y["scale"])
 
+    def check_finite(self) -> None:
+        """Raise A2PError if any denoiser evaluation since the last check produced inf / nan outputs (include/a2p_hip.h
+        a2p_check_finite: a device flag OR-ed by the fused step tail; reading it synchronises the stream).  The sampling loops of
+        GaussianDiffusion call this once per sampling call; direct `forward` users call it when they want the answer."""
+        if self._ctx is None:
+            return
+        dev = torch.device(self._ctx_key[0])
+        with torch.cuda.device(dev):
+            _lib.check((self._ctx_lib or self._lib()).a2p_check_finite(self._ctx, _lib.current_stream(dev)), "a2p_check_finite")
+
     def sample_step(self, sampler: int, x, t_idx, timestep_map, tables, y, noise, eta: float, clip_denoised: bool):
         """Fused p_mean_variance + ddim_sample / p_sample for one step (include/a2p_hip.h a2p_sample_step)."""
         x = x.to(torch.float32).contiguous()

@@ -56,6 +56,32 @@ def synthetic_state_dict(spec: DenoiserSpec, seed: int = 10) -> Dict[str, torch.
     return sd
 
 
+def trained_like_state_dict(spec: DenoiserSpec, seed: int = 10, weight_gain: float = 1.0, qk_gain: float = 1.0,
+                            resid_gain: float = 1.0) -> Dict[str, torch.Tensor]:
+    """synthetic_state_dict pushed towards the statistics of a TRAINED denoiser (xavier-scale weights give near-uniform softmax
+    rows and a residual stream of a few units: the easy case for 16-bit operands).  `weight_gain` multiplies every Linear / conv
+    weight of the decoder stack, the conditioning path and the output head (activations grow with depth); `qk_gain` multiplies
+    the query and key rows of every attention in_proj on top of that (logits grow with its square: peaky softmax rows);
+    `resid_gain` multiplies input_projection (weight and bias): a residual stream of that many units enters layer 0, rides through
+    every LayerNorm / FiLM / out_proj epilogue and is what final_layer's split-operand rows have to carry."""
+    sd = synthetic_state_dict(spec, seed)
+    d = spec.latent_dim
+    for name, t in sd.items():
+        leaf = name.split(".")[-1]
+        if name == "rotary.freqs" or name.startswith("null_") or ".norm" in name or name.startswith("norm_cond") or name.startswith("frame_norm_cond"):
+            continue
+        if leaf in ("weight", "in_proj_weight") and t.dim() >= 2:
+            t = t * weight_gain
+            if leaf == "in_proj_weight" and qk_gain != 1.0:
+                t = t.clone()
+                t[: 2 * d] *= qk_gain
+            sd[name] = t
+    if resid_gain != 1.0:
+        for k in ("input_projection.weight", "input_projection.bias"):
+            sd[k] = sd[k] * resid_gain
+    return sd
+
+
 def _init_like_reference(seed: int, name: str, shape, prefix: str = "") -> torch.Tensor:
     """The rule synthetic_state_dict applies per parameter, shared with the guide / tokenizer dictionaries (`prefix` only
     separates their random streams)."""

@@ -108,8 +108,8 @@ class Case:
         torch.cuda.synchronize()
         self.prepare_s = time.perf_counter() - t0
         with torch.no_grad():
-            # the library measures which chain-kernel workgroup shape is faster on THIS box during the first 6 forwards of a
-            # given size (csrc/a2p_lib_run.h chain_pick_nw; both shapes give identical bits)
+            # warm-up forwards (with A2P_CHAIN_TUNE=1 the library also measures which chain-kernel workgroup shape is faster on
+            # THIS box during the first 6 forwards of a given size: csrc/a2p_lib_run.h chain_pick_nw)
             for _ in range(6):
                 self.cfg(self.x, self.steps_idx[0], self.y)
         torch.cuda.synchronize()
@@ -188,6 +188,19 @@ def kernel_breakdown(case, ksteps):
     return kernels, roofline
 
 
+def chain_workgroup_waves(case):
+    """Waves per workgroup of the chain kernels the library launched last (4 | 8).  Deterministic since round 4 (8 unless
+    A2P_CHAIN_NW / A2P_CHAIN_TUNE say otherwise; csrc/a2p_lib_run.h chain_pick_nw); both shapes produce identical bits."""
+    import ctypes as C
+    from audio2photoreal_amd import _lib
+    nw = C.c_int32(0)
+    try:
+        _lib.check(case.model._lib().a2p_debug_read(case.model._ctx, b"chain_nw", C.byref(nw), 4), "a2p_debug_read")
+    except Exception:   # noqa: BLE001 -- a report field, never a reason to lose the line
+        return None
+    return int(nw.value)
+
+
 def leg_record(case, steps, warmup, repeats, ksteps=3):
     """Sub-record of a secondary workload (same measurement as the headline, fewer fields)."""
     case.setup()
@@ -200,7 +213,8 @@ def leg_record(case, steps, warmup, repeats, ksteps=3):
             "sample_steps_per_sec": round(case.B * steps / dt, 2), "repeats_ms_per_step": [round(1e3 * t / steps, 4) for t in dts],
             "decoder_tflops": round(case.step_flops() * steps / dt / 1e12, 2),
             "decoder_mfma_frac": round(case.step_flops() * steps / dt / 1e12 / peak, 4),
-            "roofline": roofline, "kernels": kernels, "prepare_s": round(case.prepare_s, 4)}
+            "roofline": roofline, "kernels": kernels, "prepare_s": round(case.prepare_s, 4),
+            "chain_workgroup_waves": chain_workgroup_waves(case) if "chain" in kernels else None}
 
 
 # ----------------------------------------------------------------------------------------------------------------------
@@ -533,6 +547,8 @@ def main():
     kernels, roofline = {}, None
     if rank == 0 and not a.no_kernel_timing:
         kernels, roofline = kernel_breakdown(case, min(a.steps, 5))
+        if "chain" in kernels:
+            roofline["chain_workgroup_waves"] = chain_workgroup_waves(case)
         # HBM bytes per launch of the dominant class from the rocprofv3 PMC passes (FETCH_SIZE doubled per the gfx950 note of
         # MI355X_MICROARCH.md + WRITE_SIZE; scratch/run_pmc.sh writes the file) -- null when not collected for this workload
         tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")

@@ -34,6 +34,7 @@ extern "C" {
 #define A2P_ERR_STATE (-2)    /* call order: weights not finalized / conditioning not prepared */
 #define A2P_ERR_HIP (-3)      /* HIP runtime error */
 #define A2P_ERR_NOWEIGHT (-4) /* unknown / missing / mis-sized parameter (reference: load_model asserts, utils/model_util.py:30-38) */
+#define A2P_ERR_NONFINITE (-5) /* a2p_check_finite: a denoiser output held inf / nan (16-bit operand overflow, or non-finite inputs / weights) */
 
 #define A2P_FACE 0
 #define A2P_POSE 1
@@ -190,6 +191,17 @@ int a2p_kernel_time_ms(a2p_ctx* ctx, double* total_ms, int64_t* launches);
  * batch names the size of the whole batch here, so that every shard takes the family the unsharded run takes and the gathered
  * samples equal the single-process samples bit for bit (sample_parallel.py does this; 0 = no hint). */
 int a2p_set_batch_hint(a2p_ctx* ctx, int32_t global_batch);
+
+/* ---- non-finite detection ------------------------------------------------------
+ * The 16-bit throughput modes stage Q|K|V, the FFN hidden activation and the split-operand rows as IEEE half (liba2p_hip_f16.so:
+ * |x| <= 65504) or bfloat16; a checkpoint whose activations leave that range produces inf / nan, which the reference's fp32 path
+ * would not.  Every denoiser evaluation (a2p_denoise_forward, a2p_sample_step) ORs "the model output held a non-finite value"
+ * into a device flag of the context at no measurable cost (the fused step tail reads every output element anyway).
+ * a2p_check_finite synchronises `stream`, reads and CLEARS the flag: returns 0 when every evaluation since the last check was
+ * finite, A2P_ERR_NONFINITE otherwise (a2p_last_error names the remedy: precision "bf16" for range, "fp32" for parity mode).
+ * The Python loops (GaussianDiffusion.*_sample_loop) call it once per sampling call and raise A2PError; the reference has no
+ * counterpart (its torch CPU / CUDA fp32 path cannot overflow on these models). */
+int a2p_check_finite(a2p_ctx* ctx, void* stream);
 
 /* ---- run-time switches: the A2P_* environment variables that steer a forward (INTEGRATION.md "Environment switches") are read
  * when the context is created; a host that changes one afterwards calls this (the Python mirror does, model/diffusion.py). */

@@ -87,6 +87,8 @@ def _attn(R: Rounding, pre: str, q: Tensor, k: Tensor, v: Tensor, nheads: int, t
     kh = k.view(B, Lk, nheads, dh).transpose(1, 2)
     vh = v.view(B, Lk, nheads, dh).transpose(1, 2)
     s = (qh @ kh.transpose(-1, -2)) / math.sqrt(dh)
+    if hasattr(R, "logit_peak"):   # tests/tools/trained_like_budget.py: the largest |logit| any attention of the forward sees
+        R.logit_peak = max(R.logit_peak, float(s.abs().max()))
     p = torch.exp(s - s.amax(-1, keepdim=True))
     o = (R(pre + ".p", p) @ vh) / p.sum(-1, keepdim=True)
     return o.transpose(1, 2).reshape(B, Lq, d)

@@ -6,11 +6,11 @@
 #include <stdlib.h>
 #include <string.h>
 #include <vector>
-#include "../audio2photoreal_amd/csrc/kernels_chain3.h"
+#include "kernels_chain3.h"
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); exit(1);} } while (0)
 static uint4* g_tbuf = nullptr;
 static uint4* g_tout = nullptr;
-static int g_thrash = 1, g_cycle = 1;
+static int g_thrash = 1, g_cycle = 1, g_phase = 0, g_xpf = 0;
 __global__ void thrash_kernel(const uint4* __restrict__ p, size_t n_per_block, uint4* out) {
   uint4 acc = make_uint4(0, 0, 0, 0);
   const uint4* q = p + (size_t)blockIdx.x * n_per_block;
@@ -18,7 +18,9 @@ __global__ void thrash_kernel(const uint4* __restrict__ p, size_t n_per_block, u
   if (acc.x == 0x12345678) out[0] = acc;
 }
 template <int GEN, int MT, int MODE>
-void run(ChainP p, int stages, unsigned long long* st) {
+void run(ChainP p0, int stages, unsigned long long* st) {
+  Chain3P p;
+  static_cast<ChainP&>(p) = p0;
   const int grid = (p.M + 16 * MT - 1) / (16 * MT);
   const h16_t* base = p.stream;
   hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
@@ -27,7 +29,7 @@ void run(ChainP p, int stages, unsigned long long* st) {
     p.stream = base + (size_t)(it % 8) * (256 + 8) * 8192;
     if (g_thrash) thrash_kernel<<<2048, 256>>>(g_tbuf, ((size_t)512 << 20) / 16 / 2048, g_tout);
     if (!g_cycle) p.stream = base;
-    p.n_pf = 0; p.n_stages = stages;
+    p.n_pf = 0; p.n_stages = stages; p.phase_us = g_phase; p.phase_blocks = 512; p.x_prefetch = g_xpf;
     if constexpr (GEN == 3) hipExtLaunchKernelGGL((chain3_kernel<512, MT, MODE>), dim3(grid), dim3(256), 0, 0, e0, e1, 0, p);
     else if constexpr (GEN == 4) hipExtLaunchKernelGGL((chain_kernel<512, MT, MODE, 0, 4>), dim3(grid), dim3(256), 0, 0, e0, e1, 0, p);
     else hipExtLaunchKernelGGL((chain_kernel<512, MT, MODE, 0, 8>), dim3(grid), dim3(512), 0, 0, e0, e1, 0, p);
@@ -52,6 +54,9 @@ void run(ChainP p, int stages, unsigned long long* st) {
   }
 }
 int main(int argc, char** argv) {
+  if (argc > 1) g_phase = atoi(argv[1]);
+  if (argc > 2) g_xpf = atoi(argv[2]);
+  printf("phase_us=%d x_prefetch=%d\n", g_phase, g_xpf);
   const int D = 512, Mmax = 38400;
   float *x, *aux, *vec, *film; h16_t *ain, *stream, *qk, *vt; float2* cs;
   CK(hipMalloc(&x, (size_t)Mmax * D * 4)); CK(hipMalloc(&ain, (size_t)Mmax * D * 2)); CK(hipMalloc(&stream, (size_t)(8 * (256 + 8) + 64) * 16384));

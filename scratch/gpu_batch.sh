@@ -1,11 +1,13 @@
 #!/bin/bash
-# round 4, call 1: vendor GEMM yardstick, generation-3 chain kernels (isolated bench, bit-identity tests, in-step A/B)
+# round 4, call 2: generation-3 chain kernels after the PRE fix: bit-identity, phase shift / x prefetch sweep (isolated + in-step)
 cd "$GRAFT_REPO_ROOT" 2>/dev/null || cd /root/repo
 mkdir -p gpurun_out
-T=c1
-( timeout -k 5 200 python scratch/vendor_gemm.py > gpurun_out/${T}_vendor_gemm.txt 2> gpurun_out/${T}_vendor_gemm.err; echo "vendor rc=$?" )
-( timeout -k 5 120 ./scratch/chain3_bench > gpurun_out/${T}_chain3_bench.txt 2>&1; echo "chain3_bench rc=$?"; tail -40 gpurun_out/${T}_chain3_bench.txt )
-timeout -k 5 600 python -m pytest tests/test_hip_round3.py -m gpu -q -x -k "generation3" 2>&1 | tail -8 | tee gpurun_out/${T}_tests.log
+T=c2
+timeout -k 5 600 python -m pytest tests/test_hip_round3.py -m gpu -q -x -k "generation3" 2>&1 | tail -5 | tee gpurun_out/${T}_tests.log
+for ph in 0 25 40; do for xpf in 0 1; do
+  timeout -k 5 120 ./scratch/chain3_bench $ph $xpf 2>&1 | grep -A3 "M=38400" | grep -A2 "gen 3 rows 48 mode 2" | head -3
+done; done | tee gpurun_out/${T}_chain3_sweep.txt
+timeout -k 5 120 ./scratch/chain3_bench 30 1 > gpurun_out/${T}_chain3_bench.txt 2>&1
 B="python bench.py --steps 60 --warmup 10 --repeats 2 --no-cpu-baseline --no-parity --no-legs"
 run() {
   local tag=$1; shift
@@ -20,10 +22,10 @@ except Exception as e:
 PY
 }
 run b32_v1 A2P_X=0 $B --batch 32
-run b32_v3 A2P_CHAIN_V=3 $B --batch 32
-run b8_v1 A2P_X=0 $B --batch 8
-run b8_v3 A2P_CHAIN_V=3 $B --batch 8
-run b16_v3 A2P_CHAIN_V=3 $B --batch 16
+run b32_v3_p0 A2P_CHAIN_V=3 $B --batch 32
+run b32_v3_p30x A2P_CHAIN_V=3 A2P_C3_PHASE=30 A2P_C3_XPF=1 $B --batch 32
+run b32_v3_p0x A2P_CHAIN_V=3 A2P_C3_XPF=1 $B --batch 32
 run b16_v1 A2P_X=0 $B --batch 16
+run b16_v3_p30x A2P_CHAIN_V=3 A2P_C3_PHASE=30 A2P_C3_XPF=1 $B --batch 16
 run body_v1 A2P_X=0 $B --model pose --batch 16
-run body_v3 A2P_CHAIN_V=3 $B --model pose --batch 16
+run body_v3_p15x A2P_CHAIN_V=3 A2P_C3_PHASE=15 A2P_C3_XPF=1 $B --model pose --batch 16

@@ -1,4 +1,7 @@
-// Row-panel chain kernels, third generation (round 4): TWO workgroups per CU.
+// EXPERIMENT (round 4; scratch, not product -- built only by scratch/chain3_bench.hip): row-panel chain kernels, third generation:
+// TWO workgroups per CU.  Bit-identical to kernels_chain.h (14 GPU test cases at 0.0 while it was wired into the library, commit
+// "Chain kernels generation 3"), measured EQUAL-TO-SLOWER inside the step (B=32: 207-225 vs 200 us per chain launch; B=16 equal;
+// B=8 and the body model slower) and removed from the library again -- profiles/r04_chain3_bench*.txt, DESIGN.md section 4.1c.
 //
 // The same three chains as kernels_chain.h (PRE / MID / POST of FiLMTransformerDecoderLayer.forward,
 // transformer_modules.py:178-267) and the same bits.  What rounds 1-3 measured: a chain launch spends
@@ -23,7 +26,13 @@
 // and the L2 -> CU path delivers 64 B/clk: two workgroups in their GEMM loops are bound by that path (256 cycles per stage each =
 // 75 % of the matrix peak); what the second workgroup buys is everything else.
 #pragma once
-#include "kernels_chain.h"
+#include "../audio2photoreal_amd/csrc/kernels_chain.h"
+
+// the experiment's extra launch parameters (not part of the product's ChainP)
+struct Chain3P : ChainP {
+  int phase_us, phase_blocks;   // start delay (us) of the workgroups placed second on their CU among the first phase_blocks of the launch
+  int x_prefetch;               // touch the residual rows at kernel start
+};
 
 #pragma clang fp contract(off)
 
@@ -57,7 +66,7 @@ __global__ __launch_bounds__(256) void chain3_pack_kernel(const ChainPackDesc* _
 }
 
 template <int D, int MT, int MODE>
-__device__ __forceinline__ void chain3_body(const ChainP& p, h16_t* const smem, const int m0) {
+__device__ __forceinline__ void chain3_body(const Chain3P& p, h16_t* const smem, const int m0) {
   constexpr int NJ = 2, CW = 32, BM = 16 * MT, CPR = D / 8, NT = D / 128, KS = D / 64, FT = 8, HLD = 128, AUX_F = 2560, PF = CHAIN3_PF;
   static_assert(PF == 4 || PF == 2, "ring depth");
   static_assert(KS % PF == 0 && (2 * NT) % PF == 0, "every GEMM must consume a multiple of the register ring");
@@ -181,8 +190,10 @@ __device__ __forceinline__ void chain3_body(const ChainP& p, h16_t* const smem, 
           __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
         }
         if (refill) __builtin_amdgcn_sched_group_barrier(0x020, 4, 0);   // ... then the stage's four weight loads
+        // every half stage is its own scheduling region: left to one region per body hipcc sinks the fragment reads of the first
+        // PF stages into the half stage that consumes them (ds_read, s_waitcnt lgkmcnt(0), MFMA: un-pipelined)
+        __builtin_amdgcn_sched_barrier(0);
       }
-      __builtin_amdgcn_sched_barrier(0);   // bodies are scheduled one by one
     }
   };
   // acc[t] += P[:, 0 : 64*NKS] x stages^T for all NT tiles, k-major (stage = ks*NT + t): the A fragments of a k-step are read
@@ -228,8 +239,8 @@ __device__ __forceinline__ void chain3_body(const ChainP& p, h16_t* const smem, 
             if (i < nread) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
           }
           if (refill) __builtin_amdgcn_sched_group_barrier(0x020, 4, 0);
+          __builtin_amdgcn_sched_barrier(0);
         }
-      __builtin_amdgcn_sched_barrier(0);
     }
   };
   // accumulators start at the per-column bias held in the LDS aux block (row-major consumers: 8 contiguous columns per lane)
@@ -249,6 +260,18 @@ __device__ __forceinline__ void chain3_body(const ChainP& p, h16_t* const smem, 
     }
   };
 
+  // ---- phase shift ---------------------------------------------------------------------------------------------------------
+  // The two workgroups of a CU that start together (the launch's first round) would run in lock step -- both in their GEMM loops,
+  // bound by the 64 B/clk weight path, then both in their epilogues with the matrix pipe idle.  The one that sits in the UPPER
+  // half of the CU's LDS (HW_REG_LDS_ALLOC.lds_base != 0: it was placed second) starts p.phase_us later, so that its epilogues
+  // fall under its neighbour's GEMM loops.  Later rounds start whenever a slot frees up and need no help.
+  if (p.phase_us > 0 && (int)blockIdx.x < p.phase_blocks) {
+    const unsigned lds_alloc = __builtin_amdgcn_s_getreg((6 << 0) | (0 << 6) | ((8 - 1) << 11));   // hwreg(HW_REG_LDS_ALLOC, 0, 8): lds_base
+    if (lds_alloc != 0) {
+      const unsigned long long t0 = wall_clock64();
+      while (wall_clock64() - t0 < (unsigned long long)p.phase_us * 100ull) __builtin_amdgcn_s_sleep(32);
+    }
+  }
   // ---- kernel start: attention-output panel + aux block by LDS-DMA, weight ring primed ----------------------------------
   if constexpr (MODE != CHAIN_PRE) {
     constexpr int RPI = 64 / CPR;
@@ -262,7 +285,27 @@ __device__ __forceinline__ void chain3_body(const ChainP& p, h16_t* const smem, 
     }
   }
   for (int kb = W4; kb < p.aux_kb; kb += 4) chain_glds16(p.aux + kb * 256 + lane * 4, aux + kb * 256);
-  w_prime();
+  if constexpr (MODE != CHAIN_PRE) w_prime();   // (MODE_PRE: pre_work primes the ring in front of its first GEMM)
+  if constexpr (MODE != CHAIN_PRE) {
+    // Touch the residual rows the out_proj epilogue will read (film_res: 8 dependent batches of loads) so that they come from
+    // L2 by then instead of HBM.  Every load targets one scratch register that is never read (loads return in order; the
+    // compiler's own counted waits only ever over-wait because of them).
+    if (p.x_prefetch) {
+      const float* xs = p.xsrc ? p.xsrc : p.x;
+      const uint32_t ts = x_tstride(p.x_in_tiled), js = x_jstride(p.x_in_tiled);
+      f32x4 sink;
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) {
+        const int ms = (p.src_rows > 0 && row_m[mt] >= p.src_rows) ? row_m[mt] - p.src_rows : row_m[mt];
+        const uint32_t xb = x_rbase(ms, p.x_in_tiled);
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+          for (int j = 0; j < NJ; ++j)
+            asm volatile("global_load_dwordx4 %0, %1, %2" : "=&v"(sink) : "v"((xb + t * ts + j * js) << 2), "s"(xs));
+      }
+    }
+  }
   // the DMA pieces have landed for this wave (the compiler is free to order the ring's first loads in front of them, so the
   // wait is for everything: once per kernel) ...
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -285,34 +328,36 @@ __device__ __forceinline__ void chain3_body(const ChainP& p, h16_t* const smem, 
       xb[mt] = x_rbase(ms, tiled);
       fb[mt] = (uint32_t)rs * (uint32_t)p.film_seq_stride + (uint32_t)col_of(0, 0);
     }
-    // operands in batches of one sub-tile column (3 f32x4 per row = 36 registers in flight at 48 rows next to the accumulators and
-    // the weight ring), all loads of a batch issued before its arithmetic.  `film` may be NULL (plain residual): tested per batch,
-    // uniform.
+    // operands in batches of one tile (both sub-tiles: 6 f32x4 per row = 72 registers in flight at 48 rows -- the weight ring's
+    // registers are free here), all loads of a batch issued before its arithmetic: NT dependent round trips per epilogue
 #pragma unroll
-    for (int t = 0; t < NT; ++t)
+    for (int t = 0; t < NT; ++t) {
+      f32x4 b[NJ], xo[NJ][MT], sc[NJ][MT], sh[NJ][MT];
 #pragma unroll
       for (int j = 0; j < NJ; ++j) {
-        const f32x4 b = *reinterpret_cast<const f32x4*>(bias + col_of(t, j));
-        f32x4 xo[MT], sc[MT], sh[MT];
+        b[j] = *reinterpret_cast<const f32x4*>(bias + col_of(t, j));
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
-          xo[mt] = ld4(xs, xb[mt] + t * ts + j * js);
-          sc[mt] = ld4(film, fb[mt] + t * 128 + j * 4);
-          sh[mt] = ld4(film, fb[mt] + t * 128 + j * 4 + (uint32_t)p.film_shift_off);
+          xo[j][mt] = ld4(xs, xb[mt] + t * ts + j * js);
+          sc[j][mt] = ld4(film, fb[mt] + t * 128 + j * 4);
+          sh[j][mt] = ld4(film, fb[mt] + t * 128 + j * 4 + (uint32_t)p.film_shift_off);
         }
+      }
+#pragma unroll
+      for (int j = 0; j < NJ; ++j)
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
-          const f32x4 y = R[t][j][mt] + b, s1 = sc[mt] + 1.0f;
-          f32x4 xr = xo[mt];
+          const f32x4 y = R[t][j][mt] + b[j], s1 = sc[j][mt] + 1.0f;
+          f32x4 xr = xo[j][mt];
 #pragma unroll
-          for (int e = 0; e < 4; ++e) xr[e] += fmaf(s1[e], y[e], sh[mt][e]);
+          for (int e = 0; e < 4; ++e) xr[e] += fmaf(s1[e], y[e], sh[j][mt][e]);
           R[t][j][mt] = xr;
           // the RESULT is pinned here: hipcc otherwise sinks this arithmetic to the first use of the rows (the LayerNorm sums) and
           // keeps every loaded operand of every batch alive until then
           asm volatile("" : "+v"(R[t][j][mt]));
         }
-        __builtin_amdgcn_sched_barrier(0);   // one batch at a time
-      }
+      __builtin_amdgcn_sched_barrier(0);   // one batch at a time
+    }
   };
   float ln_mean[MT], ln_rstd[MT];
   auto group_partials = [&](const float* q) __attribute__((always_inline)) {
@@ -505,9 +550,12 @@ __device__ __forceinline__ void chain3_body(const ChainP& p, h16_t* const smem, 
     C3_FENCE();
     ln_write(R, p.lnB_g, p.lnB_b, std::true_type{});
     C3_FENCE();
+    // (the ring is primed BEFORE the row stores: vmcnt counts stores too, and loads issued behind 96 KiB of stores would wait for
+    // their acknowledgement in front of the first GEMM stage)
+    w_prime();
+    C3_FENCE();
     if (write_x) store_x(R, p.x_out_tiled);
     C3_FENCE();
-    w_prime();
     stamp(9);
     gemm_store(std::integral_constant<int, 2 * NT>{}, aq, p.qk_out, p.ld_qk, false);
     chain_bar();   // every wave is done reading the rotated panel
@@ -548,16 +596,18 @@ __device__ __forceinline__ void chain3_body(const ChainP& p, h16_t* const smem, 
     if constexpr (MODE == CHAIN_MID) {
       ln_write(R, p.lnA_g, p.lnA_b, std::true_type{});
       C3_FENCE();
+      w_prime();
+      C3_FENCE();
       store_x(R, p.x_out_tiled);
       C3_FENCE();
-      w_prime();
       gemm_store(std::integral_constant<int, NT>{}, aux, p.q_out, p.ld_q, false);
     } else {
       ln_write(R, p.lnA_g, p.lnA_b, std::false_type{});
       C3_FENCE();
+      w_prime();
+      C3_FENCE();
       store_x(R, p.x_out_tiled);            // parked: the feed-forward block runs without the residual rows in registers
       C3_FENCE();
-      w_prime();
       stamp(4);
       // Feed forward, split-K over the 8 hidden chunks: linear1 chunk -> GELU -> LDS -> linear2 partial.
 #pragma unroll
@@ -603,7 +653,7 @@ __device__ __forceinline__ void chain3_body(const ChainP& p, h16_t* const smem, 
 }
 
 template <int D, int MT, int MODE>
-__global__ __launch_bounds__(256, 2) void chain3_kernel(const ChainP p) {
+__global__ __launch_bounds__(256, 2) void chain3_kernel(const Chain3P p) {
   __shared__ __attribute__((aligned(16))) h16_t smem[Chain3Lds<D, MT>::ELEMS];
   chain3_body<D, MT, MODE>(p, smem, (int)blockIdx.x * (16 * MT));
 }

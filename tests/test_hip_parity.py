@@ -357,11 +357,9 @@ def test_chain_workgroup_shapes_are_bit_identical(dev, fmt, B, frames, precision
     cfg = ClassifierFreeSampleModel(model)
     outs = {}
     for nw in ("4", "8"):
-        monkeypatch.setenv("A2P_CHAIN_V", "1")      # the 4- / 8-wave shapes are generation-1 kernels (csrc/kernels_chain.h)
         monkeypatch.setenv("A2P_CHAIN_NW", nw)
         outs[nw] = cfg(x, times, y).clone()
     monkeypatch.delenv("A2P_CHAIN_NW")
-    monkeypatch.delenv("A2P_CHAIN_V")
     auto = [cfg(x, times, y).clone() for _ in range(7)]          # calibration forwards alternate the shapes, then one sticks
     assert torch.equal(outs["4"], outs["8"])
     assert all(torch.equal(a, outs["4"]) for a in auto)

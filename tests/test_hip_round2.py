@@ -187,11 +187,9 @@ def test_chain_workgroup_shapes_are_bit_identical_pose(dev, B, T, precision, mon
     t = torch.tensor(([901, 417, 33, 0] * 4)[:B], device=dev)
     outs = {}
     for nw in ("4", "8"):
-        monkeypatch.setenv("A2P_CHAIN_V", "1")      # the 4- / 8-wave shapes are generation-1 kernels (csrc/kernels_chain.h)
         monkeypatch.setenv("A2P_CHAIN_NW", nw)
         outs[nw] = cfg(x, t, y).clone()
     monkeypatch.delenv("A2P_CHAIN_NW")
-    monkeypatch.delenv("A2P_CHAIN_V")
     d = float((outs["4"] - outs["8"]).abs().max())
     record(f"pose_nw/{precision}/B{B}_T{T}", max_abs_diff=d)
     assert torch.equal(outs["4"], outs["8"]), f"max |diff| = {d:.3e}"
@@ -216,7 +214,6 @@ def test_layer0_shared_half_is_bit_identical_to_the_duplicated_path(dev, fmt, B,
     t = torch.tensor(([901, 417, 33, 0] * 4)[:B], device=dev)
     outs = {}
     for nw in ("4", "8"):
-        monkeypatch.setenv("A2P_CHAIN_V", "1")      # the 4- / 8-wave shapes are generation-1 kernels (csrc/kernels_chain.h)
         monkeypatch.setenv("A2P_CHAIN_NW", nw)
         monkeypatch.delenv("A2P_NO_SHARED_HALF", raising=False)
         shared = cfg(x, t, y).clone()
@@ -245,7 +242,6 @@ def test_mixed_panel_heights_are_bit_identical_to_the_uniform_launch(dev, B, T, 
     assert 2 * B * T > 256 * 48 and (2 * B * T + 47) // 48 % 256 != 0, "shape does not reach the mixed launch"
     outs = {}
     for nw in ("4", "8"):   # the mixed launch exists for the 8-wave shape; the 4-wave runs are the uniform reference
-        monkeypatch.setenv("A2P_CHAIN_V", "1")      # the 4- / 8-wave shapes are generation-1 kernels (csrc/kernels_chain.h)
         monkeypatch.setenv("A2P_CHAIN_NW", nw)
         monkeypatch.delenv("A2P_CHAIN_NO_MIX", raising=False)
         mixed = cfg(x, t, y).clone()
