@@ -406,6 +406,7 @@ static int launch_attn(a2p_ctx* c, const AttnP& p0, int nseq, int kind, hipStrea
   }
   // A2P_ATTN_WAVES=2 (16-bit modes): 2-wave workgroups of 64 queries -- a perfectly even 5 workgroups per CU at B=8, but every K/V
   // tile then feeds half as many queries: measured 97 vs 70 us for the cross attention (experiment switch, kernels_attn.h NWV)
+  p.stat_max = (c->DH != 128 && c->nonfinite.p) ? reinterpret_cast<int*>(c->nonfinite.p) + 1 : nullptr;   // denoiser attentions only
   static const bool two = getenv("A2P_ATTN_WAVES") && atoi(getenv("A2P_ATTN_WAVES")) == 2;
   const int nwv = (c->bf16 && two) ? 2 : 4;
   p.nq = (p.Tq + 32 * nwv - 1) / (32 * nwv); p.nheads = c->H; p.nseq = nseq;
@@ -591,6 +592,7 @@ extern "C" int a2p_ctx_create(const a2p_config* cfg, a2p_ctx** out) {
     A(c->kf_pack, (size_t)B * c->KFmax * c->KdPad * c->esz); A(c->kf_tok, (size_t)B * c->KFmax * d * 4);
   }
   A(c->slot_cond, B * 4); A(c->slot_unc, B * 4); A(c->slot_cfg, N * 4); A(c->nonfinite, 64);
+  if (rc == 0 && hipMemsetAsync(reinterpret_cast<int*>(c->nonfinite.p) + 1, 0x80, 4, nullptr) != hipSuccess) rc = A2P_ERR_HIP;   // logit maximum: "none yet" (0x80808080 < every ordered float)
   if (getenv("A2P_CHAIN_CLK")) A(c->clk, 64 * 32 * 8 + 2 * 64 * 8);   // + phase stamps of the diagnostic build (-DA2P_STAMPS)
   if (rc == 0 && hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking) != hipSuccess) rc = A2P_ERR_HIP;
   for (int i = 0; i < 8 && rc == 0; ++i)

@@ -930,6 +930,23 @@ extern "C" int a2p_sample_step(a2p_ctx* c, int32_t sampler, const float* x, cons
   return launch_step_tail(c, sp, s);
 }
 
+extern "C" int a2p_attention_logit_max(a2p_ctx* c, float* max_logit_host, void* stream) {
+  ARG(c && max_logit_host, "null argument");
+  hipStream_t s = (hipStream_t)stream;
+  int v = 0;
+  int* dev = reinterpret_cast<int*>(c->nonfinite.p) + 1;
+  HIPCHK(hipMemcpyAsync(&v, dev, sizeof(int), hipMemcpyDeviceToHost, s));
+  HIPCHK(hipStreamSynchronize(s));
+  HIPCHK(hipMemsetAsync(dev, 0x80, sizeof(int), s));
+  if (v == (int)0x80808080) {   // no query-split attention launch since the last call
+    *max_logit_host = -INFINITY;
+    return 0;
+  }
+  const int bits = v >= 0 ? v : v ^ 0x7fffffff;
+  memcpy(max_logit_host, &bits, sizeof(float));
+  return 0;
+}
+
 extern "C" int a2p_check_finite(a2p_ctx* c, void* stream) {
   ARG(c, "null ctx");
   hipStream_t s = (hipStream_t)stream;

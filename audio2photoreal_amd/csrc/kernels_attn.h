@@ -47,7 +47,17 @@ struct AttnP {
   // -- and, with 8 heads, every sequence of a head, i.e. all users of the shared unconditional K/V slot -- read their K/V
   // through ONE L2 instead of five (T = 600: 5 query blocks per pair, each of which used to pull the pair's K/V from HBM)
   int nq, nheads, nseq, xcd_remap;
+  // optional (a2p_attention_logit_max): the largest row maximum of the scaled scores q.k / sqrt(head_dim) any query of the launch
+  // saw, as an order-preserving int (attn_ordered_int), atomicMax-ed once per wave at the end of the kernel.  The operand
+  // rounding of the 16-bit modes turns into a logit error proportional to the logits' magnitude: this is the number that says
+  // whether a checkpoint sits inside the range the parity tests cover (INTEGRATION.md "validity envelope").
+  int* stat_max;
 };
+
+__device__ __forceinline__ int attn_ordered_int(float v) {   // monotone float -> int map (atomicMax on ints)
+  const int i = __float_as_int(v);
+  return i >= 0 ? i : i ^ 0x7fffffff;
+}
 
 __device__ __forceinline__ int attn_slot(const AttnP& p, int seq) {
   if (p.slot_rule == 1) return 1 + seq;
@@ -422,6 +432,14 @@ __global__ __launch_bounds__(64 * NWV, 3) void attn_kernel(AttnP p) {
   if (wave_active) tile_loop(integral_constant<bool, true>{});
   else tile_loop(integral_constant<bool, false>{});
 
+  if (p.stat_max && wave_active) {   // largest row maximum (natural units) of this wave's queries
+    float m = mrun[0];
+#pragma unroll
+    for (int qt = 1; qt < QT; ++qt) m = fmaxf(m, mrun[qt]);
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));   // over the 16 queries of a lane group (rows are already reduced)
+    if (lane == 0) atomicMax(p.stat_max, attn_ordered_int(m * 0.6931471805599453f));   // log2 domain -> natural units
+  }
   // ---- normalise and store: lane owns query l15, rows dv*16 + g*4 + {0..3} ----
   if constexpr (sizeof(T) == 2) {
     // 16-bit: a lane holds 4 consecutive head-dim values (8 bytes) of one query, so a direct store writes 16 rows x 32 bytes

@@ -133,6 +133,7 @@ class FiLMTransformer(nn.Module):
         self.audio_frontend = audio_frontend          # None | callable(audio) -> cond_embed | "native" (set up below)
         self.precision = precision
         self.max_batch = max_batch
+        self.last_logit_max = float("-inf")           # largest attention logit of the denoiser evaluations covered by the last check_finite()
         self.global_batch_hint = 0                   # set by sample_parallel: size of the unsharded batch (a2p_set_batch_hint)
         d = latent_dim
         self.latent_dim, self.ff_size, self.num_layers, self.num_heads = d, ff_size, num_layers, num_heads
@@ -395,12 +396,25 @@ class FiLMTransformer(nn.Module):
     def check_finite(self) -> None:
         """Raise A2PError if any denoiser evaluation since the last check produced inf / nan outputs (include/a2p_hip.h
         a2p_check_finite: a device flag OR-ed by the fused step tail; reading it synchronises the stream).  The sampling loops of
-        GaussianDiffusion call this once per sampling call; direct `forward` users call it when they want the answer."""
+        GaussianDiffusion call this once per sampling call; direct `forward` users call it when they want the answer.
+        In the 16-bit modes it also reads the largest attention logit the denoiser saw (a2p_attention_logit_max ->
+        `self.last_logit_max`) and warns with A2PPrecisionWarning when it leaves the range those modes were validated on."""
         if self._ctx is None:
             return
         dev = torch.device(self._ctx_key[0])
+        lib = self._ctx_lib or self._lib()
         with torch.cuda.device(dev):
-            _lib.check((self._ctx_lib or self._lib()).a2p_check_finite(self._ctx, _lib.current_stream(dev)), "a2p_check_finite")
+            stream = _lib.current_stream(dev)
+            peak = C.c_float(float("-inf"))
+            _lib.check(lib.a2p_attention_logit_max(self._ctx, C.byref(peak), stream), "a2p_attention_logit_max")
+            self.last_logit_max = float(peak.value)
+            _lib.check(lib.a2p_check_finite(self._ctx, stream), "a2p_check_finite")
+        if self.precision != "fp32" and self.last_logit_max > _lib.LOGIT_ENVELOPE_FP16:
+            import warnings
+            warnings.warn(f"attention logits reach {self.last_logit_max:.1f} (row maximum of q.k/sqrt(d_head)): beyond "
+                          f"{_lib.LOGIT_ENVELOPE_FP16:g} the 16-bit operand rounding of precision=\"{self.precision}\" costs more than the 1e-3 "
+                          "parity bar on the sampler's return value (measured 2.8e-3 at 29, divergent at 54: "
+                          "profiles/r04_trained_like_budget.json); precision=\"fp32\" is exact there", _lib.A2PPrecisionWarning, stacklevel=2)
 
     def sample_step(self, sampler: int, x, t_idx, timestep_map, tables, y, noise, eta: float, clip_denoised: bool):
         """Fused p_mean_variance + ddim_sample / p_sample for one step (include/a2p_hip.h a2p_sample_step)."""

@@ -104,28 +104,31 @@ def _replace_keyframes(model_kwargs, model, uniforms: Optional[torch.Tensor] = N
 
 
 def _run_single_diffusion(args, model_kwargs, diffusion, model, inv_transform: Callable, gt: Optional[torch.Tensor],
-                          noise: Optional[torch.Tensor] = None, rep_i: Optional[int] = None):
+                          noise: Optional[torch.Tensor] = None, rep_i: Optional[int] = None, call_i: Optional[int] = None):
     """One ddim_sample_loop over the (possibly rank-sharded) batch + un-normalisation (reference :74-107).
 
     Under torch.distributed every random draw is a function of (shared base seed, repetition, GLOBAL sample id): the initial
     noise via `per_sample_noise`, the guide transformer's uniforms from one generator all ranks seed alike -- so the gathered
     result does not depend on the world size, the keyframes rank 0 saves are the ones every rank conditioned on, and every
-    repetition draws fresh noise like the reference's `randn` does (`rep_i`; default = this process's call counter)."""
+    repetition of every sampling call draws fresh noise like the reference's `randn` does: seed = derive_seed(base, call,
+    repetition, global id), where `call` counts the sampling calls of this process (`call_i`; `_generate_sequences` takes one
+    number for all its repetitions; every rank makes the same calls in the same order)."""
     import torch.distributed as dist
     sharded = dist.is_available() and dist.is_initialized()
     base = shared_base_seed() if sharded else None
-    rep = next(_CALLS) if rep_i is None else int(rep_i)
+    call = next(_CALLS) if call_i is None else int(call_i)
+    rep = 0 if rep_i is None else int(rep_i)
     has_guide = getattr(args, "resume_trans", None) is not None or getattr(model, "resume_trans", None) is not None
     if args.data_format == "pose" and has_guide:   # reference :82-83
         y = model_kwargs["y"]
         uniforms = None
         if sharded:
             n = y["keyframes"].shape[1] * model.tokenizer.residual_depth
-            uniforms = torch.rand(n, y["keyframes"].shape[0], generator=torch.Generator().manual_seed(derive_seed(base, rep, 0x6775696465)))
+            uniforms = torch.rand(n, y["keyframes"].shape[0], generator=torch.Generator().manual_seed(derive_seed(base, call, rep, 0x6775696465)))
         y["keyframes"] = _replace_keyframes(model_kwargs, model, uniforms).to(y["keyframes"].device)
     shape = (args.batch_size, model.nfeats, 1, args.curr_seq_length)
     if noise is None and sharded:
-        noise = per_sample_noise(shape, [derive_seed(base, rep, g) for g in range(shape[0])])
+        noise = per_sample_noise(shape, [derive_seed(base, call, rep, g) for g in range(shape[0])])
     with torch.no_grad():
         sample = sample_parallel(diffusion.ddim_sample_loop, model, shape, model_kwargs, noise=noise,
                                  clip_denoised=False, init_image=None, progress=False, dump_steps=None, const_noise=False)
@@ -140,12 +143,13 @@ def _run_single_diffusion(args, model_kwargs, diffusion, model, inv_transform: C
 def _generate_sequences(args, model_kwargs, diffusion, model, inv_transform: Callable, gt: Optional[torch.Tensor] = None):
     """Repetition loop + results dict (reference :110-152)."""
     motions, lengths, audio, gts, kfs = [], [], [], [], []
+    call_i = next(_CALLS)   # two calls of one process (another clip, or the same clip again) must not reuse each other's noise
     for rep_i in range(args.num_repetitions):
         if args.guidance_param != 1:
             model_kwargs["y"]["scale"] = torch.ones(args.batch_size, device=args.device) * args.guidance_param
         model_kwargs["y"] = {k: v.to(args.device) if torch.is_tensor(v) else v for k, v in model_kwargs["y"].items()}
         sample, curr_audio, keyframes, gt_seq = _run_single_diffusion(args, model_kwargs, diffusion, model, inv_transform, gt,
-                                                                      rep_i=rep_i)
+                                                                      rep_i=rep_i, call_i=call_i)
         motions.append(sample.cpu().numpy())
         if curr_audio is not None:
             audio.append(curr_audio)

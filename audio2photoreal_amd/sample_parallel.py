@@ -73,18 +73,29 @@ def derive_seed(base: int, *ids: int) -> int:
     return h & 0x7FFFFFFFFFFFFFFF
 
 
+def gather_blocks(local: torch.Tensor, sizes: Sequence[int], group=None) -> torch.Tensor:
+    """One all_gather of per-rank blocks of DIFFERENT lengths (`sizes[r]` rows on rank r, zero allowed): every rank pads its
+    block to the longest, the result is the concatenation of the true blocks in rank order.  Works for host tensors (gloo)
+    and device tensors (backend "nccl" = RCCL over xGMI); a rank without rows still takes part."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return local
+    world = dist.get_world_size(group)
+    assert len(sizes) == world and local.shape[0] == sizes[dist.get_rank(group)], (sizes, tuple(local.shape))
+    maxn = max(max(sizes), 1)
+    pad = torch.zeros((maxn,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+    pad[: local.shape[0]] = local
+    bufs = [torch.empty_like(pad) for _ in range(world)]
+    dist.all_gather(bufs, pad, group=group)
+    return torch.cat([bufs[r][: sizes[r]] for r in range(world)], dim=0)
+
+
 def gather_samples(local: torch.Tensor, total: int, group=None) -> torch.Tensor:
     """The single end-of-run collective: all ranks receive all samples, in global order."""
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
         return local
     world = dist.get_world_size(group)
-    sizes = [shard_bounds(total, world, r) for r in range(world)]
-    maxn = max(hi - lo for lo, hi in sizes)
-    pad = torch.zeros((maxn,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
-    pad[: local.shape[0]] = local
-    bufs = [torch.empty_like(pad) for _ in range(world)]
-    dist.all_gather(bufs, pad, group=group)
-    return torch.cat([bufs[r][: hi - lo] for r, (lo, hi) in enumerate(sizes)], dim=0)
+    sizes = [hi - lo for lo, hi in (shard_bounds(total, world, r) for r in range(world))]
+    return gather_blocks(local, sizes, group)
 
 
 def _set_batch_hint(model, total: int):

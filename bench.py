@@ -346,39 +346,73 @@ def cpu_and_parity(case, dev, want_parity=True, chain_steps=1000, chain_batch=2)
 
 
 # ----------------------------------------------------------------------------------------------------------------------
-def run_pipeline(a, dev):
-    """One subject of BASELINE configs[4] on one GPU, from raw 48 kHz stereo audio: native front end (vq-wav2vec conv features +
-    lip regressor, stub geometry / synthetic weights) -> guide tokens -> VQ keyframes -> body ddim100 -> face ddim100."""
-    from audio2photoreal_amd.model.cfg_sampler import ClassifierFreeSampleModel
-    from audio2photoreal_amd.model.guide import GuideTransformer
-    from audio2photoreal_amd.model.vqvae import TemporalVertexCodec
-    from audio2photoreal_amd.model_util import create_model_and_diffusion, default_args, load_model
-    from audio2photoreal_amd.sample.generate import _replace_keyframes
-    from audio2photoreal_amd.spec import GuideSpec, TokenizerSpec, face_spec, pose_spec
-    from audio2photoreal_amd.synthetic import (cond_tokens_for_frames, synthetic_audio, synthetic_frontend_state_dict, synthetic_guide_state_dict,
-                                               synthetic_state_dict, synthetic_tokenizer_state_dict)
-    B, T = a.batch, a.frames
-    S0, gs, ts = cond_tokens_for_frames(T), GuideSpec(), TokenizerSpec()
-    guide = GuideTransformer(tokens=gs.tokens, num_layers=gs.num_layers, dim=gs.dim, emb_len=gs.emb_len,
-                             num_audio_layers=gs.num_audio_layers, max_batch=B, max_positions=96)
-    guide.load_state_dict(synthetic_guide_state_dict(gs, 10), strict=False)
-    tok = TemporalVertexCodec(ts.n_vertices, ts.latent_dim, ts.categories, ts.residual_depth)
-    tok.load_state_dict(synthetic_tokenizer_state_dict(ts, 10), strict=False)
-    models = {}
-    for fmt, spec in (("pose", pose_spec()), ("face", face_spec())):
-        m, d = create_model_and_diffusion(default_args(fmt, timestep_respacing="ddim100"), "test", precision=a.precision, max_batch=B,
-                                          audio_frontend="native")
-        load_model(m, {**synthetic_state_dict(spec, 10), **synthetic_frontend_state_dict(10, lip=fmt == "face")})
-        if fmt == "pose":
-            m.setup_guide_predictor(guide.to(dev).eval(), tok.to(dev))
-        models[fmt] = (spec, ClassifierFreeSampleModel(m.to(dev).eval()), d)
-    nk = len(range(T)[::30])
-    audio = synthetic_audio(10, B, T).to(dev)          # y["audio"]: z-normalised 48 kHz stereo [B, T * 1600, 2]
+class PipelineSubject:
+    """One subject of BASELINE configs[4] (its own weight set: synthetic seed 10 + subject) on one GPU, from raw 48 kHz stereo audio:
+    native front end (vq-wav2vec conv features + lip regressor, stub geometry / synthetic weights) -> guide tokens -> VQ keyframes
+    -> body ddim -> face ddim, for the samples `sample_ids` of that subject.  Every random draw is a function of (subject, global
+    sample id): how the samples of a subject are split over ranks does not change them."""
 
-    def once():
-        guide.invalidate_cond()                       # every run pays the hoisted conditioning of all three models
-        for _, cfg_m, _ in models.values():
+    def __init__(self, a, dev, subject, sample_ids, subject_samples=None):
+        from audio2photoreal_amd.model.cfg_sampler import ClassifierFreeSampleModel
+        from audio2photoreal_amd.model.guide import GuideTransformer
+        from audio2photoreal_amd.model.vqvae import TemporalVertexCodec
+        from audio2photoreal_amd.model_util import create_model_and_diffusion, default_args, load_model
+        from audio2photoreal_amd.sample_parallel import derive_seed, per_sample_noise
+        from audio2photoreal_amd.spec import GuideSpec, TokenizerSpec, face_spec, pose_spec
+        from audio2photoreal_amd.synthetic import (synthetic_frontend_state_dict, synthetic_guide_state_dict, synthetic_state_dict,
+                                                   synthetic_tensor, synthetic_tokenizer_state_dict)
+        self.dev, self.subject, self.ids = dev, subject, list(sample_ids)
+        B, T = len(self.ids), a.frames
+        self.B, self.T = B, T
+        seed = 10 + subject
+        respacing = a.respacing or "ddim100"
+        gs, ts = GuideSpec(), TokenizerSpec()
+        self.guide = GuideTransformer(tokens=gs.tokens, num_layers=gs.num_layers, dim=gs.dim, emb_len=gs.emb_len,
+                                      num_audio_layers=gs.num_audio_layers, max_batch=B, max_positions=96)
+        self.guide.load_state_dict(synthetic_guide_state_dict(gs, seed), strict=False)
+        tok = TemporalVertexCodec(ts.n_vertices, ts.latent_dim, ts.categories, ts.residual_depth)
+        tok.load_state_dict(synthetic_tokenizer_state_dict(ts, seed), strict=False)
+        self.models = {}
+        for fmt, spec in (("pose", pose_spec()), ("face", face_spec())):
+            m, d = create_model_and_diffusion(default_args(fmt, timestep_respacing=respacing), "test", precision=a.precision, max_batch=B,
+                                              audio_frontend="native")
+            load_model(m, {**synthetic_state_dict(spec, seed), **synthetic_frontend_state_dict(seed, lip=fmt == "face")})
+            if fmt == "pose":
+                m.setup_guide_predictor(self.guide.to(dev).eval(), tok.to(dev))
+            if subject_samples and subject_samples > B:     # a block of a subject's samples: take the kernel family of the whole subject
+                m.global_batch_hint = subject_samples       # (include/a2p_hip.h a2p_set_batch_hint; sample_parallel does the same)
+            self.models[fmt] = (spec, ClassifierFreeSampleModel(m.to(dev).eval()), d)
+        self.nk = len(range(T)[::30])
+        # y["audio"]: z-normalised 48 kHz stereo [B, T * 1600, 2], one stream per (subject, global sample id)
+        self.audio = torch.stack([synthetic_tensor(seed, f"audio/{g}", (T * 1600, 2)) for g in self.ids]).to(dev)
+        n_uni = self.nk * tok.residual_depth
+        self.uniforms = torch.stack([torch.rand(n_uni, generator=torch.Generator().manual_seed(derive_seed(4321, subject, 1, g)))
+                                     for g in self.ids], dim=1)                                   # [n, B]: column b belongs to sample ids[b]
+        self.noise = {fmt: per_sample_noise((B, spec.nfeats, 1, T), [derive_seed(4321, subject, 2 + k, g) for g in self.ids]).to(dev)
+                      for k, (fmt, (spec, _, _)) in enumerate(self.models.items())}
+
+    def _invalidate(self):
+        self.guide.invalidate_cond()                       # every run pays the hoisted conditioning of all three models
+        for _, cfg_m, _ in self.models.values():
             cfg_m.model.invalidate_cond()
+
+    def _body(self, feats):
+        from audio2photoreal_amd.sample.generate import _replace_keyframes
+        dev, B, T = self.dev, self.B, self.T
+        spec, cfg, diff = self.models["pose"]
+        y = {"cond_embed": feats, "keyframes": torch.zeros(B, self.nk, 104, device=dev), "mask": torch.ones(B, 1, 1, T, dtype=torch.bool, device=dev),
+             "scale": torch.full((B,), 2.0, device=dev)}
+        y["keyframes"] = _replace_keyframes({"y": y}, cfg, self.uniforms).to(dev)
+        return y, lambda: diff.ddim_sample_loop(cfg, (B, spec.nfeats, 1, T), noise=self.noise["pose"], clip_denoised=False, model_kwargs={"y": y})
+
+    def _face(self, face_ce):
+        spec, cfg, diff = self.models["face"]
+        yf = {"cond_embed": face_ce, "scale": torch.full((self.B,), 10.0, device=self.dev)}
+        return diff.ddim_sample_loop(cfg, (self.B, spec.nfeats, 1, self.T), noise=self.noise["face"], clip_denoised=False, model_kwargs={"y": yf})
+
+    def sequential(self):
+        """Stage by stage with a synchronise in between: the per-stage times."""
+        self._invalidate()
         torch.cuda.synchronize()
         st, t0 = {}, time.perf_counter()
 
@@ -387,74 +421,145 @@ def run_pipeline(a, dev):
             torch.cuda.synchronize()
             t1 = time.perf_counter()
             st[name], t0 = (t1 - t0) * 1e3, t1
-        feats = models["pose"][1].model.audio_frontend.encode_audio(audio)     # encode_audio: shared by the guide, body and face models
-        face_ce = models["face"][1].model.audio_frontend.encode_lip(audio, feats)  # encode_lip: + the lip regressor's 1014 channels
+        feats = self.models["pose"][1].model.audio_frontend.encode_audio(self.audio)     # encode_audio: shared by the guide, body and face models
+        face_ce = self.models["face"][1].model.audio_frontend.encode_lip(self.audio, feats)  # encode_lip: + the lip regressor's 1014 channels
         mark("audio_front_end_ms")
-        spec, cfg, diff = models["pose"]
-        y = {"cond_embed": feats, "keyframes": torch.zeros(B, nk, 104, device=dev), "mask": torch.ones(B, 1, 1, T, dtype=torch.bool, device=dev),
-             "scale": torch.full((B,), 2.0, device=dev)}
-        torch.manual_seed(101)                        # guide uniforms + body x_T (the overlapped run draws them in another order)
-        y["keyframes"] = _replace_keyframes({"y": y}, cfg).to(dev)
+        _, run_body = self._body(feats)
         mark("guide_tokens_and_vq_decode_ms")
-        body = diff.ddim_sample_loop(cfg, (B, spec.nfeats, 1, T), clip_denoised=False, model_kwargs={"y": y})
-        mark("body_ddim100_ms")
-        spec, cfg, diff = models["face"]
-        yf = {"cond_embed": face_ce, "scale": torch.full((B,), 10.0, device=dev)}
-        torch.manual_seed(202)
-        face = diff.ddim_sample_loop(cfg, (B, spec.nfeats, 1, T), clip_denoised=False, model_kwargs={"y": yf})
-        mark("face_ddim100_ms")
+        body = run_body()
+        mark("body_ddim_ms")
+        face = self._face(face_ce)
+        mark("face_ddim_ms")
         assert bool(torch.isfinite(body).all()) and bool(torch.isfinite(face).all())
-        st["_out"] = (body, face)
-        return st
-    def overlapped():
+        return st, body, face
+
+    def overlapped(self):
         """The same work with the dependency graph it actually has: the face model needs only the audio features, the body model
         needs the guide's keyframes.  Face runs on one HIP stream; guide (one CU per sequence, latency-bound) -> VQ decode -> body on
         another, so the guide transformer's 54 ms pass under the face model's denoising steps."""
-        guide.invalidate_cond()
-        for _, cfg_m, _ in models.values():
-            cfg_m.model.invalidate_cond()
+        dev = self.dev
+        self._invalidate()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        feats = models["pose"][1].model.audio_frontend.encode_audio(audio)
-        face_ce = models["face"][1].model.audio_frontend.encode_lip(audio, feats)
+        feats = self.models["pose"][1].model.audio_frontend.encode_audio(self.audio)
+        face_ce = self.models["face"][1].model.audio_frontend.encode_lip(self.audio, feats)
         main = torch.cuda.current_stream(dev)
         s_face, s_body = torch.cuda.Stream(dev), torch.cuda.Stream(dev)
         s_face.wait_stream(main)
         s_body.wait_stream(main)
         with torch.cuda.stream(s_face):           # enqueued first: nothing on this stream ever blocks the host
-            spec, cfg, diff = models["face"]
-            yf = {"cond_embed": face_ce, "scale": torch.full((B,), 10.0, device=dev)}
-            torch.manual_seed(202)
-            face = diff.ddim_sample_loop(cfg, (B, spec.nfeats, 1, T), clip_denoised=False, model_kwargs={"y": yf})
+            face = self._face(face_ce)
         with torch.cuda.stream(s_body):
-            spec, cfg, diff = models["pose"]
-            y = {"cond_embed": feats, "keyframes": torch.zeros(B, nk, 104, device=dev), "mask": torch.ones(B, 1, 1, T, dtype=torch.bool, device=dev),
-                 "scale": torch.full((B,), 2.0, device=dev)}
-            torch.manual_seed(101)
-            y["keyframes"] = _replace_keyframes({"y": y}, cfg).to(dev)
-            body = diff.ddim_sample_loop(cfg, (B, spec.nfeats, 1, T), clip_denoised=False, model_kwargs={"y": y})
+            body = self._body(feats)[1]()
         main.wait_stream(s_face)
         main.wait_stream(s_body)
         torch.cuda.synchronize()
-        dt = time.perf_counter() - t0
-        return dt, body, face
+        return time.perf_counter() - t0, body, face
 
-    once().pop("_out")                        # contexts, weight upload, allocator warm-up
-    st = once()
-    body_seq, face_seq = st.pop("_out")
+    def release(self):
+        for _, cfg_m, _ in self.models.values():
+            cfg_m.model.release()
+
+
+def run_pipeline(a, dev):
+    """One subject on one GPU (`bench.py --pipeline`): sequential stage times, the two-stream schedule, and that both give the
+    same samples bit for bit."""
+    B = a.batch
+    subj = PipelineSubject(a, dev, 0, list(range(B)))
+    subj.sequential()                         # contexts, weight upload, allocator warm-up
+    st, body_seq, face_seq = subj.sequential()
     total = sum(st.values()) / 1e3
-    _, body_ov, face_ov = overlapped()
+    _, body_ov, face_ov = subj.overlapped()
     same = bool(torch.equal(body_ov, body_seq)) and bool(torch.equal(face_ov, face_seq))
     assert same, "the two-stream schedule changed the samples"
-    ov = min(overlapped()[0] for _ in range(2))
-    print(json.dumps({"metric": "end-to-end sec/sample: audio front end -> guide transformer -> body ddim100 -> face ddim100, 600 frames, from raw "
-                                "48 kHz audio (BASELINE configs[4] shape, one subject, one GPU)",
-                      "value": round(min(total, ov) / B, 5), "unit": "s/sample", "higher_is_better": False, "n_gpus": 1, "batch": B,
-                      "dtype": a.precision, "data": "synthetic", "total_s": round(min(total, ov), 4),
-                      "sequential_total_s": round(total, 4), "overlapped_total_s": round(ov, 4), "overlapped_equals_sequential": same,
-                      "value_note": "overlapped = face on one HIP stream, guide -> VQ -> body on another (the face model does not depend on "
-                                    "the guide); stages_ms are the per-stage times of the sequential run",
-                      "stages_ms": {k: round(v, 2) for k, v in st.items()}}))
+    ov = min(subj.overlapped()[0] for _ in range(2))
+    line = {"metric": "end-to-end sec/sample: audio front end -> guide transformer -> body ddim -> face ddim, from raw "
+                      "48 kHz audio (BASELINE configs[4] shape, one subject, one GPU)",
+            "value": round(min(total, ov) / B, 5), "unit": "s/sample", "higher_is_better": False, "n_gpus": 1, "batch": B, "frames": a.frames,
+            "respacing": a.respacing or "ddim100", "dtype": a.precision, "data": "synthetic", "total_s": round(min(total, ov), 4),
+            "sequential_total_s": round(total, 4), "overlapped_total_s": round(ov, 4), "overlapped_equals_sequential": same,
+            "value_note": "overlapped = face on one HIP stream, guide -> VQ -> body on another (the face model does not depend on "
+                          "the guide); stages_ms are the per-stage times of the sequential run",
+            "stages_ms": {k: round(v, 2) for k, v in st.items()}}
+    print(json.dumps(line))
+    return line
+
+
+def pipeline_placement(subjects, samples, world):
+    """rank -> [(subject, first sample, one-past-last sample)] for BASELINE configs[4] (`subjects` weight sets x `samples` samples over
+    `world` GPUs).  world >= subjects: world // subjects ranks per weight set (the reference ships one checkpoint pair per subject, so a
+    rank holds ONE subject's weights), each taking a contiguous block of that subject's samples; the world % subjects leftover ranks join
+    the first subjects.  world < subjects: subjects are dealt round-robin, all samples of a subject on its rank."""
+    from audio2photoreal_amd.sample_parallel import shard_bounds
+    plan = [[] for _ in range(world)]
+    if world >= subjects:
+        base, extra = divmod(world, subjects)
+        r = 0
+        for s in range(subjects):
+            n = base + (1 if s < extra else 0)
+            for k in range(n):
+                lo, hi = shard_bounds(samples, n, k)
+                plan[r].append((s, lo, hi))
+                r += 1
+    else:
+        for s in range(subjects):
+            plan[s % world].append((s, 0, samples))
+    return plan
+
+
+def run_pipeline_job(a, dev, rank, world, dist, coll_dev):
+    """BASELINE configs[4] as a job: `--subjects` weight sets x `--batch` samples each over `--gpus` ranks (placement above), the
+    two-stream schedule per (rank, subject), NO communication until the one gather of all [body | face] samples at the end.
+    value = end-to-end seconds per sample = max-over-ranks wall time / (subjects x samples)."""
+    from audio2photoreal_amd.sample_parallel import gather_blocks
+    S, N = a.subjects, a.batch
+    plan = pipeline_placement(S, N, world)
+    mine = [(s, lo, hi) for (s, lo, hi) in plan[rank] if hi > lo]
+    units = [PipelineSubject(a, dev, s, list(range(lo, hi)), subject_samples=N) for (s, lo, hi) in mine]
+    for u in units:
+        u.overlapped()                        # contexts, weight upload, allocator warm-up
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    dts, outs = [], None
+    for _ in range(max(1, a.repeats)):
+        barrier()
+        t0 = time.perf_counter()
+        outs = [u.overlapped()[1:] for u in units]
+        barrier()
+        dts.append(time.perf_counter() - t0)
+    if world > 1:
+        tt = torch.tensor(dts, device=coll_dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dts = [float(v) for v in tt.tolist()]
+    dt = statistics.median(dts)
+    T = a.frames
+    local = (torch.cat([torch.cat([b, f], dim=1) for (b, f) in outs], dim=0) if outs else torch.zeros(0, 104 + 256, 1, T, device=dev)).contiguous()
+    sizes = [sum(hi - lo for (_, lo, hi) in plan[r]) for r in range(world)]
+    barrier()
+    t0 = time.perf_counter()
+    allx = gather_blocks(local.to(coll_dev), sizes) if world > 1 else local
+    torch.cuda.synchronize()
+    gather_ms = (time.perf_counter() - t0) * 1e3 if world > 1 else None
+    assert allx.shape[0] == S * N and bool(torch.isfinite(allx).all())
+    if rank == 0:
+        order = [(s, g) for r in range(world) for (s, lo, hi) in plan[r] for g in range(lo, hi)]   # (subject, sample) of every gathered row
+        digest = {f"{s}/{g}": float(allx[i].double().abs().sum().cpu()) for i, (s, g) in enumerate(order)}
+        line = {"metric": "end-to-end sec/sample: audio front end -> guide transformer -> body ddim -> face ddim, from raw 48 kHz audio "
+                          f"(BASELINE configs[4]: {S} subjects x {N} samples)",
+                "value": round(dt / (S * N), 5), "unit": "s/sample", "higher_is_better": False, "n_gpus": world, "steps": 1, "warmup": 1,
+                "scaling": "strong", "dtype": a.precision, "data": "synthetic", "total_s": round(dt, 4), "repeats_s": [round(t, 4) for t in dts],
+                "gather_ms": gather_ms, "vs_baseline": None,
+                "config": {"workload": f"{S} subjects (weight sets) x {N} samples, T={T}, {a.respacing or 'ddim100'} body + face, native audio front end",
+                           "placement": {str(r): [[s, lo, hi] for (s, lo, hi) in plan[r]] for r in range(world)},
+                           "parallelism": f"subject/sample-parallel x{world}: no communication before the final gather"},
+                "sample_digests": digest}
+        print(json.dumps(line), flush=True)
+    for u in units:
+        u.release()
 
 
 def main():
@@ -475,6 +580,13 @@ def main():
     ap.add_argument("--pipeline", action="store_true",
                     help="instead of the step benchmark: BASELINE configs[4] shape on this GPU for one subject -- audio features -> "
                          "guide transformer tokens -> VQ keyframes -> body ddim100 -> face ddim100 (demo/demo.py:156-216), sec/sample")
+    ap.add_argument("--subjects", type=int, default=1,
+                    help="with --pipeline: BASELINE configs[4] as a job -- this many subjects (weight sets) x --batch samples each, placed over "
+                         "--gpus ranks (world // subjects ranks per subject), one gather at the end")
+    ap.add_argument("--respacing", default=None, help="with --pipeline: timestep respacing of both diffusion models (default ddim100; tests use ddim5)")
+    ap.add_argument("--total-samples", type=int, default=0,
+                    help="STRONG scaling (BASELINE configs[3]): a fixed number of samples split over --gpus ranks (contiguous blocks; a rank may "
+                         "hold none) instead of --batch samples per GPU; the pose model then steps its ddim100 chain")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--no-parity", action="store_true", help="skip the parity legs (the oracle still times the cpu_baseline)")
@@ -514,35 +626,63 @@ def main():
     from audio2photoreal_amd.sample_parallel import gather_samples, shard_bounds
 
     if a.pipeline:
-        return run_pipeline(a, dev)
+        if world == 1 and a.subjects == 1:
+            return run_pipeline(a, dev)
+        run_pipeline_job(a, dev, rank, world, dist, coll_dev)
+        if world > 1:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
     B, T = a.batch, a.frames
-    lo, hi = shard_bounds(world * B, world, rank)          # this rank's block of the global batch (weak scaling: B per GPU)
-    case = Case(a.model, B, T, a.precision, dev, list(range(lo, hi)))
-    case.setup()
+    strong = a.total_samples > 0
+    total = a.total_samples if strong else world * B
+    lo, hi = shard_bounds(total, world, rank)              # this rank's block of the global batch (weak scaling: B per GPU; strong: total / world)
+    B = hi - lo
+    assert not (rank == 0 and B == 0), "no samples at all"
+    case = None
+    if B > 0:                                              # a rank without samples (strong scaling, total < world) only joins the collectives
+        if strong and a.model == "pose":
+            case = Case(a.model, B, T, a.precision, dev, list(range(lo, hi)), respacing="ddim100", sampler="ddim")
+        else:
+            case = Case(a.model, B, T, a.precision, dev, list(range(lo, hi)))
+        if world > 1:
+            case.model.global_batch_hint = total           # every shard takes the kernel family of the unsharded batch (a2p_set_batch_hint)
+        case.setup()
 
     def barrier():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    dts = time_case(case, a.steps, a.warmup, a.repeats, barrier)
+    if case is not None:
+        dts = time_case(case, a.steps, a.warmup, a.repeats, barrier)
+    else:
+        dts = []
+        for _ in range(a.repeats):
+            barrier()
+            barrier()
+            dts.append(0.0)
     if world > 1:   # max over ranks per repeat, then the median repeat
         tt = torch.tensor(dts, device=coll_dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dts = [float(v) for v in tt.tolist()]
     dt = statistics.median(dts)
-    assert torch.isfinite(case.state["x"]).all(), "non-finite samples"
+    assert case is None or torch.isfinite(case.state["x"]).all(), "non-finite samples"
 
     # ---- the single end-of-run collective (outside the timed region): all ranks receive all samples, in global order ----
     gather_ms = None
     if world > 1:
-        mine = case.state["x"].contiguous().to(coll_dev)
+        if case is not None:
+            mine = case.state["x"].contiguous().to(coll_dev)
+        else:
+            from audio2photoreal_amd.spec import face_spec, pose_spec
+            mine = torch.zeros(0, (face_spec() if a.model == "face" else pose_spec()).nfeats, 1, T, device=coll_dev)
         barrier()
         t0 = time.perf_counter()
-        allx = gather_samples(mine, world * B)
+        allx = gather_samples(mine, total)
         torch.cuda.synchronize()
         gather_ms = (time.perf_counter() - t0) * 1e3
-        assert allx.shape[0] == world * B and bool(torch.isfinite(allx).all())
+        assert allx.shape[0] == total and bool(torch.isfinite(allx).all())
 
     kernels, roofline = {}, None
     if rank == 0 and not a.no_kernel_timing:
@@ -567,7 +707,7 @@ def main():
             if parity and a.write_parity:
                 with open(a.write_parity, "w") as f:
                     json.dump(parity, f, indent=1)
-        if not a.no_legs and a.model == "face" and B == 8 and a.precision != "fp32":
+        if not a.no_legs and a.model == "face" and B == 8 and a.precision != "fp32" and not strong:
             case.model.release()           # free the headline context before the larger ones
             if a.precision != "bf16":
                 legs["bf16"] = leg_record(Case("face", 8, T, "bf16", dev, list(range(8))), a.steps, a.warmup, a.repeats)
@@ -587,23 +727,28 @@ def main():
                                     "latency bound, not compute bound")
 
     if rank == 0:
-        value = world * a.steps / dt
+        # weak scaling: every rank steps its own B samples -> world x steps; strong scaling: ONE job of `total` samples -> steps
+        value = (1 if strong else world) * a.steps / dt
         peak = PEAK_F32_TFLOPS if a.precision == "fp32" else PEAK_BF16_TFLOPS
         spec, S0 = case.spec, case.S0
         line = {
-            "metric": f"diffusion denoise steps/sec ({a.model}, {T}-frame seq, batch {B} per GPU, CFG)", "value": round(value, 4),
+            "metric": (f"diffusion denoise steps/sec ({a.model}, {T}-frame seq, {total} samples over {world} GPU(s), CFG)" if strong else
+                       f"diffusion denoise steps/sec ({a.model}, {T}-frame seq, batch {B} per GPU, CFG)"), "value": round(value, 4),
             "unit": "steps/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
-            "ms_per_step": round(1e3 * dt / a.steps, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "ms_per_step": round(1e3 * dt / a.steps, 4), "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None,
             "dtype": a.precision, "data": "synthetic",
-            "config": {"workload": f"{a.model} FiLM denoiser {spec.num_layers}L/{spec.num_heads}H d{spec.latent_dim}, 1000-step DDPM p_sample chain, B={B}/GPU x2 CFG, "
-                                   f"T={T}, {S0}+2 cond tokens", "global_batch": B * world, "parallelism": f"sample-parallel x{world}",
+            "config": {"workload": f"{a.model} FiLM denoiser {spec.num_layers}L/{spec.num_heads}H d{spec.latent_dim}, "
+                                   f"{'ddim100 step' if case.sampler == 'ddim' else '1000-step DDPM p_sample chain'}, B={B}/GPU x2 CFG, "
+                                   f"T={T}, {S0}+2 cond tokens", "global_batch": total,
+                       "parallelism": f"sample-parallel x{world}" + (f" (strong scaling: {total} samples in contiguous blocks, {B} on rank 0)" if strong else ""),
                        "dtype_note": ("16-bit MFMA operands are IEEE half instead of the bfloat16 BASELINE configs[1] names: same MFMA rate and "
                                       "kernels, and the only 16-bit format that meets the north_star's 1e-3 on the loop's return value "
                                       "(parity record); the bfloat16 run of the same workload is legs.bf16") if a.precision == "fp16" else None},
             "repeats": a.repeats, "repeats_ms_per_step": [round(1e3 * t / a.steps, 4) for t in dts],
-            "value_note": "steps of every rank / max-over-ranks time (median repeat); one step advances B samples per GPU",
-            "sample_steps_per_sec": round(value * B, 3),
-            "decoder_tflops": round(world * case.step_flops() * a.steps / dt / 1e12, 2),
+            "value_note": ("steps of the whole job / max-over-ranks time (median repeat); one step advances all samples of the job" if strong else
+                           "steps of every rank / max-over-ranks time (median repeat); one step advances B samples per GPU"),
+            "sample_steps_per_sec": round(value * (total if strong else B), 3),
+            "decoder_tflops": round((total / B) * case.step_flops() * a.steps / dt / 1e12, 2),
             "decoder_mfma_frac": round(case.step_flops() * a.steps / dt / 1e12 / peak, 4),
             "prepare_s": round(case.prepare_s, 4), "gather_ms": gather_ms,
             "roofline": roofline, "kernels": kernels, "cpu_baseline": cpu, "parity": parity, "legs": legs or None,

@@ -203,6 +203,16 @@ int a2p_set_batch_hint(a2p_ctx* ctx, int32_t global_batch);
  * counterpart (its torch CPU / CUDA fp32 path cannot overflow on these models). */
 int a2p_check_finite(a2p_ctx* ctx, void* stream);
 
+/* ---- validity envelope of the 16-bit modes ----------------------------------------
+ * The largest row maximum of the scaled attention scores q.k / sqrt(head_dim) that any self- or cross-attention query of the
+ * denoiser saw since the last call (synchronises `stream`, then resets; -inf when no attention ran).  The operand rounding of the
+ * 16-bit modes becomes a logit error proportional to the logits' magnitude, and softmax turns logit errors into probability
+ * errors one for one: measured on the CPU model of the rounding sites and on the GPU (profiles/r04_trained_like_budget.json,
+ * tests/test_hip_round4.py), IEEE-half operands hold <= 1e-3 on the loop's return value up to a maximum of ~13-15 and reach
+ * 2.4e-3 at ~29; bfloat16 is 8x worse throughout.  The Python model mirror warns (A2PPrecisionWarning) above 16 in the 16-bit
+ * modes; precision="fp32" is the answer there.  No reference counterpart (its path is fp32). */
+int a2p_attention_logit_max(a2p_ctx* ctx, float* max_logit_host, void* stream);
+
 /* ---- run-time switches: the A2P_* environment variables that steer a forward (INTEGRATION.md "Environment switches") are read
  * when the context is created; a host that changes one afterwards calls this (the Python mirror does, model/diffusion.py). */
 int a2p_reload_env(a2p_ctx* ctx);
