@@ -54,9 +54,13 @@ class A2PGuideConfig(C.Structure):
 
 
 class A2PFrontendConfig(C.Structure):
-    _fields_ = [(n, C.c_int32) for n in (
+    _fields_ = ([(n, C.c_int32) for n in (
         "conv_dim", "resample", "lip", "d_model", "num_heads", "ff_size", "enc_layers", "dec_layers", "lip_out", "lip_pad",
-        "chunk_frames", "samples_per_frame", "max_batch", "max_frames", "conv_16bit")] + [("reserved", C.c_int32 * 1)]
+        "chunk_frames", "samples_per_frame", "max_batch", "max_frames", "conv_16bit",
+        "a_group_norm", "l_group_norm", "a_activation", "l_activation", "a_log_compression", "l_log_compression", "a_skip", "l_skip")]
+        + [("a_residual_scale", C.c_float), ("l_residual_scale", C.c_float), ("l_layers", C.c_int32), ("agg_layers", C.c_int32),
+           ("agg_skip", C.c_int32), ("agg_residual_scale", C.c_float), ("agg_conv_bias", C.c_int32), ("agg_zero_pad", C.c_int32),
+           ("agg_activation", C.c_int32), ("reserved", C.c_int32 * 2)])
 
 
 class A2PError(RuntimeError):
@@ -67,9 +71,10 @@ class A2PPrecisionWarning(UserWarning):
     """The checkpoint / inputs leave the range the 16-bit throughput modes were validated on (FiLMTransformer.check_finite)."""
 
 
-# largest row maximum of the scaled attention scores up to which the IEEE-half mode holds the 1e-3 parity bar on the loop's
-# return value (profiles/r04_trained_like_budget.json: 9.3e-4 at 13.1, 2.8e-3 at 29.3)
-LOGIT_ENVELOPE_FP16 = 16.0
+# Row maximum of the scaled attention scores beyond which the 16-bit modes are outside what the parity tests cover
+# (profiles/r04_trained_like_budget.json, IEEE half, error of the ddim loop's return value: q/k rows x2 -> maximum 13.5, 5.1e-4;
+# every weight x2 -> 13.1, 9.3e-4; q/k rows x3 -> 29.3, 2.8e-3; the xavier fixtures reach 17.7 late in the ddim10 loop at 3.7e-4)
+LOGIT_ENVELOPE_FP16 = 20.0
 
 
 _libs = {}

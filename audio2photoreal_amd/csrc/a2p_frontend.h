@@ -14,6 +14,12 @@
 // ReLU, (k, s) = (10,5) (8,4) (4,2) (4,2) (4,2) (1,1) (1,1) (1,1)) and the resampler is either torchaudio's documented
 // windowed-sinc kernel (sinc_interp_hann, lowpass_filter_width 6, rolloff 0.99: "parity unpinned") or the plain 3:1
 // decimation the golden generator's stub uses.
+//
+// Round 4: fairseq's published blocks behind configuration flags (a2p_frontend_config a_* / l_* / agg_*), so that a real
+// vq-wav2vec / wav2vec-large checkpoint's on-path tensors are consumed instead of refused: Conv1d -> Fp32GroupNorm(1, C, affine)
+// -> ReLU | GELU per layer, skip connections, log compression (ConvFeatureExtractionModel), and the lip encoder's ConvAggregator
+// (causal replicate / zero padding, kernels 2..13, GroupNorm, skip connections with residual scale).  Restated from fairseq 0.12
+// models/wav2vec/wav2vec.py -- absent offline: PARITY UNPINNED (oracle/frontend_oracle.py carries the same restatement).
 #pragma once
 
 struct a2p_frontend_ctx {
@@ -25,6 +31,9 @@ struct a2p_frontend_ctx {
   std::map<std::string, Buf> w;
   bool finalized = false;
   std::vector<Buf> conv_a, conv_l;  // repacked conv weights [Co][k*Ci] of the audio / lip feature extractors (layer 0: [Co][32])
+  std::vector<Buf> conv_g;          // repacked ConvAggregator weights [Co][k*Ci] (cfg.agg_layers)
+  Buf pre, gn_part, gn_stat;        // fairseq blocks: fp32 pre-activation rows of a layer, GroupNorm partial sums / {mean, rstd}
+  Buf aggp[2];                      // aggregator: left-padded layer inputs [S + 12][C]
   Buf fir;                          // 41-tap 3:1 resampling kernel
   Buf po_w, po_b;                   // project_output padded to a multiple of 4 outputs (the GEMM epilogue stores float4)
   int lo_pad = 0;
@@ -72,7 +81,7 @@ __global__ void fe_resample_kernel(const float* __restrict__ x, const float* __r
 constexpr int FE0_TB = 64;
 template <typename T>
 __global__ __launch_bounds__(256) void fe_conv0_kernel(const float* __restrict__ x, const float* __restrict__ w, T* __restrict__ out,
-                                                       int64_t T0, int Co, int k, int stride) {
+                                                       int64_t T0, int Co, int k, int stride, int relu = 1) {
   __shared__ float win[FE0_TB * 8 + 16];   // stride <= 8
   const int64_t t0 = (int64_t)blockIdx.x * FE0_TB;
   const int nt = (int)(T0 - t0 < FE0_TB ? T0 - t0 : FE0_TB);
@@ -88,9 +97,93 @@ __global__ __launch_bounds__(256) void fe_conv0_kernel(const float* __restrict__
 #pragma unroll
       for (int j = 0; j < 16; ++j)
         if (j < k) acc = fmaf(wr[j], win[t * stride + j], acc);
-      out[(t0 + t) * Co + c] = from_f32<T>(acc > 0.f ? acc : 0.f);
+      out[(t0 + t) * Co + c] = from_f32<T>((acc > 0.f || !relu) ? acc : 0.f);
     }
   }
+}
+
+// ---- fairseq blocks --------------------------------------------------------------------------------------------------------
+// Fp32GroupNorm(1, C) normalises over ALL channels and frames of one sequence: sum / sum of squares in double, two stages
+// (per-workgroup partials in a fixed order, one finishing workgroup): deterministic.
+__global__ __launch_bounds__(256) void fe_gn_partial_kernel(const float* __restrict__ x, int64_t n, double* __restrict__ part) {
+  __shared__ double sh[2][256];
+  const int64_t per = (n + gridDim.x - 1) / gridDim.x, lo = (int64_t)blockIdx.x * per, hi = lo + per < n ? lo + per : n;
+  double s = 0.0, q = 0.0;
+  for (int64_t i = lo + threadIdx.x; i < hi; i += 256) {
+    const double v = (double)x[i];
+    s += v;
+    q += v * v;
+  }
+  sh[0][threadIdx.x] = s; sh[1][threadIdx.x] = q;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o) { sh[0][threadIdx.x] += sh[0][threadIdx.x + o]; sh[1][threadIdx.x] += sh[1][threadIdx.x + o]; }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) { part[2 * blockIdx.x] = sh[0][0]; part[2 * blockIdx.x + 1] = sh[1][0]; }
+}
+__global__ void fe_gn_final_kernel(const double* __restrict__ part, int nblk, int64_t n, float* __restrict__ stat) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  double s = 0.0, q = 0.0;
+  for (int i = 0; i < nblk; ++i) { s += part[2 * i]; q += part[2 * i + 1]; }
+  const double mean = s / (double)n, var = q / (double)n - mean * mean;
+  stat[0] = (float)mean;
+  stat[1] = (float)(1.0 / sqrt((var > 0.0 ? var : 0.0) + 1e-5));
+}
+
+// Epilogue of one fairseq block on channel-last rows: y = act(GN(pre) * gamma + beta) [+ bias first, aggregator]; skip:
+// y = (y + resid[t * rstride]) * rs; log compression: y = log(|y| + 1).  Output fp32 or 16-bit, at row offset `out_row0`.
+struct FeBlockP {
+  const float* pre;        // [T][C] fp32 pre-activation (conv output)
+  int64_t T;
+  int C;
+  const float* stat;       // {mean, rstd} or NULL (no GroupNorm)
+  const float* gamma;      // [C] GroupNorm affine (NULL with stat == NULL)
+  const float* beta;
+  const float* bias;       // [C] conv bias or NULL
+  int act;                 // 0 ReLU, 1 GELU
+  const void* resid;       // skip input rows [..][C] (same element type as the output) or NULL
+  int64_t rstride;         // residual row of output row t: t * rstride
+  float rs;                // sqrt(residual_scale)
+  int logc;
+  int resid16;             // residual element type: 1 = h16_t, 0 = float
+  void* out;
+  int out16;               // output element type: 1 = h16_t, 0 = float
+};
+__global__ __launch_bounds__(256) void fe_block_kernel(FeBlockP p) {
+  const int64_t i4 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x, n4 = p.T * (p.C / 4);
+  if (i4 >= n4) return;
+  const int64_t t = i4 / (p.C / 4);
+  const int c = (int)(i4 - t * (p.C / 4)) * 4;
+  const float4 v4 = *reinterpret_cast<const float4*>(p.pre + t * p.C + c);
+  float v[4] = {v4.x, v4.y, v4.z, v4.w};
+  const float mean = p.stat ? p.stat[0] : 0.f, rstd = p.stat ? p.stat[1] : 1.f;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    float y = v[e] + (p.bias ? p.bias[c + e] : 0.f);
+    if (p.stat) y = (y - mean) * rstd * p.gamma[c + e] + p.beta[c + e];
+    y = p.act == 1 ? act_gelu(y) : (y > 0.f ? y : 0.f);
+    if (p.resid) {
+      const int64_t ro = t * p.rstride * p.C + c + e;
+      const float r = p.resid16 ? (float)reinterpret_cast<const h16_t*>(p.resid)[ro] : reinterpret_cast<const float*>(p.resid)[ro];
+      y = (y + r) * p.rs;
+    }
+    if (p.logc) y = logf(fabsf(y) + 1.0f);
+    v[e] = y;
+  }
+  if (p.out16) {
+    *reinterpret_cast<h16x4*>(reinterpret_cast<h16_t*>(p.out) + t * p.C + c) = h16x4{(h16_t)v[0], (h16_t)v[1], (h16_t)v[2], (h16_t)v[3]};
+  } else {
+    *reinterpret_cast<float4*>(reinterpret_cast<float*>(p.out) + t * p.C + c) = make_float4(v[0], v[1], v[2], v[3]);
+  }
+}
+
+// the k - 1 causal pad rows in front of an aggregator layer's input: copies of its first row (ReplicationPad1d) or zeros
+template <typename T>
+__global__ void fe_pad_rows_kernel(T* __restrict__ buf, int pad_rows, int C, int zero) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= pad_rows * C) return;
+  buf[i] = zero ? from_f32<T>(0.f) : buf[(int64_t)pad_rows * C + (i % C)];
 }
 
 // fp32 -> 16-bit copy of a repacked conv weight
@@ -151,6 +244,25 @@ __global__ void fe_concat_kernel(const float* __restrict__ cond_in, const float*
 // ---------------------------------------------------------------------------------------------------------------
 static const int kFeK[8] = {10, 8, 4, 4, 4, 1, 1, 1}, kFeS[8] = {5, 4, 2, 2, 2, 1, 1, 1};
 
+// one conv feature extractor's block options (a2p_frontend_config a_* / l_*)
+struct FeStack {
+  int layers, gn, act, logc, skip;
+  float rs;   // sqrt(residual_scale)
+  std::string prefix;
+  bool fairseq() const { return gn || act || logc || skip; }
+};
+static FeStack fe_stack(const a2p_frontend_ctx* f, bool lip) {
+  const a2p_frontend_config& c = f->cfg;
+  FeStack st;
+  st.layers = lip ? ((c.l_layers == 7) ? 7 : 8) : 8;
+  st.gn = lip ? c.l_group_norm : c.a_group_norm; st.act = lip ? c.l_activation : c.a_activation;
+  st.logc = lip ? c.l_log_compression : c.a_log_compression; st.skip = lip ? c.l_skip : c.a_skip;
+  st.rs = sqrtf(lip ? c.l_residual_scale : c.a_residual_scale);
+  st.prefix = lip ? "lip_model.audio_encoder.wav2vec_model.feature_extractor.conv_layers." : "audio_model.feature_extractor.conv_layers.";
+  return st;
+}
+static const char* kAggPrefix = "lip_model.audio_encoder.wav2vec_model.feature_aggregator.conv_layers.";
+
 static int64_t fe_conv_len(int64_t n, int layers = 8) {
   for (int i = 0; i < layers; ++i) n = n < kFeK[i] ? 0 : (n - kFeK[i]) / kFeS[i] + 1;
   return n;
@@ -161,6 +273,11 @@ extern "C" int a2p_frontend_create(const a2p_frontend_config* cfg, a2p_frontend_
   ARG(cfg->conv_dim == 512 && cfg->d_model == 512 && cfg->num_heads == 4 && cfg->ff_size % 64 == 0, "front end: conv_dim / d_model 512, 4 heads");
   ARG(cfg->resample == 0 || cfg->resample == 1, "resample must be 0 (decimate) or 1 (windowed sinc)");
   ARG(cfg->max_batch >= 1 && cfg->max_frames >= 1 && cfg->enc_layers >= 0 && cfg->dec_layers >= 0, "bad capacity");
+  ARG(cfg->agg_layers >= 0 && cfg->agg_layers <= 12 && (cfg->l_layers == 0 || cfg->l_layers == 7 || cfg->l_layers == 8), "bad aggregator / lip feature extractor depth");
+  ARG((cfg->a_activation | cfg->l_activation | cfg->agg_activation) >> 1 == 0, "activation must be 0 (ReLU) or 1 (GELU)");
+  ARG(!cfg->a_skip || cfg->a_residual_scale > 0.f, "a_skip needs a positive a_residual_scale");
+  ARG(!cfg->l_skip || cfg->l_residual_scale > 0.f, "l_skip needs a positive l_residual_scale");
+  ARG(!cfg->agg_skip || cfg->agg_residual_scale > 0.f, "agg_skip needs a positive agg_residual_scale");
   a2p_frontend_ctx* f = new a2p_frontend_ctx();
   f->cfg = *cfg;
   f->core.bf16 = false; f->core.esz = 4; f->core.d = cfg->d_model; f->core.H = cfg->num_heads; f->core.DH = cfg->d_model / cfg->num_heads;
@@ -170,12 +287,22 @@ extern "C" int a2p_frontend_create(const a2p_frontend_config* cfg, a2p_frontend_
   f->core16.use_arena = false;
   auto& e = f->expect;
   const int64_t C = cfg->conv_dim, d = cfg->d_model, ff = cfg->ff_size;
-  for (int i = 0; i < 8; ++i)
-    e["audio_model.feature_extractor.conv_layers." + std::to_string(i) + ".0.weight"] = C * (i ? C : 1) * kFeK[i];
+  auto stack_keys = [&](const FeStack& st) {
+    for (int i = 0; i < st.layers; ++i) {
+      e[st.prefix + std::to_string(i) + ".0.weight"] = C * (i ? C : 1) * kFeK[i];
+      if (st.gn) { e[st.prefix + std::to_string(i) + ".2.weight"] = C; e[st.prefix + std::to_string(i) + ".2.bias"] = C; }
+    }
+  };
+  stack_keys(fe_stack(f, false));
   if (cfg->lip) {
     const std::string L = "lip_model.";
-    for (int i = 0; i < 8; ++i)
-      e[L + "audio_encoder.wav2vec_model.feature_extractor.conv_layers." + std::to_string(i) + ".0.weight"] = C * (i ? C : 1) * kFeK[i];
+    stack_keys(fe_stack(f, true));
+    for (int j = 0; j < cfg->agg_layers; ++j) {
+      const std::string p = kAggPrefix + std::to_string(j);
+      e[p + ".1.weight"] = C * C * (j + 2);
+      if (cfg->agg_conv_bias) e[p + ".1.bias"] = C;
+      e[p + ".3.weight"] = C; e[p + ".3.bias"] = C;
+    }
     e[L + "regression_model.cond_positional_encoding.pe"] = 1024 * d;
     e[L + "regression_model.target_positional_encoding.pe"] = 1024 * d;
     auto attn = [&](const std::string& p) {
@@ -207,7 +334,8 @@ extern "C" int a2p_frontend_destroy(a2p_frontend_ctx* f) {
   for (auto& kv : f->w) buf_free(kv.second);
   for (auto& b : f->conv_a) buf_free(b);
   for (auto& b : f->conv_l) buf_free(b);
-  Buf* all[] = {&f->fir, &f->po_w, &f->po_b, &f->wav, &f->pcm, &f->act[0], &f->act[1], &f->cond, &f->xs, &f->xn, &f->qk, &f->vt, &f->ao, &f->hff, &f->lipf};
+  for (auto& b : f->conv_g) buf_free(b);
+  Buf* all[] = {&f->pre, &f->gn_part, &f->gn_stat, &f->aggp[0], &f->aggp[1], &f->fir, &f->po_w, &f->po_b, &f->wav, &f->pcm, &f->act[0], &f->act[1], &f->cond, &f->xs, &f->xn, &f->qk, &f->vt, &f->ao, &f->hff, &f->lipf};
   for (Buf* b : all) buf_free(*b);
   delete f;
   return 0;
@@ -227,8 +355,9 @@ extern "C" int a2p_frontend_set_weight(a2p_frontend_ctx* f, const char* name, co
                                     "lip_model.project_output."};
     for (const char* p : on_path)
       if (n.rfind(p, 0) == 0 && (f->cfg.lip || n.rfind("lip_model.", 0) != 0)) {
-        set_err("front end: parameter '%s' is on the conditioning path but not implemented by the stub geometry (bias-free conv + ReLU, "
-                "identity aggregator); refusing to skip it", name);
+        set_err("front end: parameter '%s' is on the conditioning path but not part of the configured geometry (a2p_frontend_config: "
+                "group norm %d/%d, lip feature extractor layers %d, aggregator layers %d, aggregator bias %d); refusing to skip it",
+                name, f->cfg.a_group_norm, f->cfg.l_group_norm, fe_stack(f, true).layers, f->cfg.agg_layers, f->cfg.agg_conv_bias);
         return A2P_ERR_NOWEIGHT;
       }
     return 1;
@@ -253,14 +382,15 @@ extern "C" int a2p_frontend_finalize(a2p_frontend_ctx* f, void* stream) {
       return A2P_ERR_NOWEIGHT;
     }
   const int C = f->cfg.conv_dim;
-  auto repack = [&](std::vector<Buf>& dst, const std::string& prefix) -> int {
-    dst.resize(8);
-    for (int i = 0; i < 8; ++i) {
-      const int Ci = i ? C : 1, ld = i ? kFeK[i] * C : 32;
+  auto repack = [&](std::vector<Buf>& dst, const std::string& prefix, int layers, bool agg) -> int {
+    dst.resize(layers);
+    for (int i = 0; i < layers; ++i) {
+      const int k = agg ? i + 2 : kFeK[i];
+      const int Ci = (i || agg) ? C : 1, ld = (i || agg) ? k * C : 32;
       CHK(buf_alloc_tmp(dst[i], (size_t)C * ld * 4));
       const int64_t n = (int64_t)C * ld;
-      fe_repack_kernel<<<(int)((n + 255) / 256), 256, 0, s>>>(FW(f, prefix + std::to_string(i) + ".0.weight"), dst[i].f(), C, Ci, kFeK[i], ld);
-      if (f->conv16 && i > 0) {   // layers 1..7 are GEMMs on 16-bit operands; layer 0 keeps fp32 taps (VALU arithmetic)
+      fe_repack_kernel<<<(int)((n + 255) / 256), 256, 0, s>>>(FW(f, prefix + std::to_string(i) + (agg ? ".1.weight" : ".0.weight")), dst[i].f(), C, Ci, k, ld);
+      if (f->conv16 && (i > 0 || agg)) {   // layers 1..7 are GEMMs on 16-bit operands; layer 0 keeps fp32 taps (VALU arithmetic)
         Buf h;
         CHK(buf_alloc_tmp(h, (size_t)n * 2));
         fe_cast_kernel<<<(int)((n + 255) / 256), 256, 0, s>>>(dst[i].f(), reinterpret_cast<h16_t*>(h.p), n);
@@ -271,8 +401,11 @@ extern "C" int a2p_frontend_finalize(a2p_frontend_ctx* f, void* stream) {
     }
     return 0;
   };
-  CHK(repack(f->conv_a, "audio_model.feature_extractor.conv_layers."));
-  if (f->cfg.lip) CHK(repack(f->conv_l, "lip_model.audio_encoder.wav2vec_model.feature_extractor.conv_layers."));
+  CHK(repack(f->conv_a, fe_stack(f, false).prefix, 8, false));
+  if (f->cfg.lip) {
+    CHK(repack(f->conv_l, fe_stack(f, true).prefix, fe_stack(f, true).layers, false));
+    if (f->cfg.agg_layers) CHK(repack(f->conv_g, kAggPrefix, f->cfg.agg_layers, true));
+  }
   {  // torchaudio _get_sinc_resample_kernel(48000, 16000): orig 3, new 1, base 0.99, width ceil(6 * 3 / 0.99) = 19, 41 taps (float64)
     const double base = 0.99, lpw = 6.0;
     float h[41];
@@ -305,39 +438,130 @@ static int fe_reserve(a2p_frontend_ctx* f, size_t samples48) {
   CHK(buf_alloc_tmp(f->pcm, (n16 + 64) * 4));
   CHK(buf_alloc_tmp(f->act[0], t0 * f->cfg.conv_dim * 4));   // layer-0 output (the largest), later even layers
   CHK(buf_alloc_tmp(f->act[1], t1 * f->cfg.conv_dim * 4));
+  if (fe_stack(f, false).fairseq() || fe_stack(f, true).fairseq() || f->cfg.agg_layers) {
+    CHK(buf_alloc_tmp(f->pre, t0 * f->cfg.conv_dim * 4));           // fp32 pre-activation rows of the widest layer
+    CHK(buf_alloc_tmp(f->gn_part, 1024 * 2 * sizeof(double)));
+    CHK(buf_alloc_tmp(f->gn_stat, 64));
+  }
   f->cap_samples = samples48;
   return 0;
 }
 
-// one mono 48 kHz sequence -> conv features, channel-last [S][C] in the returned buffer.  `lead` zeros are prepended at 16 kHz.
-static int fe_features(a2p_frontend_ctx* f, const float* wav48, int64_t L, int lead, const std::vector<Buf>& cw, const float** out,
-                       int64_t* S_out, hipStream_t s) {
+// GroupNorm statistics {mean, rstd} of n fp32 values -> f->gn_stat
+static int fe_gn_stats(a2p_frontend_ctx* f, const float* x, int64_t n, hipStream_t s) {
+  const int nblk = (int)std::min<int64_t>(1024, (n + 4095) / 4096);
+  fe_gn_partial_kernel<<<nblk, 256, 0, s>>>(x, n, reinterpret_cast<double*>(f->gn_part.p));
+  fe_gn_final_kernel<<<1, 64, 0, s>>>(reinterpret_cast<const double*>(f->gn_part.p), nblk, n, f->gn_stat.f());
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+// one mono 48 kHz sequence -> conv features, channel-last [S][C] fp32 in the returned buffer.  `lead` zeros are prepended at 16 kHz.
+// Stub geometry (st.fairseq() false): Conv1d + ReLU fused into the producing kernel.  fairseq blocks: every layer leaves its conv
+// output in f->pre (fp32), then GroupNorm statistics over the whole [T_i, C] block of the sequence, then fe_block_kernel
+// (affine, activation, skip connection, log compression) writes the next layer's operand rows.
+static int fe_features(a2p_frontend_ctx* f, const float* wav48, int64_t L, int lead, const std::vector<Buf>& cw, const FeStack& st,
+                       const float** out, int64_t* S_out, hipStream_t s) {
   const int C = f->cfg.conv_dim;
+  const bool fq = st.fairseq();
   const int64_t n16 = f->cfg.resample == 0 ? (L + 2) / 3 : (L + 2) / 3;   // x[::3] and ceil(L / 3) have the same length
   if (lead) HIPCHK(hipMemsetAsync(f->pcm.p, 0, (size_t)lead * 4, s));
   fe_resample_kernel<<<(int)((n16 + 255) / 256), 256, 0, s>>>(wav48, f->fir.f(), f->pcm.f() + lead, L, n16, f->cfg.resample);
   int64_t n = n16 + lead;
   const int64_t T0 = (n - kFeK[0]) / kFeS[0] + 1;
   ARG(T0 >= 1, "sequence of %lld samples is shorter than the first conv kernel", (long long)L);
+  // epilogue of layer i on f->pre[To][C]: reads the layer input `in` (To_in rows) for the skip connection, writes act[dst]
+  auto block = [&](int i, int64_t To, const void* in, int64_t Tin, int dst) -> int {
+    const bool last = i == st.layers - 1;
+    if (st.gn) CHK(fe_gn_stats(f, f->pre.f(), To * C, s));
+    FeBlockP bp;
+    memset(&bp, 0, sizeof(bp));
+    bp.pre = f->pre.f(); bp.T = To; bp.C = C;
+    if (st.gn) {
+      bp.stat = f->gn_stat.f();
+      bp.gamma = FW(f, st.prefix + std::to_string(i) + ".2.weight"); bp.beta = FW(f, st.prefix + std::to_string(i) + ".2.bias");
+    }
+    bp.act = st.act;
+    if (st.skip && i > 0) { bp.resid = in; bp.rstride = Tin / To; bp.rs = st.rs; bp.resid16 = f->conv16 ? 1 : 0; }
+    bp.logc = last && st.logc;
+    bp.out = f->act[dst].p; bp.out16 = (f->conv16 && !last) ? 1 : 0;   // the features leave the stack as fp32 in both modes
+    fe_block_kernel<<<(int)((To * (C / 4) + 255) / 256), 256, 0, s>>>(bp);
+    return 0;
+  };
   {
     const dim3 g0((unsigned)((T0 + FE0_TB - 1) / FE0_TB), (unsigned)((C + 255) / 256));
-    if (f->conv16) fe_conv0_kernel<h16_t><<<g0, 256, 0, s>>>(f->pcm.f(), cw[0].f(), reinterpret_cast<h16_t*>(f->act[0].p), T0, C, kFeK[0], kFeS[0]);
-    else fe_conv0_kernel<float><<<g0, 256, 0, s>>>(f->pcm.f(), cw[0].f(), f->act[0].f(), T0, C, kFeK[0], kFeS[0]);
+    if (fq) {
+      fe_conv0_kernel<float><<<g0, 256, 0, s>>>(f->pcm.f(), cw[0].f(), f->pre.f(), T0, C, kFeK[0], kFeS[0], 0);
+      CHK(block(0, T0, nullptr, 0, 0));
+    } else if (f->conv16) {
+      fe_conv0_kernel<h16_t><<<g0, 256, 0, s>>>(f->pcm.f(), cw[0].f(), reinterpret_cast<h16_t*>(f->act[0].p), T0, C, kFeK[0], kFeS[0]);
+    } else {
+      fe_conv0_kernel<float><<<g0, 256, 0, s>>>(f->pcm.f(), cw[0].f(), f->act[0].f(), T0, C, kFeK[0], kFeS[0]);
+    }
   }
   n = T0;
   int cur = 0;
-  for (int i = 1; i < 8; ++i) {
+  for (int i = 1; i < st.layers; ++i) {
     const int64_t To = (n - kFeK[i]) / kFeS[i] + 1;
     ARG(To >= 1, "sequence too short for conv layer %d", i);
-    GemmP p = gemm_base(f->act[cur].p, (int64_t)kFeS[i] * C, cw[i].p, (int64_t)kFeK[i] * C, nullptr, f->act[cur ^ 1].p, C, (int)To, C, kFeK[i] * C);
-    p.act = ACT_RELU;
-    if (f->conv16 && i == 7) p.out_f32 = 1;   // the features leave the stack as fp32 in both modes
+    GemmP p = gemm_base(f->act[cur].p, (int64_t)kFeS[i] * C, cw[i].p, (int64_t)kFeK[i] * C, nullptr, fq ? f->pre.p : f->act[cur ^ 1].p, C, (int)To, C,
+                        kFeK[i] * C);
+    if (fq) {
+      p.out_f32 = f->conv16 ? 1 : 0;    // fp32 pre-activation rows for the GroupNorm statistics
+    } else {
+      p.act = ACT_RELU;
+      if (f->conv16 && i == st.layers - 1) p.out_f32 = 1;   // the features leave the stack as fp32 in both modes
+    }
     CHK(launch_gemm(f->conv16 ? &f->core16 : &f->core, p, s));
+    if (fq) CHK(block(i, To, f->act[cur].p, n, cur ^ 1));
     n = To;
     cur ^= 1;
   }
   *out = f->act[cur].f();
   *S_out = n;
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+// ConvAggregator of the lip encoder (audio_encoder.py:44 `self.wav2vec_model.feature_aggregator(x)`; fairseq ConvAggregator.forward):
+// for layer j (kernel k = j + 2, stride 1): pad k - 1 frames on the left (replicate / zero), Conv1d(C, C, k[, bias]) -> GroupNorm(1, C)
+// -> activation; with skip connections x = (block(x) + x) * sqrt(residual_scale).  feat: [S][C] fp32 -> out: [S][C] fp32.
+static int fe_aggregate(a2p_frontend_ctx* f, const float* feat, int64_t S, float* out, hipStream_t s) {
+  const int C = f->cfg.conv_dim, NL = f->cfg.agg_layers;
+  const size_t esz = f->conv16 ? 2 : 4;
+  for (int b = 0; b < 2; ++b)
+    if (f->aggp[b].bytes < (size_t)(S + 16) * C * 4) CHK(buf_alloc_tmp(f->aggp[b], (size_t)(S + 16) * C * 4));
+  // layer 0's input rows behind its k - 1 = 1 pad row, in the GEMM operand type
+  if (f->conv16) {
+    fe_cast_kernel<<<(int)((S * C + 255) / 256), 256, 0, s>>>(feat, reinterpret_cast<h16_t*>(f->aggp[0].p) + C, S * C);
+  } else {
+    HIPCHK(hipMemcpyAsync(f->aggp[0].f() + C, feat, (size_t)S * C * 4, hipMemcpyDeviceToDevice, s));
+  }
+  int cur = 0;
+  for (int j = 0; j < NL; ++j) {
+    const int k = j + 2, pad = k - 1;
+    const std::string p = kAggPrefix + std::to_string(j);
+    if (f->conv16) fe_pad_rows_kernel<h16_t><<<(pad * C + 255) / 256, 256, 0, s>>>(reinterpret_cast<h16_t*>(f->aggp[cur].p), pad, C, f->cfg.agg_zero_pad);
+    else fe_pad_rows_kernel<float><<<(pad * C + 255) / 256, 256, 0, s>>>(f->aggp[cur].f(), pad, C, f->cfg.agg_zero_pad);
+    // channel-last rows t .. t + k - 1 of the padded buffer = frames t - k + 1 .. t: one contiguous A row of k * C values
+    GemmP g = gemm_base(f->aggp[cur].p, C, f->conv_g[j].p, (int64_t)k * C, f->cfg.agg_conv_bias ? FW(f, p + ".1.bias") : nullptr, f->pre.p, C, (int)S, C, k * C);
+    g.out_f32 = f->conv16 ? 1 : 0;
+    CHK(launch_gemm(f->conv16 ? &f->core16 : &f->core, g, s));
+    CHK(fe_gn_stats(f, f->pre.f(), S * C, s));
+    const bool last = j == NL - 1;
+    FeBlockP bp;
+    memset(&bp, 0, sizeof(bp));
+    bp.pre = f->pre.f(); bp.T = S; bp.C = C; bp.stat = f->gn_stat.f();
+    bp.gamma = FW(f, p + ".3.weight"); bp.beta = FW(f, p + ".3.bias"); bp.act = f->cfg.agg_activation;
+    if (f->cfg.agg_skip) {
+      bp.resid = reinterpret_cast<const char*>(f->aggp[cur].p) + (size_t)pad * C * esz; bp.rstride = 1; bp.rs = sqrtf(f->cfg.agg_residual_scale);
+      bp.resid16 = f->conv16 ? 1 : 0;
+    }
+    if (last) { bp.out = out; bp.out16 = 0; }
+    else { bp.out = reinterpret_cast<char*>(f->aggp[cur ^ 1].p) + (size_t)(k + 1 - 1) * C * esz; bp.out16 = f->conv16 ? 1 : 0; }   // behind the next layer's k pad rows
+    fe_block_kernel<<<(int)((S * (C / 4) + 255) / 256), 256, 0, s>>>(bp);
+    cur ^= 1;
+  }
   HIPCHK(hipGetLastError());
   return 0;
 }
@@ -357,7 +581,7 @@ extern "C" int a2p_frontend_encode_audio(a2p_frontend_ctx* f, const float* audio
       fe_deinterleave_kernel<<<(int)((samples + 255) / 256), 256, 0, s>>>(audio + (size_t)b * samples * 2, f->wav.f(), samples, ch);
       const float* feat = nullptr;
       int64_t S = 0;
-      CHK(fe_features(f, f->wav.f(), samples, 0, f->conv_a, &feat, &S, s));
+      CHK(fe_features(f, f->wav.f(), samples, 0, f->conv_a, fe_stack(f, false), &feat, &S, s));
       ARG(S == n_tokens, "%lld samples give %lld audio tokens, the caller expects %d", (long long)samples, (long long)S, n_tokens);
       fe_scatter_cols_kernel<<<(int)((S * C + 255) / 256), 256, 0, s>>>(feat, out + (size_t)b * S * 2 * C, S, C, 2 * C, ch * C);
     }
@@ -429,15 +653,16 @@ static int fe_lip_chunks(a2p_frontend_ctx* f, const float* audio, int64_t sample
   const int64_t Sc = fe_conv_len((Lc + 2) / 3 + f->cfg.lip_pad);
   ARG(Sc >= 1 && Sc <= 1024 && Tc <= 1024, "lip chunk of %d frames gives %lld wav2vec tokens (positional table holds 1024)", Tc, (long long)Sc);
   const int N = B;
-  // Wav2VecEncoder (audio_encoder.py:34-46): resample, 320 zeros on the left, feature extractor; the aggregator is the identity
-  // in the stub geometry (the real wav2vec-large aggregator is absent offline)
+  // Wav2VecEncoder (audio_encoder.py:34-46): resample, 320 zeros on the left, feature extractor, feature aggregator (the identity
+  // in the stub geometry; cfg.agg_layers > 0: fairseq's ConvAggregator, fe_aggregate)
   for (int b = 0; b < B; ++b) {
     fe_deinterleave_kernel<<<(int)((Lc + 255) / 256), 256, 0, s>>>(audio + ((size_t)b * samples + (size_t)t0 * spf) * 2, f->wav.f(), Lc, 0);
     const float* feat = nullptr;
     int64_t S = 0;
-    CHK(fe_features(f, f->wav.f(), Lc, f->cfg.lip_pad, f->conv_l, &feat, &S, s));
+    CHK(fe_features(f, f->wav.f(), Lc, f->cfg.lip_pad, f->conv_l, fe_stack(f, true), &feat, &S, s));
     ARG(S == Sc, "internal: token count %lld != %lld", (long long)S, (long long)Sc);
-    HIPCHK(hipMemcpyAsync(f->cond.f() + (size_t)b * Sc * C, feat, (size_t)Sc * C * 4, hipMemcpyDeviceToDevice, s));
+    if (f->cfg.agg_layers) CHK(fe_aggregate(f, feat, Sc, f->cond.f() + (size_t)b * Sc * C, s));
+    else HIPCHK(hipMemcpyAsync(f->cond.f() + (size_t)b * Sc * C, feat, (size_t)Sc * C * 4, hipMemcpyDeviceToDevice, s));
   }
   const int64_t nc = (int64_t)N * Sc * d, nx = (int64_t)N * Tc * d;
   // RegressionTransformer.forward (transformer_modules.py:594-627): x = 0 + pe, cond += pe

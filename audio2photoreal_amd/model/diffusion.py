@@ -113,7 +113,7 @@ class FiLMTransformer(nn.Module):
     def __init__(self, args, nfeats: int, latent_dim: int = 512, ff_size: int = 1024, num_layers: int = 4,
                  num_heads: int = 4, dropout: float = 0.1, cond_feature_dim: int = 4800,
                  activation: Callable = F.gelu, use_rotary: bool = True, cond_mode: str = "audio",
-                 split_type: str = "train", device: str = "cuda", audio_frontend=None, audio_resample: str = "sinc",
+                 split_type: str = "train", device: str = "cuda", audio_frontend=None, audio_resample: str = "sinc", audio_geometry=None,
                  precision: str = "fp32", max_batch: int = 32, **kwargs) -> None:
         super().__init__()
         if not use_rotary:
@@ -187,15 +187,16 @@ class FiLMTransformer(nn.Module):
             # the reference's own front end on the GPU: vq-wav2vec conv features of both channels and, for the
             # face model, the lip regressor -- the modules own the parameters under the reference's keys (`audio_model.*`,
             # `lip_model.*`), the arithmetic is csrc/a2p_frontend.h; `y["audio"]` is then all the caller passes
-            from .audio_frontend import Audio2LipRegressionTransformer, NativeAudioFrontend, Wav2VecModel
-            self.audio_model = Wav2VecModel()
+            from .audio_frontend import STUB, Audio2LipRegressionTransformer, NativeAudioFrontend, Wav2VecModel
+            geo = audio_geometry or STUB             # audio_frontend.FAIRSEQ: fairseq's published blocks (GroupNorm, log compression, aggregator)
+            self.audio_model = Wav2VecModel(group_norm=geo.a_group_norm)
             if self.data_format == "face":
-                self.lip_model = Audio2LipRegressionTransformer()
+                self.lip_model = Audio2LipRegressionTransformer(geometry=geo)
             for m in (self.audio_model, getattr(self, "lip_model", None)):
                 if m is not None:
                     for q in m.parameters():
                         q.requires_grad = False
-            self.audio_frontend = NativeAudioFrontend(self, resample=audio_resample, max_batch=max_batch, max_frames=self.seq_len)
+            self.audio_frontend = NativeAudioFrontend(self, resample=audio_resample, max_batch=max_batch, max_frames=self.seq_len, geometry=geo)
 
         self._ctx: Optional[C.c_void_p] = None
         self._ctx_lib = None

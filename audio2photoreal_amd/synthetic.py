@@ -120,23 +120,31 @@ def synthetic_tokenizer_state_dict(spec: TokenizerSpec, seed: int = 10) -> Dict[
     return {name: _init_like_reference(seed, name, shape, "vq.") for name, shape in tokenizer_param_shapes(spec).items()}
 
 
-def synthetic_frontend_state_dict(seed: int = 10, lip: bool = True) -> Dict[str, torch.Tensor]:
+def synthetic_frontend_state_dict(seed: int = 10, lip: bool = True, geometry=None) -> Dict[str, torch.Tensor]:
     """Parameters of the audio front end under the reference's keys (`audio_model.*`, `lip_model.*`; model/audio_frontend.py).
     Conv weights get He gain (bias-free conv + ReLU stacks: keeps the 8-layer activations O(1) on N(0,1) audio); the positional
-    tables `pe` are the reference's closed form (transformer_modules.py:284-291), not random."""
-    from .model.audio_frontend import Audio2LipRegressionTransformer, Wav2VecModel
-    mods = {"audio_model.": Wav2VecModel()}
+    tables `pe` are the reference's closed form (transformer_modules.py:284-291), not random.  `geometry`
+    (audio_frontend.FrontendGeometry): with fairseq's blocks the dictionary also carries the GroupNorm affine terms
+    (`conv_layers.{i}.2.*`) and the lip encoder's `feature_aggregator.*` -- the key set of a real (vq-)wav2vec checkpoint's
+    on-path tensors."""
+    from .model.audio_frontend import STUB, Audio2LipRegressionTransformer, Wav2VecModel
+    geo = geometry or STUB
+    mods = {"audio_model.": Wav2VecModel(group_norm=geo.a_group_norm)}
     if lip:
-        mods["lip_model."] = Audio2LipRegressionTransformer()
+        mods["lip_model."] = Audio2LipRegressionTransformer(geometry=geo)
     sd: Dict[str, torch.Tensor] = {}
     for prefix, m in mods.items():
         for name, ref in m.state_dict().items():
             key, shape = prefix + name, tuple(ref.shape)
             if name.endswith(".pe"):
                 sd[key] = ref.clone()
-            elif "conv_layers" in name:
+            elif "conv_layers" in name and len(shape) == 3:
                 fan_in = shape[1] * shape[2]
                 sd[key] = synthetic_tensor(seed, key, shape, float(np.sqrt(2.0 / fan_in)))
+            elif "conv_layers" in name and name.endswith(".weight"):      # GroupNorm scale
+                sd[key] = synthetic_tensor(seed, key, shape, 0.1, 1.0)
+            elif "conv_layers" in name:                                   # GroupNorm shift / aggregator conv bias
+                sd[key] = synthetic_tensor(seed, key, shape, 0.1)
             else:
                 sd[key] = _init_like_reference(seed, name, shape, prefix)
     return sd

@@ -209,7 +209,7 @@ int a2p_check_finite(a2p_ctx* ctx, void* stream);
  * 16-bit modes becomes a logit error proportional to the logits' magnitude, and softmax turns logit errors into probability
  * errors one for one: measured on the CPU model of the rounding sites and on the GPU (profiles/r04_trained_like_budget.json,
  * tests/test_hip_round4.py), IEEE-half operands hold <= 1e-3 on the loop's return value up to a maximum of ~13-15 and reach
- * 2.4e-3 at ~29; bfloat16 is 8x worse throughout.  The Python model mirror warns (A2PPrecisionWarning) above 16 in the 16-bit
+ * 2.4e-3 at ~29; bfloat16 is 8x worse throughout.  The Python model mirror warns (A2PPrecisionWarning) above 20 in the 16-bit
  * modes; precision="fp32" is the answer there.  No reference counterpart (its path is fp32). */
 int a2p_attention_logit_max(a2p_ctx* ctx, float* max_logit_host, void* stream);
 
@@ -288,7 +288,24 @@ typedef struct a2p_frontend_config {
   int32_t conv_16bit;        /* 1: the two conv feature extractors (99 % of the front end's FLOPs) run on 16-bit MFMA operands -- IEEE half in
                               * liba2p_hip_f16.so, bfloat16 in liba2p_hip.so -- with fp32 accumulation; 0: exact-fp32 MFMA (parity mode).
                               * The resampler, the first conv layer's arithmetic and the lip regressor stay fp32 either way. */
-  int32_t reserved[1];
+  /* fairseq's published blocks (round 4; fairseq 0.12 models/wav2vec/wav2vec.py ConvFeatureExtractionModel / ConvAggregator -- the
+   * package is absent offline: PARITY UNPINNED, restated in oracle/frontend_oracle.py).  All zero = the stub geometry of rounds 2-3
+   * (bias-free Conv1d + ReLU, 8 layers, identity aggregator).  `a_*`: audio_model.feature_extractor (vq-wav2vec.pt, model/utils.py:18-26),
+   * `l_*`: lip_model.audio_encoder.wav2vec_model (wav2vec_large.pt, model/modules/audio_encoder.py:24-46). */
+  int32_t a_group_norm, l_group_norm;     /* 1: Conv1d -> Fp32GroupNorm(1, C, affine) -> activation; parameters conv_layers.{i}.2.{weight,bias} */
+  int32_t a_activation, l_activation;     /* 0: ReLU, 1: GELU (erf) */
+  int32_t a_log_compression, l_log_compression; /* 1: log(|x| + 1) behind the last conv layer */
+  int32_t a_skip, l_skip;                 /* 1: skip connections between equal-width layers: (x + residual[..., ::r][..., :T]) * sqrt(residual_scale) */
+  float a_residual_scale, l_residual_scale;
+  int32_t l_layers;                       /* conv layers of the lip encoder's feature extractor: 0 or 8 = (10,5)(8,4)(4,2)x3(1,1)x3; 7 drops the last (1,1) */
+  int32_t agg_layers;                     /* 0: identity aggregator; n <= 12: ConvAggregator layers of kernel 2, 3, ..., n + 1 (stride 1, causal padding),
+                                           * parameters feature_aggregator.conv_layers.{j}.1.{weight[,bias]}, .3.{weight,bias} (GroupNorm) */
+  int32_t agg_skip;                       /* 1: x = (block(x) + x) * sqrt(agg_residual_scale) */
+  float agg_residual_scale;
+  int32_t agg_conv_bias;                  /* 1: the aggregator's convolutions carry a bias */
+  int32_t agg_zero_pad;                   /* 1: ZeroPad1d(k - 1, 0) instead of ReplicationPad1d((k - 1, 0)) */
+  int32_t agg_activation;                 /* as a_activation */
+  int32_t reserved[2];
 } a2p_frontend_config;
 int a2p_frontend_create(const a2p_frontend_config* cfg, a2p_frontend_ctx** out);
 int a2p_frontend_destroy(a2p_frontend_ctx* ctx);

@@ -8,9 +8,15 @@ CPU restatement (torch CPU fp32) of the reference's audio front end (SURVEY.md Â
 Pinning: `tests/golden/make_golden_frontend.py` ran the reference's own `encode_audio` / `encode_lip` (fairseq / torchaudio
 stubbed per SURVEY.md Appendix A: bias-free conv + ReLU stack with the vq-wav2vec geometry, x[::3] resampler) on
 audio2photoreal_amd.synthetic weights; `tests/test_frontend_oracle.py` checks this file against those fixtures.
-PARITY UNPINNED for the two third-party pieces: fairseq's real (vq-)wav2vec feature extractor (GroupNorm, log compression,
-aggregator are not modelled -- only the published conv geometry) and torchaudio's Resample, restated below from its documented
-algorithm (`resample_sinc`) with nothing in the container to check it against.
+PARITY UNPINNED for the two third-party pieces: fairseq's real (vq-)wav2vec models and torchaudio's Resample, restated below
+from their published sources with nothing in the container to check them against:
+  * `resample_sinc`: torchaudio 2.0.2 functional `_get_sinc_resample_kernel` / `_apply_sinc_resample_kernel`;
+  * `conv_features(..., geometry)` / `conv_aggregator` (round 4): fairseq 0.12 fairseq/models/wav2vec/wav2vec.py --
+    `ConvFeatureExtractionModel` (block = Conv1d(bias=False) -> Dropout -> Fp32GroupNorm(1, C) -> activation; forward: skip
+    connections `(x + residual[..., ::r][..., :T]) * sqrt(residual_scale)`, then `log(|x| + 1)` with --log-compression) and
+    `ConvAggregator` (block = ReplicationPad1d((k - 1, 0)) | ZeroPad1d -> Conv1d(k) -> Dropout -> Fp32GroupNorm(1, C) -> activation;
+    forward: `x = (block(x) + residual) * sqrt(residual_scale)` with --skip-connections-agg).  `geometry` is any object with the
+    attributes of audio2photoreal_amd.model.audio_frontend.FrontendGeometry (a_* / l_* / agg_*); None = the stub geometry.
 """
 from __future__ import annotations
 
@@ -51,27 +57,76 @@ def resample_sinc(x: Tensor) -> Tensor:
     return y[..., : math.ceil(new * shape[-1] / orig)].reshape(*shape[:-1], -1)
 
 
-def conv_features(x: Tensor, sd: Dict[str, Tensor], prefix: str) -> Tensor:
-    """`model.feature_extractor(x)` of the (vq-)wav2vec stub geometry: x [B, L] -> [B, 512, L'] through 8 x (Conv1d(bias=False), ReLU)."""
+def _act(name: str):
+    return F.gelu if name == "gelu" else F.relu
+
+
+def conv_features(x: Tensor, sd: Dict[str, Tensor], prefix: str, layers: int = 8, group_norm: bool = False, activation: str = "relu",
+                  log_compression: bool = False, skip: bool = False, residual_scale: float = 0.5) -> Tensor:
+    """`model.feature_extractor(x)`: x [B, L] -> [B, 512, L'].  Defaults = the stub geometry (8 x (Conv1d(bias=False), ReLU));
+    the options are fairseq's ConvFeatureExtractionModel (module docstring)."""
     h = x.unsqueeze(1)
-    for i, (_, s) in enumerate(CONV_GEOMETRY):
-        h = F.relu(F.conv1d(h, sd[f"{prefix}conv_layers.{i}.0.weight"], stride=s))
+    act, rs = _act(activation), math.sqrt(residual_scale)
+    for i, (_, s) in enumerate(CONV_GEOMETRY[:layers]):
+        residual = h
+        h = F.conv1d(h, sd[f"{prefix}conv_layers.{i}.0.weight"], stride=s)
+        if group_norm:
+            h = F.group_norm(h.float(), 1, sd[f"{prefix}conv_layers.{i}.2.weight"], sd[f"{prefix}conv_layers.{i}.2.bias"], 1e-5)
+        h = act(h)
+        if skip and h.size(1) == residual.size(1):
+            tsz, r_tsz = h.size(2), residual.size(2)
+            residual = residual[..., :: r_tsz // tsz][..., :tsz]
+            h = (h + residual) * rs
+    if log_compression:
+        h = (h.abs() + 1).log()
     return h
 
 
-def encode_audio(audio: Tensor, sd: Dict[str, Tensor], resample=resample_decimate) -> Tensor:
+def conv_aggregator(x: Tensor, sd: Dict[str, Tensor], prefix: str, layers: int, skip: bool = True, residual_scale: float = 0.5,
+                    conv_bias: bool = True, zero_pad: bool = False, activation: str = "relu") -> Tensor:
+    """fairseq ConvAggregator.forward on x [B, 512, T] (all layers 512 -> 512: residual_proj is None everywhere)."""
+    act, rs = _act(activation), math.sqrt(residual_scale)
+    for j in range(layers):
+        k = j + 2
+        ka = k // 2
+        kb = ka - 1 if k % 2 == 0 else ka
+        residual = x
+        h = F.pad(x, (ka + kb, 0), mode="constant" if zero_pad else "replicate")
+        h = F.conv1d(h, sd[f"{prefix}conv_layers.{j}.1.weight"], sd[f"{prefix}conv_layers.{j}.1.bias"] if conv_bias else None)
+        h = F.group_norm(h.float(), 1, sd[f"{prefix}conv_layers.{j}.3.weight"], sd[f"{prefix}conv_layers.{j}.3.bias"], 1e-5)
+        x = act(h)
+        if skip:
+            x = (x + residual) * rs
+    return x
+
+
+def _stack_kw(geometry, side: str) -> dict:
+    if geometry is None:
+        return {}
+    g = lambda n: getattr(geometry, f"{side}_{n}")
+    return dict(layers=(geometry.l_layers if side == "l" else 8), group_norm=g("group_norm"), activation=g("activation"),
+                log_compression=g("log_compression"), skip=g("skip"), residual_scale=g("residual_scale"))
+
+
+def encode_audio(audio: Tensor, sd: Dict[str, Tensor], resample=resample_decimate, geometry=None) -> Tensor:
     """model/diffusion.py:285-293: both channels resampled, feature-extracted, concatenated -> [B, S, 1024]."""
-    z0 = conv_features(resample(audio[:, :, 0]), sd, "audio_model.feature_extractor.")
-    z1 = conv_features(resample(audio[:, :, 1]), sd, "audio_model.feature_extractor.")
+    kw = _stack_kw(geometry, "a")
+    z0 = conv_features(resample(audio[:, :, 0]), sd, "audio_model.feature_extractor.", **kw)
+    z1 = conv_features(resample(audio[:, :, 1]), sd, "audio_model.feature_extractor.", **kw)
     return torch.cat((z0, z1), dim=1).permute(0, 2, 1)
 
 
-def wav2vec_encoder(audio: Tensor, sd: Dict[str, Tensor], resample) -> Tensor:
+def wav2vec_encoder(audio: Tensor, sd: Dict[str, Tensor], resample, geometry=None) -> Tensor:
     """Wav2VecEncoder.forward (audio_encoder.py:34-46): [B, T, 1600] -> resample -> 320 zeros on the left -> feature extractor
-    (-> aggregator: identity in the stub geometry) -> [B, T_w, 512]."""
+    -> feature aggregator (the identity in the stub geometry) -> [B, T_w, 512]."""
     a = resample(audio.reshape(audio.shape[0], -1))
     a = torch.cat([torch.zeros(a.shape[0], 320), a], dim=-1)
-    return conv_features(a, sd, "lip_model.audio_encoder.wav2vec_model.feature_extractor.").permute(0, 2, 1).contiguous()
+    W = "lip_model.audio_encoder.wav2vec_model."
+    x = conv_features(a, sd, W + "feature_extractor.", **_stack_kw(geometry, "l"))
+    if geometry is not None and geometry.agg_layers:
+        x = conv_aggregator(x, sd, W + "feature_aggregator.", geometry.agg_layers, geometry.agg_skip, geometry.agg_residual_scale,
+                            geometry.agg_conv_bias, geometry.agg_zero_pad, geometry.agg_activation)
+    return x.permute(0, 2, 1).contiguous()
 
 
 def regression_transformer(x: Tensor, cond: Tensor, sd: Dict[str, Tensor], heads: int = 4) -> Tensor:
@@ -106,28 +161,28 @@ def regression_transformer(x: Tensor, cond: Tensor, sd: Dict[str, Tensor], heads
     return x
 
 
-def lip_model(audio: Tensor, sd: Dict[str, Tensor], resample) -> Tensor:
+def lip_model(audio: Tensor, sd: Dict[str, Tensor], resample, geometry=None) -> Tensor:
     """Audio2LipRegressionTransformer.forward (model/diffusion.py:63-79): [B, T, 1600] -> [B, T, 338, 3]."""
     B, T = audio.shape[0], audio.shape[1]
-    cond = wav2vec_encoder(audio, sd, resample)
+    cond = wav2vec_encoder(audio, sd, resample, geometry)
     x = regression_transformer(torch.zeros(B, T, 512), cond, sd)
     x = x @ sd["lip_model.project_output.weight"].T + sd["lip_model.project_output.bias"]
     return x.view(B, T, -1, 3)
 
 
-def lip_frames(audio: Tensor, sd: Dict[str, Tensor], resample=resample_decimate) -> Tensor:
+def lip_frames(audio: Tensor, sd: Dict[str, Tensor], resample=resample_decimate, geometry=None) -> Tensor:
     """First half of encode_lip (model/diffusion.py:296-306): channel 0 in 120-frame chunks through the lip model -> [B, T, 338, 3]."""
     reshaped = audio.reshape((audio.shape[0], -1, 1600, 2))[..., 0]
     B, T, _ = reshaped.shape
     lip = torch.zeros((B, T, 338, 3))
     for i in range(0, T, 120):
-        lip[:, i: i + 120] = lip_model(reshaped[:, i: i + 120], sd, resample)
+        lip[:, i: i + 120] = lip_model(reshaped[:, i: i + 120], sd, resample, geometry)
     return lip
 
 
-def encode_lip(audio: Tensor, cond_embed: Tensor, sd: Dict[str, Tensor], resample=resample_decimate) -> Tensor:
+def encode_lip(audio: Tensor, cond_embed: Tensor, sd: Dict[str, Tensor], resample=resample_decimate, geometry=None) -> Tensor:
     """model/diffusion.py:295-313."""
-    lip = lip_frames(audio, sd, resample)
+    lip = lip_frames(audio, sd, resample, geometry)
     B, T = lip.shape[0], lip.shape[1]
     lip = lip.permute(0, 2, 3, 1).reshape((B, 338 * 3, -1))
     lip = F.interpolate(lip, size=cond_embed.shape[1], mode="nearest-exact").permute(0, 2, 1)

@@ -65,3 +65,43 @@ def test_state_dict_layout_of_the_native_front_end():
     assert torch.equal(model.lip_model.project_output.weight, fe["lip_model.project_output.weight"])
     pose, _ = create_model_and_diffusion(default_args("pose", layers=1), "test", audio_frontend="native")
     assert not hasattr(pose, "lip_model") and hasattr(pose, "audio_model")
+
+
+def test_fairseq_block_restatement_equals_a_module_composition():
+    """oracle/frontend_oracle.py restates fairseq's ConvFeatureExtractionModel / ConvAggregator functionally (PARITY UNPINNED: the
+    package is absent).  The same published block definitions composed from torch.nn MODULES (Conv1d, GroupNorm(1, C),
+    ReplicationPad1d / ConstantPad1d, GELU / ReLU) must give the same features: guards the functional form -- padding side and
+    width, residual subsampling, where the scale and the log sit -- against slips, not against fairseq itself."""
+    import dataclasses
+    import math
+    import torch.nn as nn
+    from audio2photoreal_amd.model.audio_frontend import FAIRSEQ
+    geo = dataclasses.replace(FAIRSEQ, l_skip=True, agg_layers=4)
+    sd = synthetic_frontend_state_dict(SEED, lip=True, geometry=geo)
+    x = torch.randn(2, 4000, generator=torch.Generator().manual_seed(3))
+    P = "lip_model.audio_encoder.wav2vec_model."
+    with torch.no_grad():
+        got = FO.conv_features(x, sd, P + "feature_extractor.", layers=7, group_norm=True, activation="relu", log_compression=True, skip=True,
+                               residual_scale=0.5)
+        h = x.unsqueeze(1)
+        for i, (k, s) in enumerate(CONV_GEOMETRY[:7]):
+            conv = nn.Conv1d(h.shape[1], 512, k, stride=s, bias=False)
+            gn = nn.GroupNorm(1, 512)
+            conv.weight.copy_(sd[f"{P}feature_extractor.conv_layers.{i}.0.weight"])
+            gn.weight.copy_(sd[f"{P}feature_extractor.conv_layers.{i}.2.weight"]); gn.bias.copy_(sd[f"{P}feature_extractor.conv_layers.{i}.2.bias"])
+            res = h
+            h = nn.ReLU()(gn(conv(h)))
+            if h.shape[1] == res.shape[1]:
+                h = (h + res[..., :: res.shape[2] // h.shape[2]][..., : h.shape[2]]) * math.sqrt(0.5)
+        want = (h.abs() + 1).log()
+        assert got.shape == want.shape and rel_l2(got, want) < 1e-6
+        agg = FO.conv_aggregator(got, sd, P + "feature_aggregator.", 4, True, 0.5, True, False, "relu")
+        h = want
+        for j in range(4):
+            k = j + 2
+            conv = nn.Conv1d(512, 512, k)
+            gn = nn.GroupNorm(1, 512)
+            conv.weight.copy_(sd[f"{P}feature_aggregator.conv_layers.{j}.1.weight"]); conv.bias.copy_(sd[f"{P}feature_aggregator.conv_layers.{j}.1.bias"])
+            gn.weight.copy_(sd[f"{P}feature_aggregator.conv_layers.{j}.3.weight"]); gn.bias.copy_(sd[f"{P}feature_aggregator.conv_layers.{j}.3.bias"])
+            h = (nn.ReLU()(gn(conv(nn.ReplicationPad1d((k - 1, 0))(h)))) + h) * math.sqrt(0.5)
+        assert agg.shape == h.shape == got.shape and rel_l2(agg, h) < 1e-6

@@ -455,6 +455,17 @@ def test_native_front_end_refuses_on_path_tensors_it_does_not_implement():
                 "lip_model.audio_encoder.wav2vec_model.feature_aggregator.conv_layers.0.1.weight"):
         with pytest.raises(_lib.A2PError, match="conditioning path"):
             load_model(model, {**sd, bad: torch.ones(512)})
+    # round 4: a model built for fairseq's published blocks holds -- and consumes -- exactly those tensors ...
+    from audio2photoreal_amd.model.audio_frontend import FAIRSEQ
+    fq, _ = create_model_and_diffusion(default_args("face", layers=1), "test", audio_frontend="native", audio_geometry=FAIRSEQ)
+    sd_fq = {**synthetic_state_dict(spec, 10), **synthetic_frontend_state_dict(10, lip=True, geometry=FAIRSEQ)}
+    load_model(fq, {**sd_fq, **off_path})
+    assert "lip_model.audio_encoder.wav2vec_model.feature_aggregator.conv_layers.11.3.bias" in fq.state_dict()
+    assert "lip_model.audio_encoder.wav2vec_model.feature_extractor.conv_layers.7.0.weight" not in fq.state_dict()   # wav2vec-large: 7 layers
+    with pytest.raises(_lib.A2PError, match="conditioning path"):        # ... and still refuses what its geometry does not have
+        load_model(fq, {**sd_fq, "lip_model.audio_encoder.wav2vec_model.feature_aggregator.conv_layers.12.1.weight": torch.ones(512, 512, 14)})
+    with pytest.raises(_lib.A2PError, match="conditioning path"):        # the stub model refuses the fairseq dictionary
+        load_model(model, sd_fq)
     # a model WITHOUT the native front end is fed y["cond_embed"] by the caller: front-end tensors are none of its business
     plain, _ = create_model_and_diffusion(default_args("face", layers=1), "test")
     load_model(plain, {**synthetic_state_dict(spec, 10), "audio_model.feature_extractor.conv_layers.0.2.weight": torch.ones(512)})

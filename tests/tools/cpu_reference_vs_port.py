@@ -8,7 +8,12 @@ T frames, 1998+2 conditioning tokens at T=600, classifier-free guidance = 2 pass
 chain, the same torch thread count.  The reference runs through tests/golden/ref_import.py (fairseq / torchaudio stubbed, audio
 features fed in: decoder-only conditioning, the variant (B) path of BASELINE.md) -- what differs from the port is the reference's own
 module code (nn.MultiheadAttention, einops rearranges, per-step recomputation of everything), not the algorithm.
-Writes profiles/r03_cpu_reference_vs_port.json; the outputs of both are compared too (they are the parity pin of the oracle)."""
+Writes profiles/r03_cpu_reference_vs_port.json; the outputs of both are compared too (they are the parity pin of the oracle).
+
+Round 4 (`--variant-a`): BASELINE.md section 3's variant (A) proper -- what a user of the reference gets: `y["audio"]` goes in and
+the reference's UNMODIFIED `encode_audio` / `encode_lip` (model/diffusion.py:285-313, the reference's own Audio2LipRegressionTransformer)
+re-encode it in every forward of every step (fairseq / torchaudio: the conv + ReLU / x[::3] stubs of ref_import.py, synthetic
+weights).  Timed beside the decoder-only variant (B) above; writes profiles/r04_cpu_reference_variants.json."""
 import argparse
 import json
 import os
@@ -35,6 +40,7 @@ def main():
     ap.add_argument("--frames", type=int, default=600)
     ap.add_argument("--steps", type=int, default=4)
     ap.add_argument("--threads", type=int, default=os.cpu_count() or 1)
+    ap.add_argument("--variant-a", action="store_true", help="also time the reference with its own audio front end in every forward")
     a = ap.parse_args()
     torch.manual_seed(SEED)
     torch.set_num_threads(a.threads)
@@ -69,6 +75,27 @@ def main():
                     outs.append(x)
                 return time.perf_counter() - t0, outs
         ref_dt, ref_out = ref_steps(1)
+        var_a = None
+        if a.variant_a:
+            sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+            from make_golden_frontend import to_reference_keys
+            from audio2photoreal_amd.synthetic import synthetic_audio, synthetic_frontend_state_dict
+            model.lip_model = ns.md.Audio2LipRegressionTransformer().eval()
+            miss, unexp = model.load_state_dict(to_reference_keys(synthetic_frontend_state_dict(SEED, lip=True)), strict=False)
+            assert not unexp, unexp
+            enc_b = (type(model).encode_audio, type(model).encode_lip)
+            type(model).encode_audio, type(model).encode_lip = type(model)._ref_encode_audio, type(model)._ref_encode_lip
+            y_keep = y
+            y = {"audio": synthetic_audio(SEED, 1, a.frames), "scale": torch.full((1,), scale)}
+            try:
+                n_a = min(a.steps, 2)
+                ts_keep, ts = ts, ts[:n_a]
+                a_dt, _ = ref_steps(1)
+                var_a = {"s_per_step": round(a_dt / n_a, 3), "steps_timed": n_a}
+                ts = ts_keep
+            finally:
+                type(model).encode_audio, type(model).encode_lip = enc_b
+                y = y_keep
 
     # ---- the oracle port ----
     den = O.OracleDenoiser(sd, "face", spec.num_layers, spec.num_heads)
@@ -92,8 +119,14 @@ def main():
            "port_over_reference_speed": round(ref_dt / port_dt, 3),
            "port_vs_reference_rel_l2_after_steps": rel,
            "note": "bench.py's cpu_baseline times the port on the GPU box's host (kind 'port'); this ratio relates it to variant (A)"}
+    if var_a:
+        rec["variant_a_reference_with_its_audio_front_end"] = {
+            **var_a, "steps_per_s_batch1": round(1.0 / var_a["s_per_step"], 4),
+            "slowdown_vs_decoder_only_reference": round(var_a["s_per_step"] / (ref_dt / a.steps), 2),
+            "note": "the reference's unmodified encode_audio / encode_lip in every forward (2 per step); stub conv stack + x[::3] resampler, the "
+                    "reference's own lip regressor; same threads"}
     print(json.dumps(rec, indent=1))
-    with open(os.path.join(ROOT, "profiles", "r03_cpu_reference_vs_port.json"), "w") as f:
+    with open(os.path.join(ROOT, "profiles", "r04_cpu_reference_variants.json" if var_a else "r03_cpu_reference_vs_port.json"), "w") as f:
         json.dump(rec, f, indent=1)
 
 
