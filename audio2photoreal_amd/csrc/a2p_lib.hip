@@ -29,6 +29,7 @@
 #include "kernels_gemm.h"
 #include "kernels_misc.h"
 #include "kernels_small.h"
+#include "kernels_tail.h"
 
 static thread_local char g_err[1024] = "";
 static void set_err(const char* fmt, ...) {
@@ -76,12 +77,22 @@ struct Arena {
 };
 static thread_local Arena* g_arena = nullptr;  // set while a context allocates its long-lived buffers
 
+// Zero-fill of a fresh allocation, COMPLETE before the call returns.  (Rounds 1-3 used hipMemset: it is enqueued on the null stream
+// and may return before it has run, and the null stream is not ordered against the NON-BLOCKING streams a caller may hand to the
+// entry points (torch.cuda.Stream): the first kernels that wrote such a buffer -- weight repacks at finalize time, the guide's
+// conv stack -- raced with the zero-fill and could find part of their output zeroed afterwards.  Found in round 4 as "the first
+// process on a fresh box samples different keyframes than every later one" under bench.py --pipeline's two-stream schedule.)
+static int zero_fill_now(void* p, size_t bytes) {
+  HIPCHK(hipMemsetAsync(p, 0, bytes, nullptr));
+  HIPCHK(hipStreamSynchronize(nullptr));
+  return 0;
+}
 static int buf_alloc_tmp(Buf& b, size_t bytes) {  // short-lived scratch of the unit / setup entry points
   if (b.p && !b.pooled) (void)hipFree(b.p);
   b.p = nullptr;
   if (bytes == 0) bytes = 16;
   HIPCHK(hipMalloc(&b.p, bytes));
-  HIPCHK(hipMemset(b.p, 0, bytes));
+  CHK(zero_fill_now(b.p, bytes));
   b.bytes = bytes;
   b.pooled = false;
   return 0;
@@ -91,7 +102,9 @@ static int buf_alloc(Buf& b, size_t bytes) {
   if (!a) return buf_alloc_tmp(b, bytes);
   if (bytes == 0) bytes = 16;
   if (b.p && b.pooled && b.bytes >= bytes) {  // re-finalisation after a weight update: same slot
-    HIPCHK(hipMemset(b.p, 0, bytes));
+    // (the slot may still be read by work the caller enqueued earlier on ITS stream: let the device drain first)
+    HIPCHK(hipDeviceSynchronize());
+    CHK(zero_fill_now(b.p, bytes));
     return 0;
   }
   if (b.p && !b.pooled) (void)hipFree(b.p);
@@ -109,7 +122,7 @@ static int buf_alloc(Buf& b, size_t bytes) {
   b.p = a->cur + pad;
   a->cur += pad + bytes;
   a->left -= pad + bytes;
-  HIPCHK(hipMemset(b.p, 0, bytes));
+  CHK(zero_fill_now(b.p, bytes));
   b.bytes = bytes;
   b.pooled = true;
   return 0;
@@ -192,6 +205,9 @@ struct a2p_ctx {
   Buf cak_w32, cak_b, cav_w32, cav_b, cak_wt, cav_wt;
   Buf ca2k_wt, ca2v_wt, ca2k_b, ca2v_b;
   Buf conv_wt[7];
+  Buf tail_w, tail_b;                  // fused output tail of the body model (kernels_tail.h): packed MFMA weight operands, [8][256] biases
+  int64_t tail_woff[8] = {};
+  bool tail_fused = false;
   std::vector<Buf> ch_stream, ch_aux;  // packed weight streams [layout * L*4 + layer*4 + kind] (layout 0: 4-wave LDS slices, 1: 8-wave) / bias blocks [layer*4 + kind]
   int ch_nw = 4;                       // waves per chain workgroup of the forward being enqueued (4 or 8; chain_pick_nw)
   struct ChainTune {                   // per forward size (rows): which workgroup shape is faster ON THIS BOX, measured in situ
@@ -634,7 +650,7 @@ extern "C" int a2p_ctx_destroy(a2p_ctx* c) {
                 &c->k2c, &c->vt2c, &c->slot_cond, &c->slot_unc, &c->slot_cfg, &c->x, &c->xn, &c->xr, &c->qk, &c->vt, &c->ao,
                 &c->hff, &c->inpack, &c->mo, &c->cb[0], &c->cb[1], &c->cb[2], &c->cb[3], &c->emb, &c->th, &c->tct, &c->tvec,
                 &c->mt, &c->tokn, &c->tokr, &c->film, &c->ktail, &c->vtail, &c->ce_pack, &c->pooled, &c->tmpa, &c->tmpb,
-                &c->kf_pack, &c->kf_tok, &c->clk, &c->t3, &c->nonfinite};
+                &c->kf_pack, &c->kf_tok, &c->clk, &c->t3, &c->nonfinite, &c->tail_w, &c->tail_b};
   for (Buf* b : all) buf_free(*b);
   for (int i = 0; i < 7; ++i) buf_free(c->conv_wt[i]);
   for (auto& b : c->ch_stream) buf_free(b);
@@ -845,6 +861,31 @@ extern "C" int a2p_finalize_weights(a2p_ctx* c, void* stream) {
         CHK(launch_cast(c, W32(c, nm) + t, (int64_t)ci[i] * taps, c->offT(c->conv_wt[i], (int64_t)t * co[i] * cip), cip, co[i], ci[i],
                         cip, nullptr, s, taps));
     }
+  }
+  if (c->pose && c->tail_x3 && c->d == 256 && c->C == 104 && !getenv("A2P_NO_FUSED_TAIL")) {
+    // fused output tail (kernels_tail.h): final_layer, post_pose_layers.0..5, final_conv as (hi, lo) MFMA operands in consumption order
+    struct L { std::string w, b; int Co, Ci, taps, cpin, nt; };
+    std::vector<L> ls = {{"final_layer.weight", "final_layer.bias", c->C, c->d, 1, 256, 8}};
+    for (int i = 0; i < 6; ++i)
+      ls.push_back({"post_pose_layers." + std::to_string(i) + ".weight", "post_pose_layers." + std::to_string(i) + ".bias", i == 0 ? 256 : c->C,
+                    i == 1 ? 256 : c->C, 3, i == 1 ? 256 : 128, i == 0 ? 16 : 8});
+    ls.push_back({"final_conv.weight", "final_conv.bias", c->C, c->C, 1, 128, 8});
+    int64_t total = 0;
+    for (size_t i = 0; i < ls.size(); ++i) {
+      c->tail_woff[i] = total;
+      total += (int64_t)(ls[i].taps * ls[i].cpin / 32) * ls[i].nt * 2 * 512;
+    }
+    CHK(buf_alloc(c->tail_w, (size_t)total * 2));
+    CHK(buf_alloc(c->tail_b, (size_t)8 * 256 * 4));   // zero-filled: the padded output columns carry a zero bias
+    for (size_t i = 0; i < ls.size(); ++i) {
+      const int kcs = ls[i].taps * ls[i].cpin / 32;
+      const int64_t n = (int64_t)kcs * ls[i].nt * 64;
+      tail_pack_kernel<<<(int)((n + 255) / 256), 256, 0, s>>>(W32(c, ls[i].w), ls[i].Co, ls[i].Ci, ls[i].taps, ls[i].cpin, ls[i].nt, kcs,
+                                                            reinterpret_cast<h16_t*>(c->tail_w.p) + c->tail_woff[i]);
+      HIPCHK(hipMemcpyAsync(c->tail_b.f() + i * 256, W32(c, ls[i].b), (size_t)ls[i].Co * 4, hipMemcpyDeviceToDevice, s));
+    }
+    HIPCHK(hipGetLastError());
+    c->tail_fused = true;
   }
   HIPCHK(hipStreamSynchronize(s));
   buf_free(ca2k32);

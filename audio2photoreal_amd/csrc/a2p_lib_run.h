@@ -784,6 +784,18 @@ static int forward_body(a2p_ctx* c, const float* x_in, const int64_t* t_orig, in
     *mo_seq_rows = T;
     return 0;
   }
+  if (c->pose && c->tail_fused) {   // final_layer + dilated conv stack + final_conv in ONE LDS-resident kernel (kernels_tail.h)
+    TailP tp;
+    memset(&tp, 0, sizeof(tp));
+    tp.x = c->x.f(); tp.T = T; tp.d = d; tp.C = c->C; tp.nblk = (T + tail::TB - 1) / tail::TB;
+    tp.w = reinterpret_cast<const h16_t*>(c->tail_w.p); tp.bias = c->tail_b.f(); tp.out = c->mo.f();
+    for (int i = 0; i < tail::NLAYERS; ++i) tp.woff[i] = c->tail_woff[i];
+    KernelTimer kt(c, A2P_KERNEL_GEMM);
+    A2P_LAUNCH(kt, pose_tail_kernel, N * tp.nblk, 512, s, tp);
+    HIPCHK(hipGetLastError());
+    *mo_seq_rows = T;
+    return 0;
+  }
   // fp32 GEMMs read the residual stream in place; the split-operand variant splits it, the all-16-bit variant casts it first
   Fp32Scope f32(c, c->tail32 && !c->tail_x3);
   const void* rows = c->x.p;

@@ -244,7 +244,15 @@ __global__ __launch_bounds__(64 * NWV, 3) void attn_kernel(AttnP p) {
     }
     for (int v = tid; v < DH * VVR; v += 256) {
       const int r = v / VVR, c = v % VVR;
-      const uint4 val = *reinterpret_cast<const uint4*>(Vb + (int64_t)r * p.ldvt + kv0 + c * VEC);
+      uint4 val = *reinterpret_cast<const uint4*>(Vb + (int64_t)r * p.ldvt + kv0 + c * VEC);
+      // columns of keys past the end were never written (0 x nan = nan in the PV product): zero them (see load_vfr)
+      const int nvalid = p.S_main - (kv0 + c * VEC);   // (the time-token tail rows are patched in afterwards)
+      if (nvalid < 4) {
+        if (nvalid < 1) val.x = 0u;
+        if (nvalid < 2) val.y = 0u;
+        if (nvalid < 3) val.z = 0u;
+        val.w = 0u;
+      }
       reinterpret_cast<uint2*>(&Vs[r * L::LSV + c * VEC])[0] = make_uint2(val.x, val.y);
       reinterpret_cast<uint2*>(&Vs[r * L::LSV + c * VEC])[1] = make_uint2(val.z, val.w);
     }
@@ -322,6 +330,19 @@ __global__ __launch_bounds__(64 * NWV, 3) void attn_kernel(AttnP p) {
 #pragma unroll
       for (int dv = 0; dv < DVT; ++dv)
         vfr[c][dv] = *reinterpret_cast<const h16x8*>(&Vs[L::vidx(dv * 16 + l15, c * 32 + g * 8)]);
+#ifndef A2P_ATTN_AB_R3   // (scratch A/B build: the round-3 tile body, to price the two round-4 additions on one box)
+      if constexpr (MASKED) {
+        // Keys past the end carry P = 0, but their V^T columns were never written by anybody: whatever the workspace held there
+        // goes into the MFMA, and 0 x (inf | nan) = nan.  One earlier non-finite forward on the context (an overflowing checkpoint:
+        // a2p_check_finite) would poison every later one through these columns: zero them.  Last tile only.
+        const int nvalid = S_total - (kv0 + c * 32 + g * 8);   // keys of this lane's 8-key fragment that exist
+#pragma unroll
+        for (int dv = 0; dv < DVT; ++dv)
+#pragma unroll
+          for (int e = 0; e < 8; ++e)
+            if (e >= nvalid) vfr[c][dv][e] = (h16_t)0.f;
+      }
+#endif
     };
     if constexpr (sizeof(T) == 2) load_vfr(0);   // the second half follows the softmax (register budget: 3 waves per SIMD)
     // ---- online softmax (log2 domain); lane owns query l15, keys kt*16 + g*4 + r ----
@@ -380,7 +401,7 @@ __global__ __launch_bounds__(64 * NWV, 3) void attn_kernel(AttnP p) {
     // ---- O^T += V^T P^T ----
     if constexpr (sizeof(T) == 2) {
       load_vfr(1);
-#pragma unroll
+  #pragma unroll
       for (int c = 0; c < 2; ++c) {  // 32-key chunk: k-slot e of lane group g -> key c*32 + g*8 + e (see AttnLds::krow)
         h16x8 pf[QT];
 #pragma unroll
@@ -401,7 +422,7 @@ __global__ __launch_bounds__(64 * NWV, 3) void attn_kernel(AttnP p) {
           }
         }
       }
-    } else {
+      } else {
 #pragma unroll
       for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
@@ -432,14 +453,20 @@ __global__ __launch_bounds__(64 * NWV, 3) void attn_kernel(AttnP p) {
   if (wave_active) tile_loop(integral_constant<bool, true>{});
   else tile_loop(integral_constant<bool, false>{});
 
+#ifndef A2P_ATTN_AB_R3
   if (p.stat_max && wave_active) {   // largest row maximum (natural units) of this wave's queries
     float m = mrun[0];
 #pragma unroll
     for (int qt = 1; qt < QT; ++qt) m = fmaxf(m, mrun[qt]);
 #pragma unroll
     for (int o = 8; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));   // over the 16 queries of a lane group (rows are already reduced)
-    if (lane == 0) atomicMax(p.stat_max, attn_ordered_int(m * 0.6931471805599453f));   // log2 domain -> natural units
+    // One address for the whole launch: an unconditional atomic per wave serialises ~5000 of them at one L2 channel (measured: the
+    // body model's attention launches went from 31 / 47 us to 65 / 77 us).  The stored maximum only ever grows, so a plain load filters
+    // all but the few waves that actually raise it (a stale read costs one redundant atomic, never a wrong result).
+    const int mi = attn_ordered_int(m * 0.6931471805599453f);   // log2 domain -> natural units
+    if (lane == 0 && mi > __atomic_load_n(p.stat_max, __ATOMIC_RELAXED)) atomicMax(p.stat_max, mi);
   }
+#endif
   // ---- normalise and store: lane owns query l15, rows dv*16 + g*4 + {0..3} ----
   if constexpr (sizeof(T) == 2) {
     // 16-bit: a lane holds 4 consecutive head-dim values (8 bytes) of one query, so a direct store writes 16 rows x 32 bytes

@@ -409,6 +409,10 @@ class PipelineSubject:
         y = {"cond_embed": feats, "keyframes": torch.zeros(B, self.nk, 104, device=dev), "mask": torch.ones(B, 1, 1, T, dtype=torch.bool, device=dev),
              "scale": torch.full((B,), 2.0, device=dev)}
         y["keyframes"] = _replace_keyframes({"y": y}, cfg, self.uniforms).to(dev)
+        if os.environ.get("A2P_BENCH_DEBUG"):     # diagnosis of run-to-run differences: which stage moved?
+            import hashlib
+            hh = lambda t: hashlib.sha1(t.detach().cpu().contiguous().numpy().tobytes()).hexdigest()[:10]
+            print(f"[debug] subject {self.subject} ids {self.ids}: feats {hh(feats)} keyframes {hh(y['keyframes'])}", file=sys.stderr, flush=True)
         return y, lambda: diff.ddim_sample_loop(cfg, (B, spec.nfeats, 1, T), noise=self.noise["pose"], clip_denoised=False, model_kwargs={"y": y})
 
     def _face(self, face_ce):

@@ -70,7 +70,7 @@ def test_pipeline_job_placements_agree_sample_for_sample():
         assert (line["gather_ms"] is not None) == (n > 1)
     assert lines[4]["config"]["placement"] == {"0": [[0, 0, 1]], "1": [[0, 1, 2]], "2": [[1, 0, 1]], "3": [[1, 1, 2]]}
     assert lines[1]["sample_digests"] == lines[2]["sample_digests"] == lines[4]["sample_digests"], lines
-    assert len(set(lines[1]["sample_digests"].values())) == 4                 # four different samples
+    assert len({tuple(v) for v in lines[1]["sample_digests"].values()}) == 4  # four different samples
     record("pipeline_job_placements", sec_per_sample={str(n): float(l["value"]) for n, l in lines.items()})
 
 
@@ -191,3 +191,41 @@ def test_16bit_modes_on_trained_like_statistics(dev, fmt, name, kw, inside):
     else:
         assert peaks["fp32"] > _lib.LOGIT_ENVELOPE_FP16 and warned["fp16"] and warned["bf16"], (peaks, warned)
         assert errs["fp16"] < 1e-2 and errs["bf16"] < 8e-2, errs          # out of the envelope, not out of control
+
+
+# ----------------------------------------------------------------------------- fused output tail of the body model
+@pytest.mark.parametrize("precision", ["fp16", "bf16"])
+@pytest.mark.parametrize("B,T", [(2, 600), (3, 208), (1, 64), (2, 40)])
+def test_fused_pose_tail_equals_the_nine_gemm_launches(dev, B, T, precision, monkeypatch):
+    """csrc/kernels_tail.h: final_layer + the six dilated convolutions + final_conv of the body model as ONE LDS-resident kernel
+    (64 output frames + a 24-frame halo per workgroup) against rounds 2-3's nine split-operand GEMM launches (A2P_NO_FUSED_TAIL=1,
+    read when the weights are finalized).  Both are the same exact-island arithmetic (hi/lo operand pairs, three products, fp32
+    accumulation) in a different summation order: they must agree to fp32 rounding, far inside the 16-bit modes' distance from the
+    oracle.  T = 208 / 40: ragged last frame block; T = 64: a single block whose halo lies entirely before the sequence start."""
+    spec = pose_spec()
+    inp = synthetic_inputs(spec, B, T, SEED)
+    sd = synthetic_state_dict(spec, SEED)
+    y = {"cond_embed": inp["cond_embed"].to(dev), "scale": torch.full((B,), 2.0, device=dev), "keyframes": inp["keyframes"].to(dev),
+         "mask": inp["mask"].to(dev)}
+    t = torch.tensor(([901, 417, 33] * 2)[:B], device=dev)
+    outs = {}
+    for name in ("gemms", "fused"):
+        if name == "gemms":
+            monkeypatch.setenv("A2P_NO_FUSED_TAIL", "1")
+        else:
+            monkeypatch.delenv("A2P_NO_FUSED_TAIL", raising=False)
+        model, _ = create_model_and_diffusion(default_args("pose"), "test", precision=precision, max_batch=B)
+        load_model(model, sd)
+        cfg = ClassifierFreeSampleModel(model.to(dev).eval())
+        if 2 * B * T < 960:
+            monkeypatch.setenv("A2P_CHAIN_MT", "3")
+        outs[name] = cfg(inp["x_T"].to(dev), t, y).cpu()
+        monkeypatch.delenv("A2P_CHAIN_MT", raising=False)
+        model.release()
+    assert torch.isfinite(outs["fused"]).all()
+    err = float((outs["fused"] - outs["gemms"]).norm() / outs["gemms"].norm())
+    worst = float((outs["fused"] - outs["gemms"]).abs().max() / outs["gemms"].abs().max())
+    record(f"fused_tail_vs_gemms/{precision}/B{B}_T{T}", rel_l2=err, max_norm=worst)
+    # IEEE-half pairs carry 22 mantissa bits, bfloat16 pairs 16: the dropped lo x lo term and the pair's own rounding sit at 2^-22 / 2^-17
+    tol = {"fp16": 2e-6, "bf16": 4e-5}[precision]
+    assert err < tol and worst < 10 * tol, (err, worst)
