@@ -630,10 +630,13 @@ extern "C" int a2p_set_batch_hint(a2p_ctx* c, int32_t global_batch) {
   return 0;
 }
 
+static void graphs_drop(a2p_ctx* c);   // a2p_lib_run.h: waits for the device, then destroys every captured forward
+
 extern "C" int a2p_reload_env(a2p_ctx* c) {
   ARG(c, "null ctx");
   load_opts(c->opt);
-  ++c->graph_epoch;   // captured forwards carry the kernel choices of the switches they were captured under
+  ++c->graph_epoch;   // captured forwards carry the kernel choices of the switches they were captured under:
+  graphs_drop(c);     // evicted here, not left to pile up behind a key no forward will ask for again
   return 0;
 }
 
@@ -720,6 +723,7 @@ static int chain_build_streams(a2p_ctx* c, hipStream_t s);
 extern "C" int a2p_finalize_weights(a2p_ctx* c, void* stream) {
   ARG(c, "null ctx");
   ++c->graph_epoch;   // the compute-dtype weight copies are rebuilt: captured forwards hold the old pointers
+  graphs_drop(c);
   ArenaScope scope(c->use_arena ? &c->arena : nullptr);
   hipStream_t s = (hipStream_t)stream;
   std::map<std::string, int64_t> e;

@@ -835,7 +835,11 @@ static int forward_body(a2p_ctx* c, const float* x_in, const int64_t* t_orig, in
 // host runs ahead either way, and the step takes the same time (1742 vs 1757 steps/s); what the graph saves is ~200 us of host time per
 // step.  Graphs die with the state they captured: a2p_finalize_weights / a2p_reload_env bump graph_epoch.  Never while a kernel class
 // is being timed (dispatch-packet events are not capturable).
+// Destroying an executable that a caller's stream may still be replaying is not something HIP promises to defer: a drop waits for the
+// device first (rare: the 17th geometry of a long-lived context, a weight update, a2p_reload_env, a2p_ctx_destroy).
 static void graphs_drop(a2p_ctx* c) {
+  if (c->graphs.empty()) return;
+  (void)hipDeviceSynchronize();
   for (auto& g : c->graphs) (void)hipGraphExecDestroy(g.exec);
   c->graphs.clear();
 }

@@ -1,8 +1,8 @@
 #!/bin/bash
-# round 4, call 13: attention without the s_setprio branches, placements test, full GPU suite
+# round 4, call 14: price of the two round-4 additions to the attention tile body (same box, A2P_LIB_F16 A/B), alternating
 cd "$GRAFT_REPO_ROOT" 2>/dev/null || cd /root/repo
 mkdir -p gpurun_out
-T=c13
+T=c14
 B="python bench.py --steps 60 --warmup 10 --repeats 2 --no-cpu-baseline --no-parity --no-legs"
 run() {
   local tag=$1; shift
@@ -16,8 +16,9 @@ except Exception as e:
     print("$tag failed", e); print(open("gpurun_out/${T}_$tag.err").read()[-800:])
 PY
 }
-run b8 A2P_X=0 $B --batch 8
-run b32 A2P_X=0 $B --batch 32
-timeout -k 5 900 python -m pytest tests/test_hip_round4.py -m gpu -q -x -k "placements" 2>&1 | grep -E "Differing|^E  |passed|failed" | head -20 | cut -c1-600 | tee gpurun_out/${T}_placements.log
-timeout -k 5 1500 python -m pytest tests -m gpu -q 2>&1 | tail -12 | tee gpurun_out/${T}_tests_all.log
-cp gpurun_out/parity_tests.json gpurun_out/${T}_parity_tests.json 2>/dev/null
+for i in 1 2; do
+run b8_new$i A2P_X=0 $B --batch 8
+run b8_r3attn$i A2P_LIB_F16=$PWD/scratch/ab/liba2p_attn_r3_f16.so $B --batch 8
+done
+run b32_new A2P_X=0 $B --batch 32
+run b32_r3attn A2P_LIB_F16=$PWD/scratch/ab/liba2p_attn_r3_f16.so $B --batch 32

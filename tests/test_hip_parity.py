@@ -305,10 +305,13 @@ def test_chain_kernels_match_the_per_op_kernels_16bit(dev, golden, fmt, mt, prec
     e_pair, e_gold, e_old = rel_l2(chained, per_op), rel_l2(chained, ref), rel_l2(per_op, ref)
     record(f"chain_vs_perop/{precision}/{fmt}/MT{mt}", pair=e_pair, chain_vs_golden=e_gold, perop_vs_golden=e_old)
     # bf16 measured in round 2: chain vs per-op 3.0e-3 (face) / 8.4e-3 (pose), both 4.4e-3 / 8.5e-3 from the fp32 reference;
-    # IEEE-half operands carry 3 more mantissa bits: gates 1/6 of the bf16 ones
-    k = 1.0 if precision == "bf16" else 1.0 / 6.0
-    assert e_pair < k * (6.5e-3 if fmt == "face" else 1.7e-2) and e_gold < k * (9e-3 if fmt == "face" else 1.7e-2) \
-        and e_gold < 1.2 * e_old + k * 1e-3
+    # IEEE-half operands (the default throughput mode) are held to north_star's bar itself: 1e-3 against the fp32 reference
+    # (measured 4.2e-4 / 4.8e-4; the two kernel families 2.6e-4 / 2.2e-4 apart)
+    if precision == "fp16":
+        assert e_pair < 1e-3 and e_gold < 1e-3 and e_gold < 1.2 * e_old + 2e-4
+    else:
+        assert e_pair < (6.5e-3 if fmt == "face" else 1.7e-2) and e_gold < (9e-3 if fmt == "face" else 1.7e-2) \
+            and e_gold < 1.2 * e_old + 1e-3
 
 
 @pytest.mark.parametrize("precision", ["bf16", "fp16"])
@@ -338,8 +341,10 @@ def test_chain_kernels_with_frame_counts_that_are_not_a_multiple_of_4(dev, fmt, 
                           inp.get("keyframes", [None])[:2] if spec.is_pose else None, inp["mask"][:2] if spec.is_pose else None)
     e_pair, e_ref = rel_l2(chained, per_op), rel_l2(chained[:2], ref)
     record(f"chain_ragged/{precision}/{fmt}/T{frames}", pair=e_pair, chain_vs_oracle=e_ref, perop_vs_oracle=rel_l2(per_op[:2], ref))
-    k = 1.0 if precision == "bf16" else 1.0 / 6.0    # bf16 measured 3.1e-3 / 8.8e-3, 4.3e-3 / 7.5e-3
-    assert e_pair < k * (6.5e-3 if fmt == "face" else 1.8e-2) and e_ref < k * (9e-3 if fmt == "face" else 1.5e-2)
+    if precision == "fp16":                          # the 1e-3 bar itself (measured 2.6e-4 / 2.3e-4 and 4.2e-4 / 4.9e-4)
+        assert e_pair < 1e-3 and e_ref < 1e-3
+    else:                                            # bf16 measured 3.1e-3 / 8.8e-3, 4.3e-3 / 7.5e-3
+        assert e_pair < (6.5e-3 if fmt == "face" else 1.8e-2) and e_ref < (9e-3 if fmt == "face" else 1.5e-2)
 
 
 @pytest.mark.parametrize("precision", ["bf16", "fp16"])

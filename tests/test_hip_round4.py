@@ -229,3 +229,78 @@ def test_fused_pose_tail_equals_the_nine_gemm_launches(dev, B, T, precision, mon
     # IEEE-half pairs carry 22 mantissa bits, bfloat16 pairs 16: the dropped lo x lo term and the pair's own rounding sit at 2^-22 / 2^-17
     tol = {"fp16": 2e-6, "bf16": 4e-5}[precision]
     assert err < tol and worst < 10 * tol, (err, worst)
+
+
+# ----------------------------------------------------------------------------- sharded blocks take the unsharded batch's kernels
+@pytest.mark.parametrize("precision", ["fp16", "bf16"])
+@pytest.mark.parametrize("fmt", ["face", "pose"])
+def test_batch_hint_makes_shards_bit_identical_across_the_family_boundary(dev, fmt, precision):
+    """include/a2p_hip.h a2p_set_batch_hint (sample_parallel sets `global_batch_hint`): a global batch of 4 sequences of 240 frames is
+    2*4*240 = 1920 rows under guidance -- a chain-kernel forward -- while its shards of 2 and 1 samples (960 / 480 rows) lie below the
+    family threshold (1100 rows for the face model, 960 for the body model) and would take the small-forward / per-op kernels, whose
+    rounding differs.  With the hint every shard must reproduce its rows of the unsharded forward BIT FOR BIT, whatever panel heights,
+    tile shapes or workgroup shapes its own row count selects inside the family."""
+    spec = face_spec() if fmt == "face" else pose_spec()
+    B, T = 4, 240
+    inp = synthetic_inputs(spec, B, T, SEED)
+    model, _ = create_model_and_diffusion(default_args(fmt), "test", precision=precision, max_batch=B)
+    load_model(model, synthetic_state_dict(spec, SEED))
+    cfg = ClassifierFreeSampleModel(model.to(dev).eval())
+    t = torch.tensor([911, 640, 333, 7], device=dev)
+
+    def y_of(lo, hi):
+        y = {"cond_embed": inp["cond_embed"][lo:hi].to(dev), "scale": torch.full((hi - lo,), 10.0 if fmt == "face" else 2.0, device=dev)}
+        if spec.is_pose:
+            y["keyframes"], y["mask"] = inp["keyframes"][lo:hi].to(dev), inp["mask"][lo:hi].to(dev)
+        return y
+    x = inp["x_T"].to(dev)
+    whole = cfg(x, t, y_of(0, B)).cpu()
+    for blocks in ([(0, 2), (2, 4)], [(0, 1), (1, 2), (2, 3), (3, 4)], [(0, 3), (3, 4)]):
+        model.global_batch_hint = B
+        parts = [cfg(x[lo:hi].contiguous(), t[lo:hi].contiguous(), y_of(lo, hi)).cpu() for lo, hi in blocks]
+        assert torch.equal(torch.cat(parts), whole), (fmt, precision, blocks, float((torch.cat(parts) - whole).abs().max()))
+    model.global_batch_hint = 0
+    alone = cfg(x[:1].contiguous(), t[:1].contiguous(), y_of(0, 1)).cpu()        # no hint: the shard's own family, close but not equal
+    assert not torch.equal(alone, whole[:1]) and float((alone - whole[:1]).norm() / whole[:1].norm()) < (2e-3 if precision == "fp16" else 2e-2)
+    model.release()
+
+
+# ----------------------------------------------------------------------------- the A/B switches kept next to the exact islands
+@pytest.mark.parametrize("fmt", ["face", "pose"])
+@pytest.mark.parametrize("switch", ["A2P_TAIL16", "A2P_TAIL_F32"])
+def test_exact_island_ab_switches_still_run(dev, fmt, switch, monkeypatch):
+    """csrc/a2p_lib.hip: `A2P_TAIL16=1` (input_projection / final_layer / the body model's conv tail on 16-bit operands, round 2's
+    path: final_layer rides on the last chain kernel) and `A2P_TAIL_F32=1` (the islands as fp32-MFMA GEMMs on fp32 copies, round 3's first
+    version) are kept for A/B measurements next to the default split-operand islands; both are read when the weights are finalized.
+    They must keep producing the forward: TAIL_F32 at the default's accuracy, TAIL16 at round 2's (measured 8e-4 ... 2e-3)."""
+    from oracle import a2p_oracle as O
+    spec = face_spec() if fmt == "face" else pose_spec()
+    B, T = 2, 600
+    inp = synthetic_inputs(spec, B, T, SEED)
+    sd = synthetic_state_dict(spec, SEED)
+    scale = 10.0 if fmt == "face" else 2.0
+    t = torch.tensor([845, 96], device=dev)
+    y = {"cond_embed": inp["cond_embed"].to(dev), "scale": torch.full((B,), scale, device=dev)}
+    if spec.is_pose:
+        y["keyframes"], y["mask"] = inp["keyframes"].to(dev), inp["mask"].to(dev)
+    den = O.OracleDenoiser(sd, fmt, spec.num_layers, spec.num_heads, torch.float32)
+    want = den.forward_cfg(inp["x_T"][:1], t[:1].cpu(), inp["cond_embed"][:1], torch.full((1,), scale),
+                           inp["keyframes"][:1] if spec.is_pose else None, inp["mask"][:1] if spec.is_pose else None)
+    errs = {}
+    for name in ("default", switch):
+        if name != "default":
+            monkeypatch.setenv(switch, "1")
+        model, _ = create_model_and_diffusion(default_args(fmt), "test", precision="fp16", max_batch=B)
+        load_model(model, sd)
+        cfg = ClassifierFreeSampleModel(model.to(dev).eval())
+        got = cfg(inp["x_T"].to(dev), t, y).cpu()
+        assert torch.isfinite(got).all()
+        errs[name] = float((got[:1] - want).norm() / want.norm())
+        model.release()
+        monkeypatch.delenv(switch, raising=False)
+    record(f"island_switch/{fmt}/{switch}", **errs)
+    assert errs["default"] < 1e-3
+    if switch == "A2P_TAIL_F32":
+        assert errs[switch] < 1e-3 and abs(errs[switch] - errs["default"]) < 1e-4, errs
+    else:
+        assert errs["default"] <= errs[switch] * 1.05 < 4e-3, errs        # the 16-bit tail is what the islands were built to replace
