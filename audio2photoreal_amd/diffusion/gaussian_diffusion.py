@@ -305,8 +305,11 @@ class GaussianDiffusion:
         # Once per sampling call: did any denoiser evaluation produce inf / nan?  (The 16-bit throughput modes can overflow where
         # the reference's fp32 path cannot; the library ORs a device flag in its fused step tail, include/a2p_hip.h
         # a2p_check_finite.)  Raises A2PError; a loop abandoned half way by its consumer is not checked.
+        # The check reads a device flag, i.e. it WAITS for the stream.  A caller that keeps several streams busy from one host thread
+        # (bench.py --pipeline: the face loop on one stream, guide -> body on another) sets `defer_finite_check = True` on the diffusion
+        # object and calls `model.check_finite()` itself once everything is enqueued; the flag keeps accumulating until it is read.
         chk = getattr(model, "a2p_check_finite", None) or getattr(model, "check_finite", None)
-        if callable(chk):
+        if callable(chk) and not getattr(self, "defer_finite_check", False):
             chk()
 
     def p_sample_loop_progressive(self, model, shape, noise=None, clip_denoised=True, denoised_fn=None, cond_fn=None,

@@ -457,10 +457,22 @@ class PipelineSubject:
         s_face, s_body = torch.cuda.Stream(dev), torch.cuda.Stream(dev)
         s_face.wait_stream(main)
         s_body.wait_stream(main)
-        with torch.cuda.stream(s_face):           # enqueued first: nothing on this stream ever blocks the host
-            face = self._face(face_ce)
-        with torch.cuda.stream(s_body):
-            body = self._body(feats)[1]()
+        # the loops' once-per-call non-finite check reads a device flag (= waits for its stream): deferred until both streams are
+        # loaded, or the host would sit in the face loop's check while the body stream has nothing to do
+        for _, _, diff in self.models.values():
+            diff.defer_finite_check = True
+        try:
+            with torch.cuda.stream(s_face):           # enqueued first: nothing on this stream blocks the host
+                face = self._face(face_ce)
+            with torch.cuda.stream(s_body):
+                body = self._body(feats)[1]()
+            with torch.cuda.stream(s_face):
+                self.models["face"][1].a2p_check_finite()
+            with torch.cuda.stream(s_body):
+                self.models["pose"][1].a2p_check_finite()
+        finally:
+            for _, _, diff in self.models.values():
+                diff.defer_finite_check = False
         main.wait_stream(s_face)
         main.wait_stream(s_body)
         torch.cuda.synchronize()

@@ -101,6 +101,11 @@ def test_non_finite_outputs_raise_once_per_sampling_call(dev, precision):
     with pytest.raises(_lib.A2PError, match="inf / nan"):
         diffusion.ddim_sample_loop(cfg, (B, spec.nfeats, 1, T), clip_denoised=False, model_kwargs={"y": y}, noise=inp["x_T"].to(dev))
     cfg.a2p_check_finite()                                            # cleared by the raise: a second check is clean
+    diffusion.defer_finite_check = True                               # multi-stream callers: the loop does not wait for its stream ...
+    diffusion.ddim_sample_loop(cfg, (B, spec.nfeats, 1, T), clip_denoised=False, model_kwargs={"y": y}, noise=inp["x_T"].to(dev))
+    with pytest.raises(_lib.A2PError, match="inf / nan"):            # ... and the flag is still there when the caller asks
+        cfg.a2p_check_finite()
+    diffusion.defer_finite_check = False
     load_model(model, sd)
     out = diffusion.ddim_sample_loop(cfg, (B, spec.nfeats, 1, T), clip_denoised=False, model_kwargs={"y": y}, noise=inp["x_T"].to(dev))
     assert torch.isfinite(out).all()
