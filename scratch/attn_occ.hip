@@ -44,6 +44,33 @@ template <int DH> void sweep(int nseq, int S) {
   }
   CK(hipFree(q)); CK(hipFree(k)); CK(hipFree(vt)); CK(hipFree(o));
 }
+#ifdef ATTN_QT_PATCH   // needs QT as a template parameter of attn_kernel (a three-line patch: template <..., int QTP = 2>, QT = QTP, __launch_bounds__(64 * NWV, QTP == 2 ? 3 : 2))
+// 64 queries per wave (QTP = 4, two waves per workgroup, two per SIMD) against the shipped 32 (four waves per workgroup, three per SIMD)
+template <int DH, int NWV, int QTP> void qt_shape(int nseq, int T, int S) {
+  const int d = 8 * DH;
+  const int Sld = (S + 63) / 64 * 64;
+  h16_t *q, *k, *vt, *o;
+  CK(hipMalloc(&q, (size_t)nseq * T * d * 2)); CK(hipMalloc(&k, ((size_t)nseq * Sld + 64) * d * 2));
+  CK(hipMalloc(&vt, (size_t)nseq * d * Sld * 2)); CK(hipMalloc(&o, (size_t)nseq * T * d * 2));
+  std::vector<uint16_t> h((size_t)nseq * (Sld > T ? Sld : T) * d + 64 * d);
+  for (auto& v : h) v = 0x3800 + (rand() & 0x7ff) - ((rand() & 1) << 15);
+  CK(hipMemcpy(k, h.data(), ((size_t)nseq * Sld + 64) * d * 2, hipMemcpyHostToDevice));
+  CK(hipMemcpy(vt, h.data(), (size_t)nseq * d * Sld * 2, hipMemcpyHostToDevice));
+  CK(hipMemcpy(q, h.data(), (size_t)nseq * T * d * 2, hipMemcpyHostToDevice));
+  AttnP a; memset(&a, 0, sizeof(a));
+  a.Q = q; a.q_seq_stride = (int64_t)T * d; a.ldq = d; a.K = k; a.k_slot_stride = (int64_t)Sld * d; a.ldk = d;
+  a.VT = vt; a.vt_slot_stride = (int64_t)d * Sld; a.ldvt = Sld; a.O = o; a.o_seq_stride = (int64_t)T * d; a.ldo = d;
+  a.tail_mod = 1; a.Tq = T; a.S_main = S; a.S_tail = 0; a.scale_log2e = 1.4426950408889634f / sqrtf((float)DH);
+  constexpr int BQ = NWV * QTP * 16;
+  a.nq = (T + BQ - 1) / BQ; a.nheads = 8; a.nseq = nseq; a.xcd_remap = 1;
+  dim3 grid(a.nq * 8 * nseq);
+  float us = time_it([&] { attn_kernel<h16_t, DH, 0, NWV, QTP><<<grid, 64 * NWV>>>(a); });
+  CK(hipDeviceSynchronize());
+  const double gf = 4.0 * nseq * 8 * (double)T * S * DH * 1e-9;
+  printf("  dh=%d nseq=%3d T=%d S=%4d  %d waves x %2d queries  grid=%5d  %8.1f us  %7.1f TF\n", DH, nseq, T, S, NWV, QTP * 16, grid.x, us, gf / us * 1e3);
+  CK(hipFree(q)); CK(hipFree(k)); CK(hipFree(vt)); CK(hipFree(o));
+}
+#endif
 #ifdef ATTN_KS_PATCH   // needs scratch/attn_keysplit_experiment.patch applied to the kernel header
 // key split (attn_kernel KS = 2) against the plain form: time and output difference at the shapes of the product
 template <int KS> float run_ks(AttnP a, int nseq, h16_t* o) {
@@ -99,7 +126,17 @@ int main(int argc, char** argv) {
     return 0;
   }
 #endif
-  (void)argc; (void)argv;
+#ifdef ATTN_QT_PATCH
+  if (argc > 1 && !strcmp(argv[1], "qt")) {
+    for (int rep = 0; rep < 2; ++rep)
+      for (int S : {2000, 600})
+        for (int nseq : {16, 64}) {
+          qt_shape<64, 4, 2>(nseq, 600, S); qt_shape<64, 2, 4>(nseq, 600, S);
+        }
+    for (int S : {2000, 600}) { qt_shape<32, 4, 2>(32, 600, S); qt_shape<32, 2, 4>(32, 600, S); }
+    return 0;
+  }
+#endif
   sweep<64>(16, 2000);
   sweep<64>(16, 600);
   sweep<32>(32, 2000);
