@@ -1,5 +1,7 @@
 #!/bin/bash
-# round 4, call 24: 64 queries per wave (2 waves per workgroup, 2 per SIMD) against the shipped 32 (4 per workgroup, 3 per SIMD)
+# round 4, call 25: the whole GPU suite + smoke on the current HEAD
 cd "$GRAFT_REPO_ROOT" 2>/dev/null || cd /root/repo
 mkdir -p gpurun_out
-timeout -k 5 300 ./scratch/attn_occ qt 2>&1 | tee gpurun_out/c24_attn_qt4.txt
+timeout -k 5 1500 python -m pytest tests -q -m gpu -x 2>&1 | tail -8 | tee gpurun_out/c25_tests_all.log
+timeout -k 5 300 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -3 | tee -a gpurun_out/c25_tests_all.log
+cp gpurun_out/parity_tests.json gpurun_out/c25_parity_tests.json 2>/dev/null
