@@ -41,6 +41,7 @@ struct a2p_frontend_ctx {
   Buf cond, xs, xn, qk, vt, ao, hff, lipf;  // lip regressor workspaces
   size_t cap_samples = 0;
   int cap_seq = 0;
+  int64_t cap_rows = 0, cap_lip = 0;   // rows per regressor buffer / frames of the lip output buffer currently allocated
 };
 
 static const float* FW(a2p_frontend_ctx* f, const std::string& n) { return f->w.at(n).f(); }
@@ -645,18 +646,22 @@ static int fe_ffn_block(a2p_frontend_ctx* f, const std::string& np, const std::s
 
 // Audio2LipRegressionTransformer.forward for `N` chunks of `Tc` frames each (model/diffusion.py:63-79): chunk audio [N][Tc*1600]
 // mono 48 kHz, gathered from channel 0 of `audio`; result rows go to lip[b][t0 + t][lip_out]
-static int fe_lip_chunks(a2p_frontend_ctx* f, const float* audio, int64_t samples, int B, int T, int t0, int Tc, hipStream_t s) {
+// `nchunk` consecutive chunks of every sample starting at frame t0 run as ONE batch of N = B * nchunk sequences (sequence n = sample
+// n / nchunk, chunk n % nchunk): the chunks are independent in the reference (a Python loop over 4-second windows), and one pass over
+// 5 x the rows costs a fifth of the launches (T = 600: 11 -> ~5 ms for the regressor at B = 8).
+static int fe_lip_chunks(a2p_frontend_ctx* f, const float* audio, int64_t samples, int B, int T, int t0, int Tc, int nchunk, hipStream_t s) {
   a2p_ctx* c = &f->core;
   const int d = f->cfg.d_model, C = f->cfg.conv_dim, spf = f->cfg.samples_per_frame, Lo = f->cfg.lip_out;
   const std::string R = "lip_model.regression_model.";
   const int64_t Lc = (int64_t)Tc * spf;
   const int64_t Sc = fe_conv_len((Lc + 2) / 3 + f->cfg.lip_pad);
   ARG(Sc >= 1 && Sc <= 1024 && Tc <= 1024, "lip chunk of %d frames gives %lld wav2vec tokens (positional table holds 1024)", Tc, (long long)Sc);
-  const int N = B;
+  const int N = B * nchunk;
   // Wav2VecEncoder (audio_encoder.py:34-46): resample, 320 zeros on the left, feature extractor, feature aggregator (the identity
   // in the stub geometry; cfg.agg_layers > 0: fairseq's ConvAggregator, fe_aggregate)
-  for (int b = 0; b < B; ++b) {
-    fe_deinterleave_kernel<<<(int)((Lc + 255) / 256), 256, 0, s>>>(audio + ((size_t)b * samples + (size_t)t0 * spf) * 2, f->wav.f(), Lc, 0);
+  for (int b = 0; b < N; ++b) {
+    const size_t frame0 = (size_t)t0 + (size_t)(b % nchunk) * Tc;
+    fe_deinterleave_kernel<<<(int)((Lc + 255) / 256), 256, 0, s>>>(audio + ((size_t)(b / nchunk) * samples + frame0 * spf) * 2, f->wav.f(), Lc, 0);
     const float* feat = nullptr;
     int64_t S = 0;
     CHK(fe_features(f, f->wav.f(), Lc, f->cfg.lip_pad, f->conv_l, fe_stack(f, true), &feat, &S, s));
@@ -683,11 +688,11 @@ static int fe_lip_chunks(a2p_frontend_ctx* f, const float* audio, int64_t sample
     CHK(fe_attn_block(f, p + "norm2", p + "cross_attn.cross_attn", N, Tc, f->cond.f(), (int)Sc, s));
     CHK(fe_ffn_block(f, p + "norm3", p + "feedforward", N * Tc, s));
   }
-  // project_output (model/diffusion.py:60,76) straight into lip[b][t0 + t][:]
+  // project_output (model/diffusion.py:60,76) straight into lip[b][t0 + t][:]: the nchunk * Tc rows of a sample are consecutive
   const int Lp = f->lo_pad;   // rows of lipf are Lp wide, the first Lo columns are the regressor's output
   GemmP po = gemm_base(f->xs.p, d, f->po_w.p, d, f->po_b.f(), f->lipf.f() + (size_t)t0 * Lp, Lp, N * Tc, Lp, d);
-  po.rows_per_seq = Tc;
-  po.out_seq_pad = T - Tc;
+  po.rows_per_seq = nchunk * Tc;
+  po.out_seq_pad = T - nchunk * Tc;
   CHK(launch_gemm(c, po, s));
   HIPCHK(hipGetLastError());
   return 0;
@@ -705,15 +710,25 @@ extern "C" int a2p_frontend_encode_lip(a2p_frontend_ctx* f, const float* audio, 
   ARG(B >= 1 && B <= f->cfg.max_batch && T >= 1 && T <= f->cfg.max_frames, "batch %d / frames %d beyond the configured capacity", B, T);
   hipStream_t s = (hipStream_t)stream;
   CHK(fe_reserve(f, (size_t)chunk * spf));
-  if (f->cap_seq < B) {
-    const size_t rows = (size_t)B * 1024 + 128, Sld = 1024;
+  const int nfull = T / chunk, Nmax = B * std::max(nfull, 1);
+  // regressor buffers: N sequences of max(audio tokens, frames) rows of the longest chunk (T = 600 at B = 8: 40 sequences x 448 rows)
+  const int Tc_long = std::min(chunk, T);
+  const int64_t Sc_long = fe_conv_len(((int64_t)Tc_long * spf + 2) / 3 + f->cfg.lip_pad);
+  const int64_t R = rup((int)std::max<int64_t>(Sc_long, Tc_long), 64);
+  if (f->cap_seq < Nmax || f->cap_rows < (int64_t)Nmax * R) {
+    const size_t rows = (size_t)Nmax * R + 128;
     CHK(buf_alloc_tmp(f->cond, rows * d * 4)); CHK(buf_alloc_tmp(f->xs, rows * d * 4)); CHK(buf_alloc_tmp(f->xn, rows * d * 4));
-    CHK(buf_alloc_tmp(f->qk, (rows + (size_t)B * Sld + 64) * d * 4)); CHK(buf_alloc_tmp(f->vt, (size_t)B * d * Sld * 4));
+    CHK(buf_alloc_tmp(f->qk, (2 * rows + 64) * d * 4)); CHK(buf_alloc_tmp(f->vt, (size_t)Nmax * d * R * 4));
     CHK(buf_alloc_tmp(f->ao, rows * d * 4)); CHK(buf_alloc_tmp(f->hff, rows * f->cfg.ff_size * 4));
-    CHK(buf_alloc_tmp(f->lipf, (size_t)B * f->cfg.max_frames * rup(Lo, 4) * 4));
-    f->cap_seq = B;
+    f->cap_seq = Nmax;
+    f->cap_rows = (int64_t)Nmax * R;
   }
-  for (int t0 = 0; t0 < T; t0 += chunk) CHK(fe_lip_chunks(f, audio, samples, B, T, t0, std::min(chunk, T - t0), s));
+  if (f->cap_lip < (int64_t)B * f->cfg.max_frames) {
+    CHK(buf_alloc_tmp(f->lipf, (size_t)B * f->cfg.max_frames * rup(Lo, 4) * 4));
+    f->cap_lip = (int64_t)B * f->cfg.max_frames;
+  }
+  if (nfull > 0) CHK(fe_lip_chunks(f, audio, samples, B, T, 0, chunk, nfull, s));                      // all whole chunks in one batch
+  if (T > nfull * chunk) CHK(fe_lip_chunks(f, audio, samples, B, T, nfull * chunk, T - nfull * chunk, 1, s));   // the ragged last one
   const int64_t total = (int64_t)B * n_tokens * (cond_dim + Lo);
   fe_concat_kernel<<<(int)((total + 255) / 256), 256, 0, s>>>(cond_in, f->lipf.f(), out, B, n_tokens, T, cond_dim, Lo, f->lo_pad);
   HIPCHK(hipGetLastError());

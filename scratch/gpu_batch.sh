@@ -1,7 +1,6 @@
 #!/bin/bash
-# round 4, call 25: the whole GPU suite + smoke on the current HEAD
+# round 4, call 27: lip regressor over all whole chunks in one batch: front-end tests, then the pipeline line
 cd "$GRAFT_REPO_ROOT" 2>/dev/null || cd /root/repo
 mkdir -p gpurun_out
-timeout -k 5 1500 python -m pytest tests -q -m gpu -x 2>&1 | tail -8 | tee gpurun_out/c25_tests_all.log
-timeout -k 5 300 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -3 | tee -a gpurun_out/c25_tests_all.log
-cp gpurun_out/parity_tests.json gpurun_out/c25_parity_tests.json 2>/dev/null
+timeout -k 5 900 python -m pytest tests/test_frontend_hip.py -x -q -m gpu 2>&1 | tail -4
+timeout -k 5 600 python bench.py --pipeline --batch 8 > gpurun_out/c27_pipeline.json 2> gpurun_out/c27_pipeline.err; tail -c 600 gpurun_out/c27_pipeline.json; tail -2 gpurun_out/c27_pipeline.err
