@@ -1,6 +1,11 @@
 #!/bin/bash
-# round 4, call 27: lip regressor over all whole chunks in one batch: front-end tests, then the pipeline line
-cd "$GRAFT_REPO_ROOT" 2>/dev/null || cd /root/repo
-mkdir -p gpurun_out
-timeout -k 5 900 python -m pytest tests/test_frontend_hip.py -x -q -m gpu 2>&1 | tail -4
-timeout -k 5 600 python bench.py --pipeline --batch 8 > gpurun_out/c27_pipeline.json 2> gpurun_out/c27_pipeline.err; tail -c 600 gpurun_out/c27_pipeline.json; tail -2 gpurun_out/c27_pipeline.err
+# round 4, call 28: final evidence on the final kernels: default bench line, body kernel stats, pipeline
+R=${GRAFT_REPO_ROOT:-/root/repo}
+O=$R/gpurun_out; mkdir -p $O
+cd /tmp && export TMPDIR=/tmp
+B="python $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-kernel-timing --no-legs --no-parity --repeats 1"
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_body -o p -- $B --model pose --batch 16 > $O/prof_body.log 2>&1
+cp $O/prof_body/p_kernel_stats.csv $O/r04_body_kernel_stats.csv; rm -rf $O/prof_body
+cd $R
+head -6 $O/r04_body_kernel_stats.csv | cut -c1-120
+timeout -k 5 900 python bench.py > $O/r04_bench_default.json 2> $O/r04_bench_default.err; tail -c 300 $O/r04_bench_default.json
