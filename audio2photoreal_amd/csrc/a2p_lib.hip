@@ -159,6 +159,7 @@ struct A2POpts {
   int ksplit_nw = 0;        // A2P_KSPLIT_NW=4|8: waves of the key-split attention
   int ksplit_qt = 0;        // A2P_KSPLIT_QT=1|2: 16-query tiles per wave of the key-split attention
   int force_ksplit = 0;     // A2P_ATTN_KSPLIT=1: every 16-bit attention launch takes the key-split kernel (tests)
+  int no_fused_kf = 0;      // A2P_NO_FUSED_KF=1: body model: MID2 | keyframe attention | POST as three launches instead of one (A/B, tests)
   int graph = 0;            // A2P_GRAPH=1: non-chain forwards replay a captured graph instead of stream launches (measured: same GPU
                             // time per step -- the launches are not host-bound -- at a tenth of the host time; off by default)
   int no_small = 0;         // A2P_NO_SMALL=1: per-op kernels for forwards below 960 rows instead of kernels_small.h
@@ -176,6 +177,7 @@ static void load_opts(A2POpts& o) {
   o.side_early_join = flag("A2P_SIDE_EARLY_JOIN"); o.no_shared_half = flag("A2P_NO_SHARED_HALF");
   o.graph = flag("A2P_GRAPH");
   o.no_ksplit = flag("A2P_NO_KSPLIT"); o.force_ksplit = flag("A2P_ATTN_KSPLIT"); o.ksplit_nw = num("A2P_KSPLIT_NW", 0); o.ksplit_qt = num("A2P_KSPLIT_QT", 0);
+  o.no_fused_kf = flag("A2P_NO_FUSED_KF");
   o.no_small = flag("A2P_NO_SMALL"); o.chain_rows = num("A2P_CHAIN_ROWS", 1100);
 }
 
@@ -208,7 +210,7 @@ struct a2p_ctx {
   Buf tail_w, tail_b;                  // fused output tail of the body model (kernels_tail.h): packed MFMA weight operands, [8][256] biases
   int64_t tail_woff[8] = {};
   bool tail_fused = false;
-  std::vector<Buf> ch_stream, ch_aux;  // packed weight streams [layout * L*4 + layer*4 + kind] (layout 0: 4-wave LDS slices, 1: 8-wave) / bias blocks [layer*4 + kind]
+  std::vector<Buf> ch_stream, ch_aux;  // packed weight streams [layout * L*5 + layer*5 + kind] (layout 0: 4-wave LDS slices, 1: 8-wave; kinds: a2p_lib_run.h CH_*) / bias blocks [layer*5 + kind]
   int ch_nw = 4;                       // waves per chain workgroup of the forward being enqueued (4 or 8; chain_pick_nw)
   struct ChainTune {                   // per forward size (rows): which workgroup shape is faster ON THIS BOX, measured in situ
     int choice = 0, calls = 0;

@@ -104,8 +104,8 @@ static bool chain_supported(const a2p_ctx* c) {
   return c->bf16 && (c->d == 512 || c->d == 256) && c->ff == 1024 && !c->ch_stream.empty() && !c->opt.no_chain;
 }
 
-enum { CH_PRE = 0, CH_MID = 1, CH_MID2 = 2, CH_POST = 3 };
-static int ch_index(int layer, int kind) { return layer * 4 + kind; }
+enum { CH_PRE = 0, CH_MID = 1, CH_MID2 = 2, CH_POST = 3, CH_MIDPOST = 4, CH_KINDS = 5 };   // CH_MIDPOST: MID2 | keyframe attention | POST as one kernel (body model)
+static int ch_index(int layer, int kind) { return layer * CH_KINDS + kind; }
 
 // stages of one GEMM: 128-row tiles of W[nrows, ldw] (tile-major), K/64 k-steps each
 // omap: the GEMM's tiles are stored straight to HBM by chain_body::gemm_store (Q|K, V, Q projections): paired column map for
@@ -130,7 +130,7 @@ static int chain_pack(a2p_ctx* c, int idx, const std::vector<ChainPackDesc>& des
   CHK(buf_alloc_tmp(dd, descs.size() * sizeof(ChainPackDesc)));
   HIPCHK(hipMemcpyAsync(dd.p, descs.data(), descs.size() * sizeof(ChainPackDesc), hipMemcpyHostToDevice, s));
   for (int w8 = 0; w8 < 2; ++w8) {  // both slice layouts: 4 waves x 32 out-cols and 8 waves x 16 (chain_pick_nw chooses per box)
-    Buf& st = c->ch_stream[(size_t)w8 * c->L * 4 + idx];
+    Buf& st = c->ch_stream[(size_t)w8 * c->L * CH_KINDS + idx];
     CHK(buf_alloc(st, (descs.size() + pad) * CHAIN_STAGE_ELEMS * 2));
     chain_pack_kernel<<<(int)descs.size(), 256, 0, s>>>(reinterpret_cast<const ChainPackDesc*>(dd.p), reinterpret_cast<h16_t*>(st.p), w8 ? 8 : 4);
   }
@@ -150,9 +150,9 @@ static int chain_pack(a2p_ctx* c, int idx, const std::vector<ChainPackDesc>& des
 // pre-pack every chain's weight stream in consumption order (called from a2p_finalize_weights)
 static int chain_build_streams(a2p_ctx* c, hipStream_t s) {
   const int d = c->d, ff = c->ff, L = c->L;
-  if (c->ch_stream.size() != (size_t)L * 8) {  // first build; later builds (weight updates) refill the same buffers
-    c->ch_stream.assign((size_t)L * 8, Buf());
-    c->ch_aux.assign((size_t)L * 4, Buf());
+  if (c->ch_stream.size() != (size_t)L * 2 * CH_KINDS) {  // first build; later builds (weight updates) refill the same buffers
+    c->ch_stream.assign((size_t)L * 2 * CH_KINDS, Buf());
+    c->ch_aux.assign((size_t)L * CH_KINDS, Buf());
   }
   auto pf = [&](int l) { return "seqTransDecoder.stack." + std::to_string(l) + "."; };
   auto add_pre = [&](std::vector<ChainPackDesc>& v, int l) {  // [Q|K] then V of layer l's self attention
@@ -194,6 +194,14 @@ static int chain_build_streams(a2p_ctx* c, hipStream_t s) {
       aux.push_back({W32(c, "final_layer.bias"), c->C});
     }
     CHK(chain_pack(c, ch_index(l, CH_POST), q, aux, s));
+    if (c->pose) {   // CHAIN_MIDPOST: out_proj of the audio cross attention | query projection of multihead_attn2 (k-major group: its
+      // tiles stay in registers until the panel can be overwritten) | everything of the POST stream
+      std::vector<ChainPackDesc> mp;
+      pk_gemm(mp, c->wt.at(pf(l) + "multihead_attn.out_proj.weight").p, d, d, d, 0, d / 128);
+      pk_gemm(mp, c->wt.at(pf(l) + "multihead_attn2.in_proj_weight").p, d, d, d, 0, d / 128);
+      mp.insert(mp.end(), q.begin(), q.end());
+      CHK(chain_pack(c, ch_index(l, CH_MIDPOST), mp, aux, s));
+    }
   }
   return 0;
 }
@@ -202,7 +210,7 @@ static void chain_base(a2p_ctx* c, ChainP& p, int N, int T, int idx, int aux_flo
   memset(&p, 0, sizeof(p));
   p.M = N * T; p.rows_per_seq = T; p.x = c->x.f(); p.cst = reinterpret_cast<const f32x4*>(c->rope_cst.p); p.cs_npos = c->rope_npos;
   p.ain = reinterpret_cast<const h16_t*>(c->ao.p); p.ld_ain = c->d;
-  p.stream = reinterpret_cast<const h16_t*>(c->ch_stream[(size_t)(c->ch_nw == 8) * c->L * 4 + idx].p);
+  p.stream = reinterpret_cast<const h16_t*>(c->ch_stream[(size_t)(c->ch_nw == 8) * c->L * CH_KINDS + idx].p);
   p.aux = c->ch_aux[idx].f(); p.aux_kb = (aux_floats + 255) / 256;
   if (c->clk.p) {  // A2P_CHAIN_CLK=1: every chain launch of a forward gets its own 8 x 4 slot (a2p_debug_read "clk")
 #ifdef A2P_STAMPS   // diagnostic build (scratch/phase_probe.py): launch A2P_STAMP_LAUNCH of every forward writes its phase stamps behind the clk slots
@@ -342,6 +350,25 @@ static int launch_chain(a2p_ctx* c, int mode, const ChainP& p, hipStream_t s) {
     else A2P_LAUNCH(kt, (chain_kernel<D, MT, CHAIN_POST, A2P_CHAIN_ABL, NW>), grid, 64 * NW, s, p);                         \
   } while (0)
 #define A2P_CHAIN(D, MT) A2P_CHAIN_W(D, MT, 4)
+  if (mode == CHAIN_MIDPOST) {   // body model only (d = 256): MID2 | keyframe attention | POST in one kernel
+    ARG(c->d == 256, "CHAIN_MIDPOST is instantiated for d = 256");
+#define A2P_CHAIN_MP(MT, NW) A2P_LAUNCH(kt, (chain_kernel<256, MT, CHAIN_MIDPOST, A2P_CHAIN_ABL, NW>), grid, 64 * NW, s, p)
+    if (w8) {
+      if (mt == 2) A2P_CHAIN_MP(2, 8);
+      else if (mt == 3) A2P_CHAIN_MP(3, 8);
+      else if (mt == 4) A2P_CHAIN_MP(4, 8);
+      else A2P_CHAIN_MP(5, 8);
+    } else {
+      if (mt == 2) A2P_CHAIN_MP(2, 4);
+      else if (mt == 3) A2P_CHAIN_MP(3, 4);
+      else if (mt == 4) A2P_CHAIN_MP(4, 4);
+      else if (mt == 5) A2P_CHAIN_MP(5, 4);
+      else A2P_CHAIN_MP(6, 4);
+    }
+#undef A2P_CHAIN_MP
+    HIPCHK(hipGetLastError());
+    return 0;
+  }
   if (w8) {
     if (c->d == 512) {
       if (mt == 2) A2P_CHAIN_W(512, 2, 8);
@@ -443,13 +470,30 @@ static int decoder_layer_chain(a2p_ctx* c, int l, int N, int T, const CrossKV& k
   };
   CHK(mid(CH_MID, "self_attn", 0, "norm2"));
   CHK(launch_cross_attention(c, N, T, kv, s));
-  if (kv2) {
+  // body model: MID2 | keyframe attention | POST as ONE kernel (kernels_chain.h CHAIN_MIDPOST) when the keyframes fit one 32-key chunk
+  // (T <= 960 frames at the reference's keyframe step of 30); A2P_NO_FUSED_KF=1 keeps the three launches (A/B, tests)
+  const bool fuse_kf = kv2 && d == 256 && kv2->S_main >= 1 && kv2->S_main <= 32 && kv2->S_tail == 0 && !c->opt.no_fused_kf && !fuse_final;
+  if (kv2 && !fuse_kf) {
     CHK(mid(CH_MID2, "multihead_attn", 1, "norm2a"));
     CHK(launch_cross_attention(c, N, T, *kv2, s));
   }
-  chain_base(c, p, N, T, ch_index(l, CH_POST), c->ff + (has_next ? 3 * d : 0));
-  chain_set_out_proj(c, p, pf + (kv2 ? "multihead_attn2" : "multihead_attn"), fr, kv2 ? 3 : 1);
-  p.lnA_g = W32(c, pf + "norm3.weight"); p.lnA_b = W32(c, pf + "norm3.bias");
+  chain_base(c, p, N, T, ch_index(l, fuse_kf ? CH_MIDPOST : CH_POST), c->ff + (has_next ? 3 * d : 0));
+  if (fuse_kf) {
+    chain_set_out_proj(c, p, pf + "multihead_attn", fr, 1);                                      // first sublayer: the audio cross attention's output
+    p.lnA_g = W32(c, pf + "norm2a.weight"); p.lnA_b = W32(c, pf + "norm2a.bias");
+    p.bias_q2 = W32(c, pf + "multihead_attn2.in_proj_bias");
+    p.bias_o2 = W32(c, pf + "multihead_attn2.out_proj.bias");
+    if (fr.base) p.film_o2 = fr.base + (int64_t)3 * 2 * d;
+    p.lnC_g = W32(c, pf + "norm3.weight"); p.lnC_b = W32(c, pf + "norm3.bias");
+    p.k2 = reinterpret_cast<const h16_t*>(kv2->K); p.k2_slot_stride = kv2->k_slot_stride; p.ld_k2 = kv2->ldk;
+    p.vt2 = reinterpret_cast<const h16_t*>(kv2->VT); p.vt2_slot_stride = kv2->vt_slot_stride; p.ld_vt2 = kv2->ldvt;
+    p.kv2_slots = kv2->slots; p.kv2_rule = kv2->slot_rule; p.kv2_b = kv2->slot_b; p.n_key2 = kv2->S_main;
+    p.scale2 = 1.0f / sqrtf((float)c->DH);
+    p.stat_max = c->nonfinite.p ? reinterpret_cast<int*>(c->nonfinite.p) + 1 : nullptr;
+  } else {
+    chain_set_out_proj(c, p, pf + (kv2 ? "multihead_attn2" : "multihead_attn"), fr, kv2 ? 3 : 1);
+    p.lnA_g = W32(c, pf + "norm3.weight"); p.lnA_b = W32(c, pf + "norm3.bias");
+  }
   p.bias_2 = W32(c, pf + "linear2.bias");
   if (fr.base) p.film_f = fr.base + (int64_t)2 * 2 * d;
   p.has_next = has_next ? 1 : 0;
@@ -460,7 +504,7 @@ static int decoder_layer_chain(a2p_ctx* c, int l, int N, int T, const CrossKV& k
     p.has_next = 2; p.fin_out = c->mo.f(); p.ld_fin = c->C; p.fin_n = c->C;
     p.aux_kb = (c->ff + c->C + 255) / 256;
   }
-  return launch_chain(c, CHAIN_POST, p, s);
+  return launch_chain(c, fuse_kf ? CHAIN_MIDPOST : CHAIN_POST, p, s);
 }
 
 // FiLMTransformerDecoderLayer.forward (transformer_modules.py:178-217) on c->x

@@ -52,7 +52,11 @@
 // OFF in this header and every fused multiply-add is written as an explicit fmaf.
 #pragma clang fp contract(off)
 
-enum { CHAIN_PRE = 0, CHAIN_MID = 1, CHAIN_POST = 2 };
+enum { CHAIN_PRE = 0, CHAIN_MID = 1, CHAIN_POST = 2, CHAIN_MIDPOST = 3 };
+// CHAIN_MIDPOST (round 4, body model): MID work of the audio cross attention's output -> the KEYFRAME cross attention
+// (multihead_attn2: <= 32 keys per sequence, transformer_modules.py:206-215) inside the kernel, on the query panel in LDS -> POST
+// work.  One launch where MID2 | attention | POST were three: the residual rows stay in registers, the query never leaves the CU,
+// and the 1280-workgroup attention launch over 20 keys (9 us of dispatch for 2 us of work) disappears.
 // An in-kernel L2 look-ahead of the stream (one 4-byte-per-lane LDS-DMA per wave per stage touching the slice 8-16 stages
 // ahead of the DMA head) was measured and rejected: +30 % kernel time warm AND cold -- the L2 request count per line, not
 // the bytes, is what the extra instruction doubles (scratch/chain_bench).
@@ -102,6 +106,19 @@ struct ChainP {
   int64_t vt_seq_stride, ld_vt;
   const f32x4* cst;  // rotary table in the panel layout [D/4][cs_npos]: (cos, sin) x 2 of 4 consecutive columns (rope_table_t_kernel)
   int cs_npos;
+  // CHAIN_MIDPOST: the second sublayer (multihead_attn2 on the keyframe tokens) between the MID and POST work
+  const float* bias_q2;        // in_proj_bias rows [0, D) of multihead_attn2 (its weight rows are the stream's second group GEMM)
+  const float* bias_o2;        // its out_proj bias / FiLM (strides as film_o)
+  const float* film_o2;
+  const float* lnC_g;          // norm3 (lnA_* is norm2a in this mode)
+  const float* lnC_b;
+  const h16_t* k2;             // keyframe K cache [slot][keys][ld_k2] (+ layer offset), 16-bit
+  const h16_t* vt2;            // keyframe V^T cache [slot][D rows][ld_vt2]
+  int64_t k2_slot_stride, ld_k2, vt2_slot_stride, ld_vt2;
+  const int* kv2_slots;        // per-sequence slot table, or the rule below (AttnP::slot_rule)
+  int kv2_rule, kv2_b, n_key2; // n_key2 <= 32
+  float scale2;                // 1 / sqrt(head_dim)
+  int* stat_max;               // a2p_attention_logit_max (kernels_attn.h), may be NULL
   // has_next == 2 (last decoder layer): final_layer (model/diffusion.py:397) instead of the next layer's PRE work;
   // fp32 rows out[m][0..fin_n), bias in aux after bias_1; the residual stream itself is not written back
   float* fin_out;
@@ -846,7 +863,7 @@ __device__ __forceinline__ void chain_body(const ChainP& p, h16_t* const smem, c
     dma_drained = true;
   } else {
     // out_proj of the attention that produced `ain`; FiLM + residual into the register rows once all tiles are done
-    {
+    auto out_proj_block = [&](const float* bias, const float* film) __attribute__((always_inline)) {
       f32x4 oacc[NT][MT][NJ];
 #pragma unroll
       for (int t = 0; t < NT; ++t) zero(oacc[t]);
@@ -854,9 +871,10 @@ __device__ __forceinline__ void chain_body(const ChainP& p, h16_t* const smem, c
       stamp(2);
       if constexpr (!(ABL & 512)) {
 #pragma unroll
-        for (int t = 0; t < NT; ++t) film_res(oacc[t], t, p.bias_o, p.film_o);
+        for (int t = 0; t < NT; ++t) film_res(oacc[t], t, bias, film);
       }
-    }
+    };
+    out_proj_block(p.bias_o, p.film_o);
     stamp(3);
     if constexpr (ABL & 256) {
       store_x();
@@ -873,7 +891,143 @@ __device__ __forceinline__ void chain_body(const ChainP& p, h16_t* const smem, c
       store_x();
       dma_drained = true;
     } else {
-      ln_write(p.lnA_g, p.lnA_b, std::false_type{});
+      if constexpr (MODE == CHAIN_MIDPOST) {
+        // ---- the keyframe cross attention (multihead_attn2) without leaving the kernel ----
+        static_assert(MODE != CHAIN_MIDPOST || D == 256, "the fused keyframe attention is written for the body model (8 heads x 32)");
+        ln_write(p.lnA_g, p.lnA_b, std::true_type{});   // norm2a + rotary -> A panel
+        {
+          // query projection of ALL tiles into registers (k-major group GEMM, like out_proj), then over the panel it was computed from
+          f32x4 qacc[NT][MT][NJ];
+#pragma unroll
+          for (int t = 0; t < NT; ++t) zero(qacc[t]);
+          gemm_group(qacc, panelA, D, std::integral_constant<int, KS>{});
+          chain_bar();   // every wave is done reading the rotated rows
+#pragma unroll
+          for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) {
+              const int n = col_of(t, j);
+              const f32x4 b = *reinterpret_cast<const f32x4*>(p.bias_q2 + n);
+#pragma unroll
+              for (int mt = 0; mt < MT; ++mt) {
+                const f32x4 v = qacc[t][mt][j] + b;
+                *reinterpret_cast<h16x4*>(panelA + (mt * 16 + l15) * D + ((((n >> 3) ^ l15) << 3) | (n & 7))) =
+                    h16x4{(h16_t)v[0], (h16_t)v[1], (h16_t)v[2], (h16_t)v[3]};
+              }
+            }
+        }
+        chain_bar();     // the query panel is complete
+#ifndef A2P_KF_SKIP   // (scratch timing build: the kernel without its attention phase)
+        {
+          // S^T = K Q^T and O^T = V^T P^T per (16-row tile, head) with the fragment / key mapping of kernels_attn.h: lane (l15, g) owns
+          // query row l15 and the 8 keys 8g .. 8g+7, so the probabilities feed the second MFMA without data movement.  Wave w takes
+          // head(s) w * HPW ..; the keys of a head stay in 4 registers for all row tiles.  A tile that straddles two sequences is
+          // computed against both caches and each row keeps its own.
+          constexpr int DH = 32, HPW = (D / DH) / NW;
+          const int nk = p.n_key2;
+          auto slot_of = [&](int seq) __attribute__((always_inline)) {
+            if (p.kv2_rule == 1) return 1 + seq;
+            if (p.kv2_rule == 2) return 0;
+            if (p.kv2_rule == 3) return seq < p.kv2_b ? 1 + seq : 0;
+            return p.kv2_slots ? p.kv2_slots[seq] : seq;
+          };
+          float mtop = -INFINITY;
+#pragma unroll
+          for (int hh = 0; hh < HPW; ++hh) {
+            const int h = wid * HPW + hh;
+            h16x8 kf[2], vf[2];
+            int cur = -1;
+            auto load_kv = [&](int slot) __attribute__((always_inline)) {
+              const h16_t* Kb = p.k2 + (int64_t)slot * p.k2_slot_stride + h * DH + g * 8;
+              const h16_t* Vb = p.vt2 + (int64_t)slot * p.vt2_slot_stride + (int64_t)(h * DH + l15) * p.ld_vt2 + g * 8;
+#pragma unroll
+              for (int kt = 0; kt < 2; ++kt) {
+                int key = 8 * (l15 >> 2) + 4 * kt + (l15 & 3);   // AttnLds::krow: accumulator rows 4g + r of both tiles = keys 8g .. 8g+7
+                key = key < nk ? key : nk - 1;                   // absent keys: any valid row (their scores are masked)
+                kf[kt] = *reinterpret_cast<const h16x8*>(Kb + (int64_t)key * p.ld_k2);
+                vf[kt] = *reinterpret_cast<const h16x8*>(Vb + (int64_t)(kt * 16) * p.ld_vt2);   // (kt here: 16-row tile of head_dim)
+#pragma unroll
+                for (int e = 0; e < 8; ++e)
+                  if (g * 8 + e >= nk) vf[kt][e] = (h16_t)0.f;   // never-written cache columns must not meet P = 0 as inf / nan
+              }
+            };
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+              const int mf = m0 + mt * 16 < p.M ? m0 + mt * 16 : p.M - 1, ml = m0 + mt * 16 + 15 < p.M ? m0 + mt * 16 + 15 : p.M - 1;
+              const int sA = slot_of(mf / p.rows_per_seq), sB = slot_of(ml / p.rows_per_seq);   // wave-uniform
+              h16_t* const qp = panelA + (mt * 16 + l15) * D;
+              const h16x8 qf = *reinterpret_cast<const h16x8*>(qp + (((h * 4 + g) ^ l15) << 3));
+              auto attend = [&](f32x4(&o)[2]) __attribute__((always_inline)) {
+                const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+                f32x4 sc[2] = {A2P_MFMA16(kf[0], qf, z), A2P_MFMA16(kf[1], qf, z)};
+                float mx = -INFINITY;
+#pragma unroll
+                for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                  for (int r = 0; r < 4; ++r) {
+                    if (g * 8 + kt * 4 + r >= nk) sc[kt][r] = -INFINITY;
+                    mx = fmaxf(mx, sc[kt][r]);
+                  }
+                mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+                mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+                mtop = fmaxf(mtop, mx);
+                const float sl = p.scale2 * 1.4426950408889634f, nm = -mx * sl;
+                float l = 0.f;
+                h16x8 pf;
+#pragma unroll
+                for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                  for (int r = 0; r < 4; ++r) {
+                    const float e = __builtin_amdgcn_exp2f(fmaf(sc[kt][r], sl, nm));
+                    l += e;
+                    pf[kt * 4 + r] = (h16_t)e;
+                  }
+                l += __shfl_xor(l, 16, 64);
+                l += __shfl_xor(l, 32, 64);
+                const float inv = 1.0f / l;
+#pragma unroll
+                for (int dt = 0; dt < 2; ++dt) {
+                  o[dt] = A2P_MFMA16(vf[dt], pf, z);
+#pragma unroll
+                  for (int r = 0; r < 4; ++r) o[dt][r] *= inv;
+                }
+              };
+              f32x4 oa[2];
+              if (sA != cur) { load_kv(sA); cur = sA; }
+              attend(oa);
+              if (sB != sA) {   // the tile straddles two sequences
+                f32x4 ob[2];
+                load_kv(sB);
+                cur = sB;
+                attend(ob);
+                const bool second = slot_of(row_seq[mt]) == sB;
+#pragma unroll
+                for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+                  for (int r = 0; r < 4; ++r) oa[dt][r] = second ? ob[dt][r] : oa[dt][r];
+              }
+#pragma unroll
+              for (int dt = 0; dt < 2; ++dt) {
+                const int n = h * DH + dt * 16 + 4 * g;
+                *reinterpret_cast<h16x4*>(qp + ((((n >> 3) ^ l15) << 3) | (n & 7))) =
+                    h16x4{(h16_t)oa[dt][0], (h16_t)oa[dt][1], (h16_t)oa[dt][2], (h16_t)oa[dt][3]};
+              }
+            }
+          }
+          if (p.stat_max) {   // largest row maximum of the scaled scores (a2p_attention_logit_max), guarded like kernels_attn.h
+            float m = mtop * p.scale2;
+#pragma unroll
+            for (int o = 8; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+            const int bits = __float_as_int(m), mi = bits >= 0 ? bits : bits ^ 0x7fffffff;
+            if (lane == 0 && mi > __atomic_load_n(p.stat_max, __ATOMIC_RELAXED)) atomicMax(p.stat_max, mi);
+          }
+        }
+#endif
+        chain_bar();     // the attention output panel is complete: the state a POST kernel starts from
+        out_proj_block(p.bias_o2, p.film_o2);
+        ln_stats();
+      }
+      ln_write(MODE == CHAIN_MIDPOST ? p.lnC_g : p.lnA_g, MODE == CHAIN_MIDPOST ? p.lnC_b : p.lnA_b, std::false_type{});
       stamp(5);
       // feed forward, split-K over the 8 hidden chunks: linear1 chunk -> GELU -> LDS -> linear2 partial
       f32x4 facc[NT][MT][NJ];

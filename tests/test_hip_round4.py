@@ -309,3 +309,48 @@ def test_exact_island_ab_switches_still_run(dev, fmt, switch, monkeypatch):
         assert errs[switch] < 1e-3 and abs(errs[switch] - errs["default"]) < 1e-4, errs
     else:
         assert errs["default"] <= errs[switch] * 1.05 < 4e-3, errs        # the 16-bit tail is what the islands were built to replace
+
+
+# ----------------------------------------------------------------------------- keyframe attention inside the chain kernel
+@pytest.mark.parametrize("precision", ["fp16", "bf16"])
+@pytest.mark.parametrize("B,T", [(2, 600), (3, 208), (1, 570), (2, 90)])
+def test_fused_keyframe_attention_equals_the_three_launches(dev, B, T, precision, monkeypatch):
+    """csrc/kernels_chain.h CHAIN_MIDPOST: MID2 | keyframe cross attention (multihead_attn2, transformer_modules.py:206-215) | POST of
+    the body model as ONE kernel -- the query panel stays in LDS, the attention over the <= 32 keyframe tokens runs on it in place --
+    against the three launches (A2P_NO_FUSED_KF=1).  Same operand roundings (16-bit q, k, v, p; fp32 accumulation), a slightly different
+    softmax arithmetic: the forwards must agree far inside the 16-bit modes' distance from the oracle, and both must keep that distance.
+    T = 600 / 208 / 90: 16-row tiles straddle two sequences (the tile is computed against both key sets); ragged last panels throughout."""
+    from oracle import a2p_oracle as O
+    spec = pose_spec()
+    inp = synthetic_inputs(spec, B, T, SEED)
+    sd = synthetic_state_dict(spec, SEED)
+    if B > 1:
+        inp["mask"][1, :, :, T // 3:] = False
+    y = {"cond_embed": inp["cond_embed"].to(dev), "scale": torch.full((B,), 2.0, device=dev), "keyframes": inp["keyframes"].to(dev),
+         "mask": inp["mask"].to(dev)}
+    t = torch.tensor(([901, 417, 33] * 2)[:B], device=dev)
+    model, _ = create_model_and_diffusion(default_args("pose"), "test", precision=precision, max_batch=B)
+    load_model(model, sd)
+    cfg = ClassifierFreeSampleModel(model.to(dev).eval())
+    if 2 * B * T < 960:
+        monkeypatch.setenv("A2P_CHAIN_ROWS", "1")
+    outs = {}
+    for name in ("three_launches", "fused"):
+        if name == "fused":
+            monkeypatch.delenv("A2P_NO_FUSED_KF", raising=False)
+        else:
+            monkeypatch.setenv("A2P_NO_FUSED_KF", "1")
+        outs[name] = cfg(inp["x_T"].to(dev), t, y).cpu()
+    monkeypatch.delenv("A2P_CHAIN_ROWS", raising=False)
+    model.check_finite()
+    peak = model.last_logit_max
+    model.release()
+    assert torch.isfinite(outs["fused"]).all()
+    pair = float((outs["fused"] - outs["three_launches"]).norm() / outs["three_launches"].norm())
+    den = O.OracleDenoiser(sd, "pose", spec.num_layers, spec.num_heads, torch.float32)
+    want = den.forward_cfg(inp["x_T"][:1], t[:1].cpu(), inp["cond_embed"][:1], torch.full((1,), 2.0), inp["keyframes"][:1], inp["mask"][:1])
+    e_f = float((outs["fused"][:1] - want).norm() / want.norm())
+    e_3 = float((outs["three_launches"][:1] - want).norm() / want.norm())
+    record(f"fused_keyframe_attention/{precision}/B{B}_T{T}", pair=pair, fused_vs_oracle=e_f, three_launches_vs_oracle=e_3, logit_max=peak)
+    k = 1.0 if precision == "fp16" else 8.0
+    assert pair < k * 2e-4 and e_f < k * 1e-3 and e_f < 1.15 * e_3 + k * 5e-5, (pair, e_f, e_3)
