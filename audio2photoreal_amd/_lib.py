@@ -21,6 +21,7 @@ PREC_F32, PREC_BF16 = 0, 1
 PASS_COND, PASS_UNCOND, PASS_CFG = 0, 1, 2
 SAMPLER_DDIM, SAMPLER_DDPM = 0, 1
 KERNEL_GEMM, KERNEL_ATTN_SELF, KERNEL_ATTN_CROSS, KERNEL_LNROPE, KERNEL_CHAIN = 0, 1, 2, 3, 4
+KERNEL_CHAIN_PRE, KERNEL_CHAIN_MID, KERNEL_CHAIN_POST, KERNEL_CHAIN_MIDPOST, KERNEL_POSE_TAIL = 5, 6, 7, 8, 9   # finer classes (a2p_hip.h)
 # a2p_table_id
 TABLE_NAMES = (
     "posterior_mean_coef1", "posterior_mean_coef2", "posterior_variance", "posterior_log_variance_clipped",

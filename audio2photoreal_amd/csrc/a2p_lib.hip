@@ -270,7 +270,8 @@ struct KernelTimer {
   a2p_ctx* c;
   bool on;
   hipEvent_t e0 = nullptr, e1 = nullptr;
-  KernelTimer(a2p_ctx* ctx, int kind) : c(ctx), on(ctx && ctx->time_kind == kind) {
+  // `sub`: a finer class of the same launch (A2P_KERNEL_CHAIN_PRE.., A2P_KERNEL_POSE_TAIL): timed when either is selected
+  KernelTimer(a2p_ctx* ctx, int kind, int sub = -2) : c(ctx), on(ctx && (ctx->time_kind == kind || ctx->time_kind == sub)) {
     if (on) {
       (void)hipEventCreate(&e0);
       (void)hipEventCreate(&e1);
@@ -407,6 +408,7 @@ static int launch_attn(a2p_ctx* c, const AttnP& p0, int nseq, int kind, hipStrea
     const bool w8 = c->opt.ksplit_nw == 8 || (c->opt.ksplit_nw == 0 && ntiles > 8);
     const int qt = c->opt.ksplit_qt == 2 ? 2 : 1;
     p.nq = (p.Tq + 16 * qt - 1) / (16 * qt); p.nheads = c->H; p.nseq = nseq; p.xcd_remap = 0;
+    p.stat_max = c->nonfinite.p ? reinterpret_cast<int*>(c->nonfinite.p) + 1 : nullptr;   // the envelope check covers the small forwards too
     dim3 grid(p.nq * c->H * nseq);
     KernelTimer kt(c, kind);
 #define A2P_KS(DH_) \
@@ -610,7 +612,10 @@ extern "C" int a2p_ctx_create(const a2p_config* cfg, a2p_ctx** out) {
     A(c->kf_pack, (size_t)B * c->KFmax * c->KdPad * c->esz); A(c->kf_tok, (size_t)B * c->KFmax * d * 4);
   }
   A(c->slot_cond, B * 4); A(c->slot_unc, B * 4); A(c->slot_cfg, N * 4); A(c->nonfinite, 64);
-  if (rc == 0 && hipMemsetAsync(reinterpret_cast<int*>(c->nonfinite.p) + 1, 0x80, 4, nullptr) != hipSuccess) rc = A2P_ERR_HIP;   // logit maximum: "none yet" (0x80808080 < every ordered float)
+  // logit maximum: "none yet" (0x80808080 < every ordered float).  Synchronous: callers run on non-blocking streams, which do not
+  // order behind the null stream -- a first attention could otherwise atomicMax before the sentinel lands and lose its value
+  if (rc == 0 && (hipMemsetAsync(reinterpret_cast<int*>(c->nonfinite.p) + 1, 0x80, 4, nullptr) != hipSuccess ||
+                  hipStreamSynchronize(nullptr) != hipSuccess)) rc = A2P_ERR_HIP;
   if (getenv("A2P_CHAIN_CLK")) A(c->clk, 64 * 32 * 8 + 2 * 64 * 8);   // + phase stamps of the diagnostic build (-DA2P_STAMPS)
   if (rc == 0 && hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking) != hipSuccess) rc = A2P_ERR_HIP;
   for (int i = 0; i < 8 && rc == 0; ++i)

@@ -314,7 +314,8 @@ static int launch_chain(a2p_ctx* c, int mode, const ChainP& p, hipStream_t s) {
     }
   }
   const int grid = (p.M + 16 * mt - 1) / (16 * mt);
-  KernelTimer kt(c, A2P_KERNEL_CHAIN);
+  KernelTimer kt(c, A2P_KERNEL_CHAIN, mode == CHAIN_PRE ? A2P_KERNEL_CHAIN_PRE : mode == CHAIN_MID ? A2P_KERNEL_CHAIN_MID
+                                       : mode == CHAIN_POST ? A2P_KERNEL_CHAIN_POST : A2P_KERNEL_CHAIN_MIDPOST);
   // d = 512, more than one round of 48-row panels with a mostly empty last round: 64-row panels for the first n_tall
   // workgroups so that the forward fits one round less (chain_kernel_mix; B=32: 96 x 64 + 672 x 48 rows = 3 full rounds
   // instead of 3.125 -> 4).  A2P_CHAIN_NO_MIX=1 keeps the uniform launch for A/B runs.
@@ -472,7 +473,11 @@ static int decoder_layer_chain(a2p_ctx* c, int l, int N, int T, const CrossKV& k
   CHK(launch_cross_attention(c, N, T, kv, s));
   // body model: MID2 | keyframe attention | POST as ONE kernel (kernels_chain.h CHAIN_MIDPOST) when the keyframes fit one 32-key chunk
   // (T <= 960 frames at the reference's keyframe step of 30); A2P_NO_FUSED_KF=1 keeps the three launches (A/B, tests)
-  const bool fuse_kf = kv2 && d == 256 && kv2->S_main >= 1 && kv2->S_main <= 32 && kv2->S_tail == 0 && !c->opt.no_fused_kf && !fuse_final;
+  // The fused attention phase is written for 8 heads x 32 (the reference's pose configuration): wave w = head w, K / V^T fragments of
+  // 32-wide heads.  Any other head geometry at d = 256 (the reference's argparse default is --heads 4, i.e. head_dim 64) takes the
+  // three launches.  A 16-row tile of the panel may straddle TWO sequences (the kernel keeps both key sets), not three: T >= 16.
+  const bool fuse_kf = kv2 && d == 256 && c->H == 8 && c->DH == 32 && T >= 16 && kv2->S_main >= 1 && kv2->S_main <= 32 &&
+                       kv2->S_tail == 0 && !c->opt.no_fused_kf && !fuse_final;
   if (kv2 && !fuse_kf) {
     CHK(mid(CH_MID2, "multihead_attn", 1, "norm2a"));
     CHK(launch_cross_attention(c, N, T, *kv2, s));
@@ -834,7 +839,7 @@ static int forward_body(a2p_ctx* c, const float* x_in, const int64_t* t_orig, in
     tp.x = c->x.f(); tp.T = T; tp.d = d; tp.C = c->C; tp.nblk = (T + tail::TB - 1) / tail::TB;
     tp.w = reinterpret_cast<const h16_t*>(c->tail_w.p); tp.bias = c->tail_b.f(); tp.out = c->mo.f();
     for (int i = 0; i < tail::NLAYERS; ++i) tp.woff[i] = c->tail_woff[i];
-    KernelTimer kt(c, A2P_KERNEL_GEMM);
+    KernelTimer kt(c, A2P_KERNEL_GEMM, A2P_KERNEL_POSE_TAIL);
     A2P_LAUNCH(kt, pose_tail_kernel, N * tp.nblk, 512, s, tp);
     HIPCHK(hipGetLastError());
     *mo_seq_rows = T;

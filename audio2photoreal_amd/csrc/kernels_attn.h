@@ -128,8 +128,14 @@ __device__ __forceinline__ float attn_rowgroup_max(float v) {
 // NWV: waves per workgroup (each wave owns QT*16 = 32 queries); 4 in production.  NWV = 2 was tried for its even grid (T = 600: 10
 // query blocks per (sequence, head), B=8: 1280 workgroups = exactly 5 per CU instead of 2 or 3) and lost clearly -- cross attention
 // 97 vs 70 us: every K/V tile then feeds 64 instead of 128 queries and the tile DMA / LDS traffic per query doubles.
+// waves per SIMD the register allocation is held to: 3 for the 16-bit and the fp32 dh <= 64 kernels.  The fp32 dh = 128 kernel (the
+// lip regressor of the audio front end: once per clip, 4 heads; 67 KB of LDS per workgroup) asks for 1: at 2 it spills 59 registers,
+// and a request of 3 was silently dropped by hipcc (the code it compiled was the occupancy-1 code all along)
+template <typename T, int DH>
+constexpr int attn_min_waves() { return (sizeof(T) == 4 && DH == 128) ? 1 : 3; }
+
 template <typename T, int DH, int ABL = 0, int NWV = 4>
-__global__ __launch_bounds__(64 * NWV, 3) void attn_kernel(AttnP p) {
+__global__ __launch_bounds__(64 * NWV, (attn_min_waves<T, DH>())) void attn_kernel(AttnP p) {
   using P = Prec<T>;
   using L = AttnLds<T, DH>;
   constexpr int QT = 2, BQ = NWV * QT * 16, KV = 64, NTHR = 64 * NWV;
@@ -785,6 +791,17 @@ __global__ __launch_bounds__(64 * NW) void attn_ksplit_kernel(AttnP p) {
     for (int dv = 0; dv < DVT; ++dv) *reinterpret_cast<f32x4*>(&so[wid][qt][dv][lane][0]) = o[qt][dv];
   }
   __syncthreads();
+  if (p.stat_max && wid == 0) {   // a2p_attention_logit_max: largest merged row maximum of this workgroup's queries (as attn_kernel)
+    float m = -INFINITY;
+#pragma unroll
+    for (int qt = 0; qt < QT; ++qt)
+#pragma unroll
+      for (int w = 0; w < NW; ++w) m = fmaxf(m, sm[w][qt][l15]);
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+    const int mi = attn_ordered_int(m * 0.6931471805599453f);   // log2 domain -> natural units
+    if (lane == 0 && mi > __atomic_load_n(p.stat_max, __ATOMIC_RELAXED)) atomicMax(p.stat_max, mi);
+  }
   T* Ob = reinterpret_cast<T*>(p.O) + (int64_t)seq * p.o_seq_stride + head * DH;
   for (int pr = wid; pr < QT * DVT; pr += NW) {
     const int qt = pr / DVT, dv = pr % DVT;

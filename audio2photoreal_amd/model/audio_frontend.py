@@ -22,6 +22,7 @@ that sit on the conditioning path are REFUSED (`check_keys`, `a2p_frontend_set_w
 """
 from __future__ import annotations
 
+import ast
 import ctypes as C
 import dataclasses
 import math
@@ -80,7 +81,7 @@ class FrontendGeometry:
 
         def nlayers(a, k, d):
             v = get(a, k, None)
-            return d if v is None else len(eval(v) if isinstance(v, str) else v)
+            return d if v is None else len(ast.literal_eval(v) if isinstance(v, str) else v)   # checkpoint metadata: never eval()
         kw = {}
         if audio_args is not None:
             kw.update(a_group_norm=True, a_activation=get(audio_args, "activation", "relu"), a_log_compression=bool(get(audio_args, "log_compression", False)),

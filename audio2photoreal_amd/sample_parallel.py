@@ -11,6 +11,7 @@ or a per-sample seed list), so 1/2/4/8-GPU runs produce identical samples.
 """
 from __future__ import annotations
 
+import os
 from typing import Callable, Dict, List, Optional, Sequence, Tuple
 
 import torch
@@ -73,14 +74,42 @@ def derive_seed(base: int, *ids: int) -> int:
     return h & 0x7FFFFFFFFFFFFFFF
 
 
-def gather_blocks(local: torch.Tensor, sizes: Sequence[int], group=None) -> torch.Tensor:
-    """One all_gather of per-rank blocks of DIFFERENT lengths (`sizes[r]` rows on rank r, zero allowed): every rank pads its
-    block to the longest, the result is the concatenation of the true blocks in rank order.  Works for host tensors (gloo)
-    and device tensors (backend "nccl" = RCCL over xGMI); a rank without rows still takes part."""
+def gather_blocks(local: torch.Tensor, sizes: Sequence[int], group=None, mode: Optional[str] = None) -> torch.Tensor:
+    """The end-of-run exchange of per-rank blocks of DIFFERENT lengths (`sizes[r]` rows on rank r, zero allowed); the result is the
+    concatenation of the true blocks in rank order on every rank.  Works for host tensors (gloo) and device tensors (backend
+    "nccl" = RCCL over xGMI); a rank without rows still takes part.  Two transports (`mode`, default: env A2P_GATHER, else "ring"):
+
+      "ring"  ONE `all_gather` of blocks padded to the longest (RCCL's ring: N-1 hops of the padded block over one link at a time);
+      "p2p"   all pairs at once -- every rank posts its TRUE block to each peer and receives each peer's block straight into place
+              (`batch_isend_irecv` = one grouped ncclSend/ncclRecv: on xGMI's point-to-point mesh every transfer has its own
+              link, one hop, no padding).  The payload here is ~2 MB per rank and latency-bound, which is
+              the regime where N-1 serial ring hops cost more than N-1 parallel direct copies.
+
+    Both give identical bytes (tests/test_multiprocess_cpu.py)."""
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
         return local
-    world = dist.get_world_size(group)
-    assert len(sizes) == world and local.shape[0] == sizes[dist.get_rank(group)], (sizes, tuple(local.shape))
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    assert len(sizes) == world and local.shape[0] == sizes[rank], (sizes, tuple(local.shape))
+    mode = mode or os.environ.get("A2P_GATHER", "ring")
+    if mode == "p2p":
+        local = local.contiguous()
+        out = torch.empty((sum(sizes),) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+        offs = [sum(sizes[:r]) for r in range(world)]
+        out[offs[rank]: offs[rank] + sizes[rank]] = local
+        ops = []
+        for k in range(1, world):       # peer order staggered by rank: no two ranks start on the same destination
+            dst, src = (rank + k) % world, (rank - k) % world
+            gdst = dist.get_global_rank(group, dst) if group is not None else dst
+            gsrc = dist.get_global_rank(group, src) if group is not None else src
+            if sizes[rank] > 0:
+                ops.append(dist.P2POp(dist.isend, local, gdst, group))
+            if sizes[src] > 0:
+                ops.append(dist.P2POp(dist.irecv, out[offs[src]: offs[src] + sizes[src]], gsrc, group))
+        if ops:
+            for w in dist.batch_isend_irecv(ops):
+                w.wait()
+        return out
+    assert mode == "ring", f"A2P_GATHER / mode must be 'ring' or 'p2p', not {mode!r}"
     maxn = max(max(sizes), 1)
     pad = torch.zeros((maxn,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
     pad[: local.shape[0]] = local
@@ -96,6 +125,19 @@ def gather_samples(local: torch.Tensor, total: int, group=None) -> torch.Tensor:
     world = dist.get_world_size(group)
     sizes = [hi - lo for lo, hi in (shard_bounds(total, world, r) for r in range(world))]
     return gather_blocks(local, sizes, group)
+
+
+def agree_on_failure(failed: bool, group=None, device=None) -> List[int]:
+    """Control plane, 1 int per rank: the ranks that report `failed` (empty list = nobody).  One small all_gather in front of the
+    data-path collective so that an exception on one rank becomes an exception on all of them instead of a collective timeout."""
+    world = dist.get_world_size(group)
+    backend = dist.get_backend(group)
+    dev = device if (backend == "nccl" and device is not None and device.type == "cuda") else \
+        (torch.device("cuda", torch.cuda.current_device()) if backend == "nccl" else torch.device("cpu"))
+    flag = torch.tensor([1 if failed else 0], dtype=torch.int32, device=dev)
+    flags = [torch.zeros_like(flag) for _ in range(world)]
+    dist.all_gather(flags, flag, group=group)
+    return [r for r in range(world) if int(flags[r].item()) != 0]
 
 
 def _set_batch_hint(model, total: int):
@@ -128,15 +170,30 @@ def sample_parallel(sample_fn: Callable, model, shape: Sequence[int], model_kwar
             local_step = lambda n: step_noise(n)[lo:hi].contiguous()
         else:
             local_step = [s[lo:hi].contiguous() for s in step_noise]
-    if hi > lo:
-        extra = {} if local_step is None else {"step_noise": local_step}
-        hinted = _set_batch_hint(model, total if world > 1 else 0)   # every shard takes the kernel family of the unsharded run
-        try:
-            local = sample_fn(model, local_shape, noise=local_noise, model_kwargs=kwargs, **extra, **kw)
-        finally:
-            for m in hinted:
-                m.global_batch_hint = 0
-    else:
-        ref = noise if noise is not None else torch.zeros(1)
-        local = torch.zeros((0,) + tuple(shape[1:]), dtype=torch.float32, device=ref.device)
+    # A failure on one rank (A2PError from the non-finite check, a bad input, ...) must not leave the others waiting in the final
+    # collective until it times out: every rank reports into one MAX-reduced flag first and all of them raise together.
+    err: Optional[BaseException] = None
+    local = None
+    try:
+        if hi > lo:
+            extra = {} if local_step is None else {"step_noise": local_step}
+            hinted = _set_batch_hint(model, total if world > 1 else 0)   # every shard takes the kernel family of the unsharded run
+            try:
+                local = sample_fn(model, local_shape, noise=local_noise, model_kwargs=kwargs, **extra, **kw)
+            finally:
+                for m in hinted:
+                    m.global_batch_hint = 0
+        else:
+            ref = noise if noise is not None else torch.zeros(1)
+            local = torch.zeros((0,) + tuple(shape[1:]), dtype=torch.float32, device=ref.device)
+    except Exception as e:   # noqa: BLE001 -- re-raised below, on every rank
+        if world == 1:
+            raise
+        err = e
+    if world > 1:
+        failed = agree_on_failure(err is not None, group, device=None if local is None else local.device)
+        if err is not None:
+            raise err
+        if failed:
+            raise RuntimeError(f"sample_parallel: rank(s) {failed} failed inside the sampling loop; rank {rank} stops before the gather")
     return gather_samples(local, total, group)

@@ -61,6 +61,27 @@ def algorithmic_flops(spec, T, S, nseq):
             "attn_cross": nseq * L * (ca_attn + ca_attn2)}
 
 
+def box_record(dev):
+    """What distinguishes one leased MI355X from another (the two-group box spread): device properties the HIP
+    runtime reports, plus rocm-smi's clocks / power cap / partition modes when the tool is there.  Every bench line carries it, so the
+    boxes of a round can be correlated with their numbers afterwards (profiles/r05_boxes.md)."""
+    import subprocess
+    pr = torch.cuda.get_device_properties(dev)
+    rec = {"name": pr.name, "gcn_arch": getattr(pr, "gcnArchName", None), "cus": pr.multi_processor_count,
+           "hbm_gb": round(pr.total_memory / 2 ** 30, 1), "l2_mb": round(getattr(pr, "L2_cache_size", 0) / 2 ** 20, 1),
+           "clock_mhz": getattr(pr, "clock_rate", 0) // 1000 or None, "mem_clock_mhz": getattr(pr, "memory_clock_rate", 0) // 1000 or None}
+    for key, cmd in (("smi", ["rocm-smi", "--showclocks", "--showpower", "--showmaxpower", "--showperflevel", "--showcomputepartition",
+                              "--showmemorypartition", "--json"]),):
+        try:
+            out = subprocess.run(cmd, capture_output=True, text=True, timeout=20).stdout
+            j = json.loads(out[out.index("{"):])
+            card = j.get("card0", j)
+            rec[key] = {k: v for k, v in card.items() if any(w in k.lower() for w in ("sclk", "mclk", "fclk", "socclk", "power", "partition", "performance"))}
+        except Exception as e:   # noqa: BLE001 -- a report field
+            rec[key] = f"unavailable ({type(e).__name__})"
+    return rec
+
+
 def rel_errors(got, want):
     got, want = got.double().cpu(), want.double().cpu()
     return {"rel_l2": float((got - want).norm() / want.norm()), "max_norm": float((got - want).abs().max() / want.abs().max())}
@@ -172,6 +193,37 @@ def kernel_breakdown(case, ksteps):
         flops["chain"], flops["gemm"] = dec_gemm, flops["io_gemm"]
     else:
         flops["gemm"] = dec_gemm + flops["io_gemm"]
+    # finer classes of the chain launches (PRE / MID / POST / MIDPOST) and the body model's fused output tail, timed the same way
+    # (include/a2p_hip.h A2P_KERNEL_CHAIN_*; a launch is timed when its class OR its sub-class is selected)
+    sub = {}
+    if "chain" in kernels or case.spec.is_pose:
+        d, ff, T, ns, L = case.spec.latent_dim, case.spec.ff_size, case.T, 2 * case.B, case.spec.num_layers
+        pre_fl, q_fl, o_fl, ffn_fl = 2.0 * T * d * 3 * d, 2.0 * T * d * d, 2.0 * T * d * d, 4.0 * T * d * ff
+        # algorithmic FLOPs per LAUNCH over all `ns` sequences: PRE = [Q|K|V]; MID = out_proj + Q; POST = out_proj + FFN (+ the next
+        # layer's PRE work for all but the last layer: averaged); MIDPOST (body) = MID2 + keyframe attention + POST
+        sub_fl = {"chain_pre": ns * pre_fl, "chain_mid": ns * (o_fl + q_fl), "chain_post": ns * (o_fl + ffn_fl + pre_fl * (L - 1) / L),
+                  "chain_midpost": ns * (2 * o_fl + q_fl + ffn_fl + pre_fl * (L - 1) / L + 4.0 * T * 20 * d), "pose_tail": None}
+        for name, kind in (("chain_pre", _lib.KERNEL_CHAIN_PRE), ("chain_mid", _lib.KERNEL_CHAIN_MID), ("chain_post", _lib.KERNEL_CHAIN_POST),
+                           ("chain_midpost", _lib.KERNEL_CHAIN_MIDPOST), ("pose_tail", _lib.KERNEL_POSE_TAIL)):
+            if name == "pose_tail" and not case.spec.is_pose:
+                continue
+            if name != "pose_tail" and "chain" not in kernels:
+                continue
+            _lib.check(lib.a2p_kernel_timing(case.model._ctx, kind, 1), "a2p_kernel_timing")
+            with torch.no_grad():
+                case.run_steps(ksteps)
+            ms, n = C.c_double(), C.c_int64()
+            _lib.check(lib.a2p_kernel_time_ms(case.model._ctx, C.byref(ms), C.byref(n)), "a2p_kernel_time_ms")
+            _lib.check(lib.a2p_kernel_timing(case.model._ctx, kind, 0), "a2p_kernel_timing")
+            if n.value == 0:
+                continue
+            ent = {"ms_per_step": round(ms.value / ksteps, 4), "launches_per_step": n.value // ksteps,
+                   "avg_launch_us": round(1e3 * ms.value / n.value, 2)}
+            if sub_fl[name]:
+                ent["algorithmic_gflop_per_launch"] = round(sub_fl[name] / 1e9, 3)
+                ent["tflops"] = round(sub_fl[name] / (ent["avg_launch_us"] * 1e-6) / 1e12, 2)
+                ent["mfma_frac"] = round(ent["tflops"] / (PEAK_F32_TFLOPS if case.precision == "fp32" else PEAK_BF16_TFLOPS), 4)
+            sub[name] = ent
     for name, ent in kernels.items():
         if name in flops:
             ent["algorithmic_gflop_per_step"] = round(flops[name] / 1e9, 2)
@@ -179,7 +231,9 @@ def kernel_breakdown(case, ksteps):
     # each class is timed in its own pass (dispatch-packet events serialise the launches of that class against the side stream);
     # the sum of the classes against the untimed step says how much that inflates
     kernels["_sum_of_classes_ms_per_step"] = round(sum(v["ms_per_step"] for v in kernels.values()), 4)
-    dom = max((k for k in kernels if k in flops), key=lambda k: kernels[k]["ms_per_step"])
+    if sub:
+        kernels["_sub_classes"] = sub     # (not part of the sum: every entry is a subset of "chain" / "gemm")
+    dom = max((k for k in kernels if k in flops and not k.startswith("_")), key=lambda k: kernels[k]["ms_per_step"])
     peak = PEAK_F32_TFLOPS if case.precision == "fp32" else PEAK_BF16_TFLOPS
     roofline = {"kernel": dom, "bound": "mfma", "achieved": kernels[dom]["tflops"], "peak": peak, "unit": "TFLOP/s",
                 "frac": round(kernels[dom]["tflops"] / peak, 4), "traffic": None,
@@ -256,11 +310,28 @@ def cpu_and_parity(case, dev, want_parity=True, chain_steps=1000, chain_batch=2)
             cur = out["sample"]
         want["tail"] = out
         cdt = time.perf_counter() - t0
-    cpu = {"value": round(len(t_list) / cdt / case.B, 5),
-           "unit": f"denoise steps/sec at batch {case.B} (1 sample timed, scaled by 1/{case.B})",
+    # cpu_baseline: the SAME step the GPU is timed on -- the whole batch (B samples, both guidance passes) through the oracle, 2 DDPM
+    # steps at the head of the chain after one warm-up step.  (Rounds 1-4 timed ONE sample and divided by B: CPU matmul efficiency
+    # at B is not B x the B=1 efficiency; the 1-sample figure stays as `one_sample_scaled` for continuity.)
+    Bc = case.B
+    xb, ceb, scb = case.x.cpu(), case.cond.cpu(), case.y["scale"].cpu()
+    fnb = lambda xx, ts: den.forward_cfg(xx, ts, ceb, scb)
+    nzb = [torch.randn(xb.shape, generator=g) for _ in range(3)]
+    n_b = 2
+    with torch.no_grad():
+        cur = smp.p_sample(fnb, xb, torch.full((Bc,), 999), nzb[0])["sample"]     # warm-up at the real batch
+        t0 = time.perf_counter()
+        for k in range(n_b):
+            cur = smp.p_sample(fnb, cur, torch.full((Bc,), 998 - k), nzb[1 + k])["sample"]
+        bdt = time.perf_counter() - t0
+    cpu = {"value": round(n_b / bdt, 5),
+           "unit": f"denoise steps/sec at batch {Bc} (the whole batch timed: {n_b} steps)",
            "cores": threads, "host_cpus": ncpu, "kind": "port",
            "sample": f"oracle (torch CPU fp32 restatement of the reference algorithm, conditioning path recomputed every forward like "
-                     f"the reference's decoder-only path), 1 sample x {len(t_list)} DDPM steps, T={T}, S={S0 + 2}: {cdt:.2f} s"}
+                     f"the reference's decoder-only path), {Bc} samples x {n_b} DDPM steps (t = 998, 997) after one warm-up step, "
+                     f"T={T}, S={S0 + 2}: {bdt:.2f} s",
+           "one_sample_scaled": {"value": round(len(t_list) / cdt / case.B, 5),
+                                 "what": f"rounds 1-4's figure: 1 sample x {len(t_list)} steps ({cdt:.2f} s), divided by {case.B}"}}
     # The reference tree is not on the GPU box: the build container timed the reference ITSELF beside this port on one sample of the
     # same workload (tests/tools/cpu_reference_vs_port.py --variant-a); the ratios travel with the repo.  Two variants of BASELINE.md
     # section 3: decoder-only (audio features fed in: what this port computes) and variant (A), what a user of the reference gets --
@@ -576,6 +647,9 @@ def run_pipeline_job(a, dev, rank, world, dist, coll_dev):
                 "value": round(dt / (S * N), 5), "unit": "s/sample", "higher_is_better": False, "n_gpus": world, "steps": 1, "warmup": 1,
                 "scaling": "strong", "dtype": a.precision, "data": "synthetic", "total_s": round(dt, 4), "repeats_s": [round(t, 4) for t in dts],
                 "gather_ms": gather_ms, "vs_baseline": None,
+                "collectives": ({"backend": dist.get_backend(), "ranks": dist.get_world_size(), "gather": os.environ.get("A2P_GATHER", "ring"),
+                                 "gather_rows": int(allx.shape[0])} if world > 1 else None),
+                "box": box_record(dev),
                 "config": {"workload": f"{S} subjects (weight sets) x {N} samples, T={T}, {a.respacing or 'ddim100'} body + face, native audio front end",
                            "placement": {str(r): [[s, lo, hi] for (s, lo, hi) in plan[r]] for r in range(world)},
                            "parallelism": f"subject/sample-parallel x{world}: no communication before the final gather"},
@@ -774,6 +848,10 @@ def main():
             "decoder_tflops": round((total / B) * case.step_flops() * a.steps / dt / 1e12, 2),
             "decoder_mfma_frac": round(case.step_flops() * a.steps / dt / 1e12 / peak, 4),
             "prepare_s": round(case.prepare_s, 4), "gather_ms": gather_ms,
+            "collectives": ({"backend": dist.get_backend(), "ranks": dist.get_world_size(), "gather": os.environ.get("A2P_GATHER", "ring"),
+                             "gather_rows": int(allx.shape[0]), "gather_bytes_per_rank": int(mine.numel() * mine.element_size())}
+                            if world > 1 else None),
+            "box": box_record(dev),
             "roofline": roofline, "kernels": kernels, "cpu_baseline": cpu, "parity": parity, "legs": legs or None,
         }
         print(json.dumps(line), flush=True)

@@ -183,6 +183,12 @@ int a2p_attention(a2p_ctx* ctx, const float* q, const float* k, const float* v, 
 #define A2P_KERNEL_ATTN_CROSS 2
 #define A2P_KERNEL_LNROPE 3
 #define A2P_KERNEL_CHAIN 4 /* fused row-panel chain kernels (projections + FiLM + LayerNorm + FFN), bf16 mode */
+/* finer classes of the launches above (a launch is timed when its class OR its sub-class is selected) */
+#define A2P_KERNEL_CHAIN_PRE 5     /* norm1 -> rotary -> [Q|K], V^T (first layer only; later layers: tail of POST) */
+#define A2P_KERNEL_CHAIN_MID 6     /* out_proj -> FiLM + residual -> LayerNorm -> rotary -> Q */
+#define A2P_KERNEL_CHAIN_POST 7    /* out_proj -> FiLM -> norm3 -> FFN -> FiLM [-> next layer's PRE work | final_layer] */
+#define A2P_KERNEL_CHAIN_MIDPOST 8 /* body model: MID2 | keyframe attention | POST in one launch */
+#define A2P_KERNEL_POSE_TAIL 9     /* body model: final_layer + 6 dilated convs + final_conv (a sub-class of A2P_KERNEL_GEMM) */
 int a2p_kernel_timing(a2p_ctx* ctx, int32_t kind, int32_t enable);
 int a2p_kernel_time_ms(a2p_ctx* ctx, double* total_ms, int64_t* launches);
 

@@ -73,7 +73,8 @@ def test_gemm_kernel(dev, precision):
                                 _lib.current_stream()), "a2p_gemm")
         err = rel_l2(out.cpu(), ref)
         record(f"gemm/{precision}/{M}x{N}x{K}", rel_l2=err)
-        assert err < {"fp32": 2e-6, "bf16": 1e-2, "fp16": 1.5e-3}[precision], (M, N, K, err)
+        # fp16 gate = min(1e-3, 2x measured): 2.0e-4..2.3e-4 on MI355X (profiles/r04_parity_tests.json)
+        assert err < {"fp32": 2e-6, "bf16": 1e-2, "fp16": 4.5e-4}[precision], (M, N, K, err)
 
 
 @pytest.mark.parametrize("precision", ["fp32", "bf16", "fp16"])
@@ -96,7 +97,8 @@ def test_attention_kernel(dev, precision, fmt):
                                      _lib.ptr(out), N, Tq, S, _lib.current_stream()), "a2p_attention")
         err = rel_l2(out.cpu(), ref)
         record(f"attn/{fmt}/{precision}/{N}x{Tq}x{S}", rel_l2=err)
-        assert err < {"fp32": 5e-6, "bf16": 2e-2, "fp16": 3e-3}[precision], (N, Tq, S, err)
+        # fp16 gate = min(1e-3, 2x measured): 4.3e-4..5.3e-4 measured -> the 1e-3 bar itself
+        assert err < {"fp32": 5e-6, "bf16": 2e-2, "fp16": 1e-3}[precision], (N, Tq, S, err)
 
 
 @pytest.mark.parametrize("precision", ["fp32", "bf16", "fp16"])
@@ -115,7 +117,7 @@ def test_decoder_layer_vs_reference_golden(dev, golden, precision, fmt):
     err = rel_l2(x.cpu(), golden[f"{fmt}/layer0"])
     record(f"layer0/{fmt}/{precision}", rel_l2=err)
     # measured on MI355X (profiles/r02_parity_tests.json): fp32 4e-7, bf16 1.6e-3, fp16 2e-4
-    assert err < {"fp32": 1e-4, "bf16": 3.2e-3, "fp16": 6e-4}[precision]
+    assert err < {"fp32": 1e-4, "bf16": 3.2e-3, "fp16": 4e-4}[precision]
 
 
 # ----------------------------------------------------------------------------- denoiser
@@ -138,7 +140,8 @@ def test_forward_vs_reference_golden(dev, golden, precision, fmt):
     record(f"fwd240/{fmt}/{precision}", cond=errs[0], uncond=errs[1], cfg=errs[2])
     # measured (profiles/r02_parity_tests.json): fp32 ~1e-6; bf16 cond/uncond 3.4-5.1e-3, guided 4.4e-3 (face) / 8.5e-3 (pose);
     # fp16 8x below bf16.  Gates = 2x the measured values (round 1 asserted 5e-2 / 0.25 here)
-    tol, tol_cfg = {"fp32": (2e-4, 2e-4), "bf16": (1.1e-2, 1.8e-2), "fp16": (1.5e-3, 2.5e-3)}[precision]
+    # round 5: fp16 = min(1e-3, 2x measured) -- measured 2.1e-4..4.7e-4 (profiles/r04_parity_tests.json fwd240/*/fp16)
+    tol, tol_cfg = {"fp32": (2e-4, 2e-4), "bf16": (1.1e-2, 1.8e-2), "fp16": (9.5e-4, 9.5e-4)}[precision]
     assert all(e < tol for e in errs[:2]) and errs[2] < tol_cfg, errs
     if spec.is_pose:   # the reference zeroes masked keyframes in y, in place (model/diffusion.py:320)
         assert float(y["keyframes"][1, 3:].abs().max()) == 0.0

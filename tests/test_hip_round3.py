@@ -156,8 +156,9 @@ def test_key_split_attention_matches_softmax_and_the_query_split_kernel(dev, fmt
         e_ref, e_pair = rel(outs["split"], ref), rel(outs["split"], outs["query"])
         record(f"attn_ksplit/{fmt}/{precision}/{N}x{Tq}x{S}", rel_l2=e_ref, vs_query_split=e_pair)
         assert torch.isfinite(outs["split"]).all()
-        assert e_ref < {"bf16": 2e-2, "fp16": 3e-3}[precision], (N, Tq, S, e_ref)
-        assert e_pair < {"bf16": 6e-3, "fp16": 8e-4}[precision], (N, Tq, S, e_pair)
+        # fp16 gates = min(1e-3, 2x measured): vs the fp64 reference 4.4e-4..5.0e-4, vs the query-split kernel 0.4e-5..1.05e-4
+        assert e_ref < {"bf16": 2e-2, "fp16": 1e-3}[precision], (N, Tq, S, e_ref)
+        assert e_pair < {"bf16": 6e-3, "fp16": 2.2e-4}[precision], (N, Tq, S, e_pair)
     model.release()
 
 

@@ -354,3 +354,39 @@ def test_fused_keyframe_attention_equals_the_three_launches(dev, B, T, precision
     record(f"fused_keyframe_attention/{precision}/B{B}_T{T}", pair=pair, fused_vs_oracle=e_f, three_launches_vs_oracle=e_3, logit_max=peak)
     k = 1.0 if precision == "fp16" else 8.0
     assert pair < k * 4e-4 and e_f < k * 1e-3 and e_f < 1.15 * e_3 + k * 5e-5, (pair, e_f, e_3)   # measured: pair 1.3e-4 .. 1.9e-4 (fp16)
+
+
+# ----------------------------------------------------------------------------- round 5: head geometries the fused kernel is NOT written for
+@pytest.mark.parametrize("heads,B,T", [(4, 2, 600), (4, 3, 208), (8, 8, 12)])
+def test_pose_head_geometries_outside_the_fused_keyframe_kernel(dev, heads, B, T, monkeypatch):
+    """CHAIN_MIDPOST hard-codes 8 heads x 32 and handles a 16-row tile that straddles at most TWO sequences.  A pose model with
+    --heads 4 (head_dim 64 at d = 256: FiLMTransformer's default num_heads and the reference's argparse default) and clips shorter
+    than 16 frames (a tile can cover three sequences) must therefore take the three launches -- checked against the oracle, and the
+    default path must equal A2P_NO_FUSED_KF=1 bit for bit (it IS the three launches)."""
+    from oracle import a2p_oracle as O
+    spec = pose_spec(num_heads=heads)
+    inp = synthetic_inputs(spec, B, T, SEED)
+    sd = synthetic_state_dict(spec, SEED)
+    y = {"cond_embed": inp["cond_embed"].to(dev), "scale": torch.full((B,), 2.0, device=dev), "keyframes": inp["keyframes"].to(dev),
+         "mask": inp["mask"].to(dev)}
+    t = torch.tensor(([901, 417, 33] * 3)[:B], device=dev)
+    model, _ = create_model_and_diffusion(default_args("pose", heads=heads), "test", precision="fp16", max_batch=B)
+    load_model(model, sd)
+    cfg = ClassifierFreeSampleModel(model.to(dev).eval())
+    if 2 * B * T < 960:
+        monkeypatch.setenv("A2P_CHAIN_ROWS", "1")
+    outs = {}
+    for name in ("default", "three_launches"):
+        if name == "default":
+            monkeypatch.delenv("A2P_NO_FUSED_KF", raising=False)
+        else:
+            monkeypatch.setenv("A2P_NO_FUSED_KF", "1")
+        outs[name] = cfg(inp["x_T"].to(dev), t, y).cpu()
+    monkeypatch.delenv("A2P_CHAIN_ROWS", raising=False)
+    model.release()
+    assert torch.equal(outs["default"], outs["three_launches"]), "a geometry outside the fused kernel's contract took the fused kernel"
+    den = O.OracleDenoiser(sd, "pose", spec.num_layers, heads, torch.float32)
+    want = den.forward_cfg(inp["x_T"][:1], t[:1].cpu(), inp["cond_embed"][:1], torch.full((1,), 2.0), inp["keyframes"][:1], inp["mask"][:1])
+    err = float((outs["default"][:1] - want).norm() / want.norm())
+    record(f"pose_heads{heads}/fp16/B{B}_T{T}", vs_oracle=err)
+    assert err < 1e-3, err

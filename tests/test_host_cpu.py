@@ -469,3 +469,74 @@ def test_native_front_end_refuses_on_path_tensors_it_does_not_implement():
     # a model WITHOUT the native front end is fed y["cond_embed"] by the caller: front-end tensors are none of its business
     plain, _ = create_model_and_diffusion(default_args("face", layers=1), "test")
     load_model(plain, {**synthetic_state_dict(spec, 10), "audio_model.feature_extractor.conv_layers.0.2.weight": torch.ones(512)})
+
+
+# ----------------------------------------------------------------------------- round 5: all-pairs gather, failures reach every rank
+def _p2p_worker(rank, world, port, out_dir):
+    import torch.distributed as dist
+    from audio2photoreal_amd.sample_parallel import gather_blocks
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    sizes = [3, 0, 2][:world] if world == 3 else [2, 3]
+    mine = torch.full((sizes[rank], 2, 1, 4), float(rank)) + torch.arange(sizes[rank]).view(-1, 1, 1, 1) * 0.25
+    ring = gather_blocks(mine, sizes, mode="ring")
+    p2p = gather_blocks(mine, sizes, mode="p2p")
+    os.environ["A2P_GATHER"] = "p2p"                          # the switch a deployment uses
+    env = gather_blocks(mine, sizes)
+    torch.save((ring, p2p, env), os.path.join(out_dir, f"p{rank}.pt"))
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_all_pairs_gather_equals_the_ring_all_gather(tmp_path, world):
+    """the end-of-run exchange as all-pairs point-to-point copies (one hop per block on xGMI's mesh) instead of
+    the ring all_gather -- same bytes on every rank, including a rank that holds nothing."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    mp.spawn(_p2p_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    outs = [torch.load(tmp_path / f"p{r}.pt") for r in range(world)]
+    for ring, p2p, env in outs:
+        assert torch.equal(ring, outs[0][0]) and torch.equal(p2p, ring) and torch.equal(env, ring)
+    assert outs[0][0].shape[0] == 5
+
+
+def _failing_loop(model, shape, noise=None, model_kwargs=None, **kw):
+    if float(model_kwargs["y"]["scale"][0]) > 1.5:            # only the rank that holds the last samples
+        raise ValueError("non-finite values in the sampling loop (stand-in for A2PError)")
+    return noise.clone()
+
+
+def _fail_worker(rank, world, port, out_dir):
+    import datetime
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=60))
+    total = 4
+    shape = (total, 4, 1, 6)
+    y = {"cond_embed": torch.zeros(total, 3, 2), "scale": torch.tensor([1.0, 1.0, 2.0, 2.0])}
+    t0 = __import__("time").perf_counter()
+    try:
+        sample_parallel(_failing_loop, None, shape, {"y": y}, noise=torch.zeros(shape))
+        msg = "no exception"
+    except Exception as e:   # noqa: BLE001
+        msg = f"{type(e).__name__}: {e}"
+    with open(os.path.join(out_dir, f"f{rank}.txt"), "w") as f:
+        f.write(f"{__import__('time').perf_counter() - t0:.2f}\n{msg}")
+    dist.destroy_process_group()
+
+
+def test_a_failure_on_one_rank_raises_on_every_rank_before_the_gather(tmp_path):
+    """check_finite() raising on one rank inside the loop left the others in the final collective until it timed out.
+    Now every rank learns about it (one 4-byte all_gather in front of the data-path collective) and raises at once."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    mp.spawn(_fail_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    r0 = (tmp_path / "f0.txt").read_text().splitlines()
+    r1 = (tmp_path / "f1.txt").read_text().splitlines()
+    assert float(r0[0]) < 30 and float(r1[0]) < 30, "a rank sat in the collective until the timeout"
+    assert r1[1].startswith("ValueError") and "non-finite" in r1[1]              # the failing rank re-raises its own error
+    assert r0[1].startswith("RuntimeError") and "rank(s) [1] failed" in r0[1]    # the healthy rank names it
