@@ -34,7 +34,7 @@ EXPORTS = (
     "a2p_ctx_create", "a2p_ctx_destroy", "a2p_last_error", "a2p_version", "a2p_set_weight", "a2p_finalize_weights",
     "a2p_prepare_cond", "a2p_denoise_forward", "a2p_sample_step", "a2p_p_mean_variance", "a2p_ddim_update",
     "a2p_p_sample_update", "a2p_q_sample", "a2p_eps_from_xstart", "a2p_plms_update", "a2p_ddim_reverse_update", "a2p_decoder_layer_forward", "a2p_gemm", "a2p_attention",
-    "a2p_kernel_timing", "a2p_kernel_time_ms", "a2p_debug_read", "a2p_reload_env", "a2p_set_batch_hint", "a2p_check_finite", "a2p_attention_logit_max",
+    "a2p_kernel_timing", "a2p_kernel_time_ms", "a2p_debug_read", "a2p_reload_env", "a2p_set_batch_hint", "a2p_check_finite", "a2p_attention_logit_max", "a2p_precision_verdict",
     "a2p_guide_create", "a2p_guide_destroy", "a2p_guide_set_weight", "a2p_guide_finalize", "a2p_guide_prepare",
     "a2p_guide_forward", "a2p_guide_generate", "a2p_guide_debug_read", "a2p_vq_decode",
     "a2p_frontend_create", "a2p_frontend_destroy", "a2p_frontend_set_weight", "a2p_frontend_finalize",
@@ -122,6 +122,7 @@ def load(half: bool = False) -> C.CDLL:
         "a2p_set_batch_hint": [vp, i32],
         "a2p_check_finite": [vp, vp],
         "a2p_attention_logit_max": [vp, C.POINTER(C.c_float), vp],
+        "a2p_precision_verdict": [vp, C.POINTER(C.c_float), C.POINTER(i32), vp],
         "a2p_guide_create": [C.POINTER(A2PGuideConfig), C.POINTER(vp)],
         "a2p_guide_destroy": [vp],
         "a2p_guide_set_weight": [vp, C.c_char_p, vp, i64, vp],

@@ -1012,6 +1012,14 @@ extern "C" int a2p_attention_logit_max(a2p_ctx* c, float* max_logit_host, void* 
   return 0;
 }
 
+extern "C" int a2p_precision_verdict(a2p_ctx* c, float* max_logit_host, int32_t* outside, void* stream) {
+  ARG(c && max_logit_host && outside, "null argument");
+  CHK(a2p_attention_logit_max(c, max_logit_host, stream));
+  // fp32 contexts are exact at any magnitude; the 16-bit contexts are validated up to A2P_LOGIT_ENVELOPE_16BIT (a2p_hip.h)
+  *outside = (c->bf16 && *max_logit_host > A2P_LOGIT_ENVELOPE_16BIT) ? 1 : 0;
+  return 0;
+}
+
 extern "C" int a2p_check_finite(a2p_ctx* c, void* stream) {
   ARG(c, "null ctx");
   hipStream_t s = (hipStream_t)stream;

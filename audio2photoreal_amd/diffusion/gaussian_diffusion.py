@@ -71,6 +71,19 @@ class LossType(enum.Enum):
         return self in (LossType.KL, LossType.RESCALED_KL)
 
 
+def _rng_snapshot(device):
+    """Generator states a repeated step / call must start from (host + the sampling device's default generator)."""
+    dev = th.device(device) if device is not None else None
+    cuda = th.cuda.get_rng_state(dev) if (dev is not None and dev.type == "cuda" and th.cuda.is_available()) else None
+    return th.get_rng_state(), cuda
+
+
+def _rng_restore(device, snap):
+    th.set_rng_state(snap[0])
+    if snap[1] is not None:
+        th.cuda.set_rng_state(snap[1], th.device(device))
+
+
 def _out_of_scope(name):
     def fn(self, *a, **k):
         raise NotImplementedError(f"GaussianDiffusion.{name} is outside the accelerated sampling path (training / gradient guidance, SURVEY.md §2)")
@@ -276,8 +289,25 @@ class GaussianDiffusion:
         return {"sample": sample, "pred_xstart": out["pred_xstart"]}
 
     # ------------------------------------------------------------------ loops
+    def _run_call(self, run, model, device):
+        """One sampling call of a non-progressive loop, repeated ONCE -- under the same random draws -- when the model moved itself
+        from a 16-bit mode to fp32 at the end of it (FiLMTransformer.check_finite: attention logits outside the validated range)."""
+        if device is None:
+            try:
+                device = next(model.parameters()).device
+            except (StopIteration, AttributeError):
+                device = None
+        rng = _rng_snapshot(device)
+        self._call_escalated = False
+        out = run()
+        if self._call_escalated:
+            self._call_escalated = False
+            _rng_restore(device, rng)
+            out = run()
+        return out
+
     def _loop(self, step_fn, model, shape, noise, model_kwargs, device, progress, skip_timesteps, init_image,
-              randomize_class, step_noise, **step_kwargs):
+              randomize_class, step_noise, _stateless_step=True, **step_kwargs):
         if device is None:
             device = next(model.parameters()).device
         assert isinstance(shape, (tuple, list))
@@ -294,12 +324,22 @@ class GaussianDiffusion:
         if progress:
             from tqdm.auto import tqdm
             indices = tqdm(indices)
+        chk = getattr(model, "a2p_check_finite", None) or getattr(model, "check_finite", None)
+        deferred = getattr(self, "defer_finite_check", False)
+        # 16-bit modes: is this checkpoint / clip inside the range they were validated on?  Asked right after the FIRST step (one
+        # stream synchronisation per sampling call) so that a model that has to escalate to fp32 (FiLMTransformer.check_finite) does so
+        # before the other N-1 steps are spent, and again at the end of the call (the logits grow as x_t sharpens).
+        early = callable(chk) and not deferred and _stateless_step and bool(getattr(model, "a2p_wants_early_check", lambda: False)())
         for n, i in enumerate(indices):
             nz = None
             if step_noise is not None:
                 nz = step_noise(n) if callable(step_noise) else step_noise[n]
+            rng = _rng_snapshot(device) if (early and n == 0) else None
             with th.no_grad():
                 out = step_fn(model, img, steps[i], model_kwargs=model_kwargs, noise=nz, **step_kwargs)
+                if rng is not None and chk() == "escalated":      # repeat the step on the fp32 context, same noise
+                    _rng_restore(device, rng)
+                    out = step_fn(model, img, steps[i], model_kwargs=model_kwargs, noise=nz, **step_kwargs)
             yield out
             img = out["sample"]
         # Once per sampling call: did any denoiser evaluation produce inf / nan?  (The 16-bit throughput modes can overflow where
@@ -308,9 +348,11 @@ class GaussianDiffusion:
         # The check reads a device flag, i.e. it WAITS for the stream.  A caller that keeps several streams busy from one host thread
         # (bench.py --pipeline: the face loop on one stream, guide -> body on another) sets `defer_finite_check = True` on the diffusion
         # object and calls `model.check_finite()` itself once everything is enqueued; the flag keeps accumulating until it is read.
-        chk = getattr(model, "a2p_check_finite", None) or getattr(model, "check_finite", None)
-        if callable(chk) and not getattr(self, "defer_finite_check", False):
-            chk()
+        # If the model escalated at the END of the call, every step above ran on 16-bit operands outside their range: the
+        # non-progressive loops (p_sample_loop / ddim_sample_loop / plms_sample_loop) repeat the call; a consumer of the progressive
+        # generators has already been handed those steps -- it gets the warning, and fp32 from its next call on.
+        if callable(chk) and not deferred and chk() == "escalated":
+            self._call_escalated = True
 
     def p_sample_loop_progressive(self, model, shape, noise=None, clip_denoised=True, denoised_fn=None, cond_fn=None,
                                   model_kwargs=None, device=None, progress=False, skip_timesteps=0, init_image=None,
@@ -325,18 +367,18 @@ class GaussianDiffusion:
                       device=None, progress=False, skip_timesteps=0, init_image=None, randomize_class=False,
                       cond_fn_with_grad=False, dump_steps=None, const_noise=False, step_noise=None):
         """reference :525-590: returns the last "sample" (or the dumped steps)."""
-        final, dump = None, []
-        for i, sample in enumerate(self.p_sample_loop_progressive(
-                model, shape, noise=noise, clip_denoised=clip_denoised, denoised_fn=denoised_fn, cond_fn=cond_fn,
-                model_kwargs=model_kwargs, device=device, progress=progress, skip_timesteps=skip_timesteps,
-                init_image=init_image, randomize_class=randomize_class, cond_fn_with_grad=cond_fn_with_grad,
-                const_noise=const_noise, step_noise=step_noise)):
-            if dump_steps is not None and i in dump_steps:
-                dump.append(deepcopy(sample["sample"]))
-            final = sample
-        if dump_steps is not None:
-            return dump
-        return final["sample"]
+        def run():
+            final, dump = None, []
+            for i, sample in enumerate(self.p_sample_loop_progressive(
+                    model, shape, noise=noise, clip_denoised=clip_denoised, denoised_fn=denoised_fn, cond_fn=cond_fn,
+                    model_kwargs=model_kwargs, device=device, progress=progress, skip_timesteps=skip_timesteps,
+                    init_image=init_image, randomize_class=randomize_class, cond_fn_with_grad=cond_fn_with_grad,
+                    const_noise=const_noise, step_noise=step_noise)):
+                if dump_steps is not None and i in dump_steps:
+                    dump.append(deepcopy(sample["sample"]))
+                final = sample
+            return dump if dump_steps is not None else final["sample"]
+        return self._run_call(run, model, device)
 
     def ddim_sample_loop_progressive(self, model, shape, noise=None, clip_denoised=True, denoised_fn=None, cond_fn=None,
                                      model_kwargs=None, device=None, progress=False, eta=0.0, skip_timesteps=0,
@@ -355,14 +397,16 @@ class GaussianDiffusion:
             raise NotImplementedError()
         if const_noise is True:
             raise NotImplementedError()
-        final = None
-        for sample in self.ddim_sample_loop_progressive(
-                model, shape, noise=noise, clip_denoised=clip_denoised, denoised_fn=denoised_fn, cond_fn=cond_fn,
-                model_kwargs=model_kwargs, device=device, progress=progress, eta=eta, skip_timesteps=skip_timesteps,
-                init_image=init_image, randomize_class=randomize_class, cond_fn_with_grad=cond_fn_with_grad,
-                step_noise=step_noise):
-            final = sample
-        return final["pred_xstart"]
+        def run():
+            final = None
+            for sample in self.ddim_sample_loop_progressive(
+                    model, shape, noise=noise, clip_denoised=clip_denoised, denoised_fn=denoised_fn, cond_fn=cond_fn,
+                    model_kwargs=model_kwargs, device=device, progress=progress, eta=eta, skip_timesteps=skip_timesteps,
+                    init_image=init_image, randomize_class=randomize_class, cond_fn_with_grad=cond_fn_with_grad,
+                    step_noise=step_noise):
+                final = sample
+            return final["pred_xstart"]
+        return self._run_call(run, model, device)
 
     # ------------------------------------------------------------------ DDIM reverse ODE, PLMS
     def _elementwise(self, fn_name, x, *args):
@@ -430,20 +474,22 @@ class GaussianDiffusion:
             return state["old_out"]
 
         yield from self._loop(step, model, shape, noise, model_kwargs, device, progress, skip_timesteps, init_image,
-                              randomize_class, None, clip_denoised=clip_denoised, denoised_fn=denoised_fn, cond_fn=cond_fn,
-                              cond_fn_with_grad=cond_fn_with_grad, order=order)
+                              randomize_class, None, _stateless_step=False, clip_denoised=clip_denoised, denoised_fn=denoised_fn,
+                              cond_fn=cond_fn, cond_fn_with_grad=cond_fn_with_grad, order=order)
 
     def plms_sample_loop(self, model, shape, noise=None, clip_denoised=True, denoised_fn=None, cond_fn=None, model_kwargs=None,
                          device=None, progress=False, skip_timesteps=0, init_image=None, randomize_class=False,
                          cond_fn_with_grad=False, order=2):
         """reference :1043-1081: returns the last "sample"."""
-        final = None
-        for sample in self.plms_sample_loop_progressive(
-                model, shape, noise=noise, clip_denoised=clip_denoised, denoised_fn=denoised_fn, cond_fn=cond_fn,
-                model_kwargs=model_kwargs, device=device, progress=progress, skip_timesteps=skip_timesteps,
-                init_image=init_image, randomize_class=randomize_class, cond_fn_with_grad=cond_fn_with_grad, order=order):
-            final = sample
-        return final["sample"]
+        def run():
+            final = None
+            for sample in self.plms_sample_loop_progressive(
+                    model, shape, noise=noise, clip_denoised=clip_denoised, denoised_fn=denoised_fn, cond_fn=cond_fn,
+                    model_kwargs=model_kwargs, device=device, progress=progress, skip_timesteps=skip_timesteps,
+                    init_image=init_image, randomize_class=randomize_class, cond_fn_with_grad=cond_fn_with_grad, order=order):
+                final = sample
+            return final["sample"]
+        return self._run_call(run, model, device)
 
     # ------------------------------------------------------------------ out of scope (SURVEY.md §2 row 1)
     condition_mean = _out_of_scope("condition_mean")

@@ -49,7 +49,11 @@ class ClassifierFreeSampleModel(nn.Module):
 
     def a2p_check_finite(self):
         """Raise A2PError when a denoiser evaluation since the last check produced inf / nan (FiLMTransformer.check_finite)."""
-        self.model.check_finite()
+        return self.model.check_finite()      # "escalated" when the model just moved itself to fp32 (the loops re-run the call)
+
+    def a2p_wants_early_check(self) -> bool:
+        """True when the wrapped denoiser runs on 16-bit operands and may still escalate: the loops then ask after the first step."""
+        return self.model.wants_early_check()
 
     def a2p_sample_step(self, sampler, x, t_idx, timestep_map, tables, y, noise, eta, clip_denoised):
         """p_mean_variance + ddim_sample / p_sample in one library call; SpacedDiffusion's loops use it when present."""

@@ -114,7 +114,7 @@ class FiLMTransformer(nn.Module):
                  num_heads: int = 4, dropout: float = 0.1, cond_feature_dim: int = 4800,
                  activation: Callable = F.gelu, use_rotary: bool = True, cond_mode: str = "audio",
                  split_type: str = "train", device: str = "cuda", audio_frontend=None, audio_resample: str = "sinc", audio_geometry=None,
-                 precision: str = "fp32", max_batch: int = 32, **kwargs) -> None:
+                 precision: str = "fp32", max_batch: int = 32, auto_escalate: bool = True, **kwargs) -> None:
         super().__init__()
         if not use_rotary:
             raise NotImplementedError("--not_rotary (absolute PE) is not on the accelerated path")
@@ -134,6 +134,10 @@ class FiLMTransformer(nn.Module):
         self.precision = precision
         self.max_batch = max_batch
         self.last_logit_max = float("-inf")           # largest attention logit of the denoiser evaluations covered by the last check_finite()
+        # 16-bit modes outside their validated range (a2p_precision_verdict): True = move this model to precision="fp32" for good the
+        # first time that happens and tell the sampling loop to repeat the call; False = rounds 1-4's behaviour (warn, return the result)
+        self.auto_escalate = auto_escalate
+        self.escalated_from: Optional[str] = None     # the precision this model was constructed with, once it has escalated
         self.global_batch_hint = 0                   # set by sample_parallel: size of the unsharded batch (a2p_set_batch_hint)
         d = latent_dim
         self.latent_dim, self.ff_size, self.num_layers, self.num_heads = d, ff_size, num_layers, num_heads
@@ -394,28 +398,48 @@ class FiLMTransformer(nn.Module):
         """Both guidance passes batched as 2B sequences + the lerp (model/cfg_sampler.py:30-33)."""
         return self._run(x, times, y, _lib.PASS_CFG, y["scale"])
 
-    def check_finite(self) -> None:
+    def wants_early_check(self) -> bool:
+        return self.precision != "fp32" and self.auto_escalate
+
+    a2p_wants_early_check = wants_early_check     # (a bare FiLMTransformer handed to the loops)
+
+    def check_finite(self) -> Optional[str]:
         """Raise A2PError if any denoiser evaluation since the last check produced inf / nan outputs (include/a2p_hip.h
         a2p_check_finite: a device flag OR-ed by the fused step tail; reading it synchronises the stream).  The sampling loops of
-        GaussianDiffusion call this once per sampling call; direct `forward` users call it when they want the answer.
-        In the 16-bit modes it also reads the largest attention logit the denoiser saw (a2p_attention_logit_max ->
-        `self.last_logit_max`) and warns with A2PPrecisionWarning when it leaves the range those modes were validated on."""
+        GaussianDiffusion call this after the first step and at the end of every sampling call; direct `forward` users call it when they
+        want the answer.
+
+        In the 16-bit modes it also asks the library whether the attention logits stayed inside the range those modes were validated
+        on (a2p_precision_verdict; `self.last_logit_max`).  Outside it the 16-bit operand rounding costs more than the 1e-3 parity bar
+        (2.6e-3 at a row maximum of 27, profiles/r04_trained_like_budget.json), so the model ESCALATES: it re-creates its context in
+        precision="fp32" (exact fp32 MFMA: 1e-6..5e-6 on the same scenarios; ~9x the step time, bench.py legs.fp32), stays there
+        for the rest of its life (`escalated_from` keeps the original mode), warns once (A2PPrecisionWarning) and returns
+        "escalated" -- the loops then repeat the step / the call, so the samples a caller gets are inside the bar.
+        `auto_escalate=False` restores the warn-and-return behaviour of rounds 1-4."""
         if self._ctx is None:
-            return
+            return None
         dev = torch.device(self._ctx_key[0])
         lib = self._ctx_lib or self._lib()
         with torch.cuda.device(dev):
             stream = _lib.current_stream(dev)
-            peak = C.c_float(float("-inf"))
-            _lib.check(lib.a2p_attention_logit_max(self._ctx, C.byref(peak), stream), "a2p_attention_logit_max")
+            peak, outside = C.c_float(float("-inf")), C.c_int32(0)
+            _lib.check(lib.a2p_precision_verdict(self._ctx, C.byref(peak), C.byref(outside), stream), "a2p_precision_verdict")
             self.last_logit_max = float(peak.value)
             _lib.check(lib.a2p_check_finite(self._ctx, stream), "a2p_check_finite")
-        if self.precision != "fp32" and self.last_logit_max > _lib.LOGIT_ENVELOPE_FP16:
-            import warnings
-            warnings.warn(f"attention logits reach {self.last_logit_max:.1f} (row maximum of q.k/sqrt(d_head)): beyond "
-                          f"{_lib.LOGIT_ENVELOPE_FP16:g} the 16-bit operand rounding of precision=\"{self.precision}\" costs more than the 1e-3 "
-                          "parity bar on the sampler's return value (measured 2.8e-3 at 29, divergent at 54: "
-                          "profiles/r04_trained_like_budget.json); precision=\"fp32\" is exact there", _lib.A2PPrecisionWarning, stacklevel=2)
+        if not outside.value:
+            return None
+        import warnings
+        head = (f"attention logits reach {self.last_logit_max:.1f} (row maximum of q.k/sqrt(d_head)): beyond {_lib.LOGIT_ENVELOPE_FP16:g} the "
+                f"16-bit operand rounding of precision=\"{self.precision}\" costs more than the 1e-3 parity bar on the sampler's return "
+                "value (measured 2.8e-3 at 29, divergent at 54: profiles/r04_trained_like_budget.json)")
+        if not self.auto_escalate:
+            warnings.warn(head + "; precision=\"fp32\" is exact there", _lib.A2PPrecisionWarning, stacklevel=2)
+            return None
+        self.escalated_from = self.escalated_from or self.precision
+        self.set_precision("fp32")              # releases the 16-bit context; weights and conditioning are rebuilt on the next call
+        warnings.warn(head + "; this model now runs in precision=\"fp32\" (exact; sticky for its lifetime) and the sampling call is repeated",
+                      _lib.A2PPrecisionWarning, stacklevel=2)
+        return "escalated"
 
     def sample_step(self, sampler: int, x, t_idx, timestep_map, tables, y, noise, eta: float, clip_denoised: bool):
         """Fused p_mean_variance + ddim_sample / p_sample for one step (include/a2p_hip.h a2p_sample_step)."""

@@ -218,6 +218,13 @@ int a2p_check_finite(a2p_ctx* ctx, void* stream);
  * 2.4e-3 at ~29; bfloat16 is 8x worse throughout.  The Python model mirror warns (A2PPrecisionWarning) above 20 in the 16-bit
  * modes; precision="fp32" is the answer there.  No reference counterpart (its path is fp32). */
 int a2p_attention_logit_max(a2p_ctx* ctx, float* max_logit_host, void* stream);
+/* The same read-and-reset, plus the library's own verdict: *outside = 1 when the context computes on 16-bit operands AND the maximum
+ * exceeds A2P_LOGIT_ENVELOPE_16BIT -- the caller should re-create the context with precision A2P_PREC_F32 (exact at any magnitude:
+ * 1e-6..5e-6 on the same scenarios) and repeat the sampling call.  The Python mirror does exactly that, once and for good per model
+ * (FiLMTransformer.check_finite: "escalation", sticky; GaussianDiffusion's loops check after the first step and at the end of a call
+ * and re-run a call that ended outside).  fp32 contexts always report 0. */
+#define A2P_LOGIT_ENVELOPE_16BIT 20.0f
+int a2p_precision_verdict(a2p_ctx* ctx, float* max_logit_host, int32_t* outside, void* stream);
 
 /* ---- run-time switches: the A2P_* environment variables that steer a forward (INTEGRATION.md "Environment switches") are read
  * when the context is created; a host that changes one afterwards calls this (the Python mirror does, model/diffusion.py). */

@@ -390,3 +390,54 @@ def test_pose_head_geometries_outside_the_fused_keyframe_kernel(dev, heads, B, T
     err = float((outs["default"][:1] - want).norm() / want.norm())
     record(f"pose_heads{heads}/fp16/B{B}_T{T}", vs_oracle=err)
     assert err < 1e-3, err
+
+
+# ----------------------------------------------------------------------------- round 5: outside the envelope the 16-bit modes escalate
+@pytest.mark.parametrize("name,kw", [("qk_x3", {"qk_gain": 3.0}), ("qk_x4", {"qk_gain": 4.0})])
+def test_16bit_sampling_call_outside_the_envelope_escalates_to_fp32(dev, name, kw):
+    """q/k rows x3 / x4: attention row maxima of ~29 / ~50, where IEEE-half operands cost 2.6e-3 / diverge.  A sampling call in
+    precision="fp16" must still RETURN a result inside the 1e-3 bar: the library reports the logit maximum after the first step
+    (a2p_precision_verdict), the model re-creates its context in fp32 (sticky), the step is repeated and the loop goes on; the
+    oracle's ddim5 loop is the reference.  `auto_escalate=False` keeps rounds 1-4's warn-and-return behaviour (recorded: its error).
+    The price is recorded too: the same call on the escalated model vs the 16-bit call."""
+    import time
+    import warnings
+    from oracle import a2p_oracle as O
+    spec = face_spec()
+    B, T = 1, 240
+    inp = synthetic_inputs(spec, B, T, SEED)
+    scale = torch.full((B,), 10.0)
+    sd = trained_like_state_dict(spec, SEED, **kw)
+    g = float(_oracle_forward(sd, "face", spec, inp, torch.tensor([700]), scale).std())
+    for k in ("final_layer.weight", "final_layer.bias"):
+        sd[k] = sd[k] / g
+    den = O.OracleDenoiser(sd, "face", spec.num_layers, spec.num_heads)
+    fn = lambda x, ts: den.forward_cfg(x, ts, inp["cond_embed"], scale)
+    with torch.no_grad():
+        _, want = O.OracleSampler("ddim5").ddim_sample_loop(fn, inp["x_T"])
+    y = {"cond_embed": inp["cond_embed"].to(dev), "scale": scale.to(dev)}
+    shape = (B, spec.nfeats, 1, T)
+    res = {}
+    for mode, auto in (("escalating", True), ("warn_only", False)):
+        model, diffusion = create_model_and_diffusion(default_args("face", timestep_respacing="ddim5"), "test", precision="fp16", max_batch=B,
+                                                      auto_escalate=auto)
+        load_model(model, sd)
+        cfg = ClassifierFreeSampleModel(model.to(dev).eval())
+        with warnings.catch_warnings(record=True) as w:
+            warnings.simplefilter("always")
+            got = diffusion.ddim_sample_loop(cfg, shape, clip_denoised=False, model_kwargs={"y": y}, noise=inp["x_T"].to(dev)).cpu()
+        warned = sum(issubclass(x.category, _lib.A2PPrecisionWarning) for x in w)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        again = diffusion.ddim_sample_loop(cfg, shape, clip_denoised=False, model_kwargs={"y": y}, noise=inp["x_T"].to(dev)).cpu()
+        torch.cuda.synchronize()
+        res[mode] = {"rel_l2": float((got - want).norm() / want.norm()), "second_call_rel_l2": float((again - want).norm() / want.norm()),
+                     "warnings": warned, "precision_after": model.precision, "escalated_from": model.escalated_from,
+                     "second_call_ms": round(1e3 * (time.perf_counter() - t0), 2), "logit_max": model.last_logit_max}
+        model.release()
+    record(f"escalation/face/{name}", **res)
+    e, wo = res["escalating"], res["warn_only"]
+    assert e["precision_after"] == "fp32" and e["escalated_from"] == "fp16" and e["warnings"] == 1, e
+    assert e["rel_l2"] < 1e-3 and e["second_call_rel_l2"] < 1e-3, e        # the call that escalated AND the sticky fp32 calls after it
+    assert wo["precision_after"] == "fp16" and wo["escalated_from"] is None and wo["warnings"] >= 1, wo
+    assert wo["rel_l2"] > e["rel_l2"], (wo, e)

@@ -540,3 +540,69 @@ def test_a_failure_on_one_rank_raises_on_every_rank_before_the_gather(tmp_path):
     assert float(r0[0]) < 30 and float(r1[0]) < 30, "a rank sat in the collective until the timeout"
     assert r1[1].startswith("ValueError") and "non-finite" in r1[1]              # the failing rank re-raises its own error
     assert r0[1].startswith("RuntimeError") and "rank(s) [1] failed" in r0[1]    # the healthy rank names it
+
+
+# ----------------------------------------------------------------------------- round 5: escalation control flow of the loops (no GPU)
+class _EscalatingModel(torch.nn.Module):
+    """Stands in for a 16-bit FiLMTransformer: `verdicts` is what its successive check_finite() calls return."""
+    def __init__(self, verdicts):
+        super().__init__()
+        self.w = torch.nn.Parameter(torch.zeros(1))
+        self.verdicts, self.checks, self.mode = list(verdicts), 0, "fp16"
+
+    def a2p_wants_early_check(self):
+        return self.mode != "fp32"
+
+    def a2p_check_finite(self):
+        self.checks += 1
+        v = self.verdicts.pop(0) if self.verdicts else None
+        if v == "escalated":
+            self.mode = "fp32"
+        return v
+
+
+def _toy_step(calls):
+    def step(model, img, t, model_kwargs=None, noise=None, **kw):
+        calls.append((model.mode, int(t[0])))
+        nz = torch.randn_like(img) if noise is None else noise          # draws from the default generator like p_sample
+        bias = 0.0 if model.mode == "fp32" else 1e-2                     # "16-bit" steps are visibly different
+        out = 0.5 * img + 0.1 * nz + bias
+        return {"sample": out, "pred_xstart": out}
+    return step
+
+
+def test_loops_repeat_the_first_step_or_the_call_when_the_model_escalates():
+    """A model that leaves the 16-bit envelope escalates to fp32 (FiLMTransformer.check_finite returns "escalated"): right after the
+    first step -> that step is repeated, the other steps run once; at the end of the call -> the non-progressive loop repeats the whole
+    call.  Either way the returned sample equals a pure-fp32 run under the same seed (same noise draws)."""
+    d = create_gaussian_diffusion(default_args("face", timestep_respacing="ddim5"))
+    shape = (2, 3, 1, 4)
+
+    def run(model, calls):
+        torch.manual_seed(77)
+        def once():
+            final = None
+            for s in d._loop(_toy_step(calls), model, shape, None, {}, torch.device("cpu"), False, 0, None, False, None):
+                final = s
+            return final["sample"]
+        return d._run_call(once, model, torch.device("cpu"))
+
+    ref_model = _EscalatingModel([])
+    ref_model.mode = "fp32"
+    c0 = []
+    want = run(ref_model, c0)
+    assert len(c0) == 5 and ref_model.checks == 1                     # fp32: no early check, one end-of-call check
+
+    early, c1 = _EscalatingModel(["escalated"]), []
+    got = run(early, c1)
+    assert torch.equal(got, want)
+    assert [m for m, _ in c1] == ["fp16"] + ["fp32"] * 5 and c1[0][1] == c1[1][1]   # step 0 twice, then 4 more
+
+    late, c2 = _EscalatingModel([None, "escalated"]), []
+    got = run(late, c2)
+    assert torch.equal(got, want)
+    assert [m for m, _ in c2] == ["fp16"] * 5 + ["fp32"] * 5                          # the whole call repeated on fp32
+
+    inside, c3 = _EscalatingModel([None, None]), []
+    got = run(inside, c3)
+    assert len(c3) == 5 and inside.checks == 2 and not torch.equal(got, want)         # stays 16-bit: one pass
