@@ -25,6 +25,7 @@
 
 #include "../../include/a2p_hip.h"
 #include "kernels_attn.h"
+#include "kernels_attn2.h"
 #include "kernels_chain.h"
 #include "kernels_gemm.h"
 #include "kernels_misc.h"
@@ -159,6 +160,8 @@ struct A2POpts {
   int ksplit_nw = 0;        // A2P_KSPLIT_NW=4|8: waves of the key-split attention
   int ksplit_qt = 0;        // A2P_KSPLIT_QT=1|2: 16-query tiles per wave of the key-split attention
   int force_ksplit = 0;     // A2P_ATTN_KSPLIT=1: every 16-bit attention launch takes the key-split kernel (tests)
+  int attn2 = 0;            // A2P_ATTN2=1: the query-split 16-bit attention launches take attn2_kernel (kernels_attn2.h: one 8-wave workgroup per CU,
+                            // 48 + 32 queries per SIMD, unit-level software pipeline); 0: attn_kernel
   int no_fused_kf = 0;      // A2P_NO_FUSED_KF=1: body model: MID2 | keyframe attention | POST as three launches instead of one (A/B, tests)
   int graph = 0;            // A2P_GRAPH=1: non-chain forwards replay a captured graph instead of stream launches (measured: same GPU
                             // time per step -- the launches are not host-bound -- at a tenth of the host time; off by default)
@@ -177,7 +180,7 @@ static void load_opts(A2POpts& o) {
   o.side_early_join = flag("A2P_SIDE_EARLY_JOIN"); o.no_shared_half = flag("A2P_NO_SHARED_HALF");
   o.graph = flag("A2P_GRAPH");
   o.no_ksplit = flag("A2P_NO_KSPLIT"); o.force_ksplit = flag("A2P_ATTN_KSPLIT"); o.ksplit_nw = num("A2P_KSPLIT_NW", 0); o.ksplit_qt = num("A2P_KSPLIT_QT", 0);
-  o.no_fused_kf = flag("A2P_NO_FUSED_KF");
+  o.no_fused_kf = flag("A2P_NO_FUSED_KF"); o.attn2 = num("A2P_ATTN2", 0);
   o.no_small = flag("A2P_NO_SMALL"); o.chain_rows = num("A2P_CHAIN_ROWS", 1100);
 }
 
@@ -432,6 +435,15 @@ static int launch_attn(a2p_ctx* c, const AttnP& p0, int nseq, int kind, hipStrea
   p.nq = (p.Tq + 32 * nwv - 1) / (32 * nwv); p.nheads = c->H; p.nseq = nseq;
   static const bool no_remap = getenv("A2P_ATTN_NO_REMAP") != nullptr;   // A/B switch
   p.xcd_remap = (!no_remap && (c->H * nseq) % 8 == 0) ? 1 : 0;
+  if (c->bf16 && c->opt.attn2 && (c->DH == 64 || c->DH == 32) && p.ldvt % 8 == 0) {   // round 5: balanced 8-wave pipeline kernel
+    p.nq = (p.Tq + 319) / 320;
+    dim3 grid2(p.nq * c->H * nseq);
+    KernelTimer kt2(c, kind);
+    if (c->DH == 64) A2P_LAUNCH(kt2, (attn2_kernel<64, 3, 2>), grid2, 512, s, p);
+    else A2P_LAUNCH(kt2, (attn2_kernel<32, 3, 2>), grid2, 512, s, p);
+    HIPCHK(hipGetLastError());
+    return 0;
+  }
   dim3 grid(p.nq * c->H * nseq);
   KernelTimer kt(c, kind);
   if (c->DH == 128) {  // lip regressor of the audio front end (4 heads x 128), fp32 only

@@ -395,11 +395,14 @@ def test_pose_head_geometries_outside_the_fused_keyframe_kernel(dev, heads, B, T
 # ----------------------------------------------------------------------------- round 5: outside the envelope the 16-bit modes escalate
 @pytest.mark.parametrize("name,kw", [("qk_x3", {"qk_gain": 3.0}), ("qk_x4", {"qk_gain": 4.0})])
 def test_16bit_sampling_call_outside_the_envelope_escalates_to_fp32(dev, name, kw):
-    """q/k rows x3 / x4: attention row maxima of ~29 / ~50, where IEEE-half operands cost 2.6e-3 / diverge.  A sampling call in
-    precision="fp16" must still RETURN a result inside the 1e-3 bar: the library reports the logit maximum after the first step
-    (a2p_precision_verdict), the model re-creates its context in fp32 (sticky), the step is repeated and the loop goes on; the
-    oracle's ddim5 loop is the reference.  `auto_escalate=False` keeps rounds 1-4's warn-and-return behaviour (recorded: its error).
-    The price is recorded too: the same call on the escalated model vs the 16-bit call."""
+    """q/k rows x3 / x4: attention row maxima of ~30 / ~50, where IEEE-half operands cost 2.6e-3 / diverge.  A sampling call in
+    precision="fp16" must still RETURN what the fp32 path returns: the library reports the logit maximum after the first step
+    (a2p_precision_verdict), the model re-creates its context in fp32 (sticky), the step is repeated and the loop goes on.
+    Reference: the oracle's ddim5 loop in FLOAT64.  The fp32 oracle's own distance from it is the scenario's conditioning in fp32
+    arithmetic: ~1e-6 at x3, but x4 (softmax rows that are one-hot to 2^-70) is chaotic over five steps -- two CORRECT fp32
+    implementations (torch CPU and the fp32 MFMA kernels) land 0.3 apart there (first GPU run of this test), so the gate is
+    max(1e-3, 4x that distance) and the x4 case proves the control flow + the single guided forward (<= 1e-3, below), not the loop.
+    `auto_escalate=False` keeps rounds 1-4's warn-and-return behaviour (recorded: its error).  The price is recorded too."""
     import time
     import warnings
     from oracle import a2p_oracle as O
@@ -411,10 +414,17 @@ def test_16bit_sampling_call_outside_the_envelope_escalates_to_fp32(dev, name, k
     g = float(_oracle_forward(sd, "face", spec, inp, torch.tensor([700]), scale).std())
     for k in ("final_layer.weight", "final_layer.bias"):
         sd[k] = sd[k] / g
-    den = O.OracleDenoiser(sd, "face", spec.num_layers, spec.num_heads)
-    fn = lambda x, ts: den.forward_cfg(x, ts, inp["cond_embed"], scale)
-    with torch.no_grad():
-        _, want = O.OracleSampler("ddim5").ddim_sample_loop(fn, inp["x_T"])
+    refs = {}
+    for dt in (torch.float64, torch.float32):
+        den = O.OracleDenoiser(sd, "face", spec.num_layers, spec.num_heads, dt)
+        fn = lambda x, ts: den.forward_cfg(x, ts, inp["cond_embed"], scale)
+        with torch.no_grad():
+            _, xs = O.OracleSampler("ddim5").ddim_sample_loop(fn, inp["x_T"].to(dt))
+            fwd = den.forward_cfg(inp["x_T"].to(dt), torch.tensor([700]), inp["cond_embed"], scale)
+        refs[dt] = (xs.double(), fwd.double())
+    want, want_fwd = refs[torch.float64]
+    cond = float((refs[torch.float32][0] - want).norm() / want.norm())          # what fp32 arithmetic itself can promise here
+    gate = max(1e-3, 4.0 * cond)
     y = {"cond_embed": inp["cond_embed"].to(dev), "scale": scale.to(dev)}
     shape = (B, spec.nfeats, 1, T)
     res = {}
@@ -425,19 +435,81 @@ def test_16bit_sampling_call_outside_the_envelope_escalates_to_fp32(dev, name, k
         cfg = ClassifierFreeSampleModel(model.to(dev).eval())
         with warnings.catch_warnings(record=True) as w:
             warnings.simplefilter("always")
-            got = diffusion.ddim_sample_loop(cfg, shape, clip_denoised=False, model_kwargs={"y": y}, noise=inp["x_T"].to(dev)).cpu()
+            got = diffusion.ddim_sample_loop(cfg, shape, clip_denoised=False, model_kwargs={"y": y}, noise=inp["x_T"].to(dev)).cpu().double()
         warned = sum(issubclass(x.category, _lib.A2PPrecisionWarning) for x in w)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        again = diffusion.ddim_sample_loop(cfg, shape, clip_denoised=False, model_kwargs={"y": y}, noise=inp["x_T"].to(dev)).cpu()
+        again = diffusion.ddim_sample_loop(cfg, shape, clip_denoised=False, model_kwargs={"y": y}, noise=inp["x_T"].to(dev)).cpu().double()
         torch.cuda.synchronize()
+        ms = round(1e3 * (time.perf_counter() - t0), 2)
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            fwd = cfg(inp["x_T"].to(dev), torch.tensor([700], device=dev), y).cpu().double()       # one guided forward on whatever the model is now
         res[mode] = {"rel_l2": float((got - want).norm() / want.norm()), "second_call_rel_l2": float((again - want).norm() / want.norm()),
+                     "forward_rel_l2": float((fwd - want_fwd).norm() / want_fwd.norm()),
                      "warnings": warned, "precision_after": model.precision, "escalated_from": model.escalated_from,
-                     "second_call_ms": round(1e3 * (time.perf_counter() - t0), 2), "logit_max": model.last_logit_max}
+                     "second_call_ms": ms, "logit_max": model.last_logit_max}
         model.release()
-    record(f"escalation/face/{name}", **res)
+    record(f"escalation/face/{name}", fp32_oracle_vs_fp64_oracle=cond, gate=gate, **res)
     e, wo = res["escalating"], res["warn_only"]
     assert e["precision_after"] == "fp32" and e["escalated_from"] == "fp16" and e["warnings"] == 1, e
-    assert e["rel_l2"] < 1e-3 and e["second_call_rel_l2"] < 1e-3, e        # the call that escalated AND the sticky fp32 calls after it
+    assert e["rel_l2"] < gate and e["second_call_rel_l2"] < gate, (e, cond)   # the call that escalated AND the sticky fp32 calls after it
+    assert e["forward_rel_l2"] < 1e-3, e                                        # a single forward is well conditioned even at x4
     assert wo["precision_after"] == "fp16" and wo["escalated_from"] is None and wo["warnings"] >= 1, wo
-    assert wo["rel_l2"] > e["rel_l2"], (wo, e)
+    assert wo["forward_rel_l2"] > 1e-3 and wo["rel_l2"] > e["rel_l2"], (wo, e)   # the 16-bit forward IS outside the bar here
+    if name == "qk_x3":
+        assert cond < 1e-4 and gate == 1e-3, cond
+
+
+# ----------------------------------------------------------------------------- round 5: the 8-wave anti-phase attention kernel (opt-in experiment)
+@pytest.mark.parametrize("precision", ["fp16", "bf16"])
+@pytest.mark.parametrize("fmt", ["face", "pose"])
+def test_attn2_kernel_is_bit_identical_to_attn_kernel(dev, fmt, precision, monkeypatch):
+    """csrc/kernels_attn2.h (A2P_ATTN2=1): one 8-wave workgroup per CU, 48 + 32 queries per SIMD, the two waves of a SIMD alternating
+    between a matrix segment (PV + next tile's QK^T) and a vector segment (softmax) in anti-phase, 8-slot K/V ring behind counted
+    vmcnt waits.  Same arithmetic per (query, key tile) as attn_kernel, so the outputs must be IDENTICAL -- through a2p_attention
+    (one tile, ragged tiles, many tiles, a spiked key) and through a whole guided forward (cached K/V slots, the time-token tail
+    patched into the last tile, the shared unconditional slot)."""
+    from audio2photoreal_amd.spec import face_spec as fs, pose_spec as ps
+    spec = fs() if fmt == "face" else ps()
+    model, _ = create_model_and_diffusion(default_args(fmt), "test", precision=precision, max_batch=2)
+    load_model(model, synthetic_state_dict(spec, SEED))
+    model = model.to(dev).eval()
+    model._ensure_ctx(dev, 2)
+    lib = model._lib()
+    d = spec.latent_dim
+    g = torch.Generator().manual_seed(7)
+
+    def both(fn):
+        outs = []
+        for val in (None, "1"):
+            if val is None:
+                monkeypatch.delenv("A2P_ATTN2", raising=False)
+            else:
+                monkeypatch.setenv("A2P_ATTN2", val)
+            _lib.check(lib.a2p_reload_env(model._ctx), "a2p_reload_env")
+            outs.append(fn())
+        monkeypatch.delenv("A2P_ATTN2", raising=False)
+        _lib.check(lib.a2p_reload_env(model._ctx), "a2p_reload_env")
+        return outs
+    for (N, Tq, S) in [(2, 100, 77), (1, 600, 800), (3, 33, 20), (2, 321, 640), (1, 150, 150)]:
+        q, k, v = (torch.randn(N, L, d, generator=g) for L in (Tq, S, S))
+        k[0, S // 3] *= 6.0
+        qd, kd, vd = q.to(dev), k.to(dev), v.to(dev)
+
+        def run():
+            out = torch.empty(N, Tq, d, device=dev)
+            _lib.check(lib.a2p_attention(model._ctx, _lib.ptr(qd), _lib.ptr(kd), _lib.ptr(vd), _lib.ptr(out), N, Tq, S, _lib.current_stream()), "a2p_attention")
+            return out.cpu()
+        a, b = both(run)
+        assert torch.isfinite(b).all() and torch.equal(a, b), (N, Tq, S, float((a - b).abs().max()))
+    B, T = 2, 600
+    inp = synthetic_inputs(spec, B, T, SEED)
+    y = {"cond_embed": inp["cond_embed"].to(dev), "scale": torch.full((B,), 10.0 if fmt == "face" else 2.0, device=dev)}
+    if spec.is_pose:
+        y["keyframes"], y["mask"] = inp["keyframes"].to(dev), inp["mask"].to(dev)
+    cfg = ClassifierFreeSampleModel(model)
+    t = torch.tensor([901, 33], device=dev)
+    a, b = both(lambda: cfg(inp["x_T"].to(dev), t, y).cpu())
+    model.release()
+    assert torch.isfinite(b).all() and torch.equal(a, b), float((a - b).abs().max())
