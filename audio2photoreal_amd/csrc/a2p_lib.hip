@@ -27,6 +27,7 @@
 #include "kernels_attn.h"
 #include "kernels_attn2.h"
 #include "kernels_chain.h"
+#include "kernels_chain4.h"
 #include "kernels_gemm.h"
 #include "kernels_misc.h"
 #include "kernels_small.h"
@@ -160,6 +161,8 @@ struct A2POpts {
   int ksplit_nw = 0;        // A2P_KSPLIT_NW=4|8: waves of the key-split attention
   int ksplit_qt = 0;        // A2P_KSPLIT_QT=1|2: 16-query tiles per wave of the key-split attention
   int force_ksplit = 0;     // A2P_ATTN_KSPLIT=1: every 16-bit attention launch takes the key-split kernel (tests)
+  int chain_v = 0;          // A2P_CHAIN_V=4: tall chain kernels (kernels_chain4.h) wherever their contract holds; A2P_CHAIN_V=1: never; 0: the
+                            // library's rule (launch_chain: forwards of >= 16 sequences of the face model)
   int attn2 = 0;            // A2P_ATTN2=1: the query-split 16-bit attention launches take attn2_kernel (kernels_attn2.h: one 8-wave workgroup per CU,
                             // 48 + 32 queries per SIMD, unit-level software pipeline); 0: attn_kernel
   int no_fused_kf = 0;      // A2P_NO_FUSED_KF=1: body model: MID2 | keyframe attention | POST as three launches instead of one (A/B, tests)
@@ -180,7 +183,7 @@ static void load_opts(A2POpts& o) {
   o.side_early_join = flag("A2P_SIDE_EARLY_JOIN"); o.no_shared_half = flag("A2P_NO_SHARED_HALF");
   o.graph = flag("A2P_GRAPH");
   o.no_ksplit = flag("A2P_NO_KSPLIT"); o.force_ksplit = flag("A2P_ATTN_KSPLIT"); o.ksplit_nw = num("A2P_KSPLIT_NW", 0); o.ksplit_qt = num("A2P_KSPLIT_QT", 0);
-  o.no_fused_kf = flag("A2P_NO_FUSED_KF"); o.attn2 = num("A2P_ATTN2", 0);
+  o.no_fused_kf = flag("A2P_NO_FUSED_KF"); o.attn2 = num("A2P_ATTN2", 0); o.chain_v = num("A2P_CHAIN_V", 0);
   o.no_small = flag("A2P_NO_SMALL"); o.chain_rows = num("A2P_CHAIN_ROWS", 1100);
 }
 
@@ -213,6 +216,7 @@ struct a2p_ctx {
   Buf tail_w, tail_b;                  // fused output tail of the body model (kernels_tail.h): packed MFMA weight operands, [8][256] biases
   int64_t tail_woff[8] = {};
   bool tail_fused = false;
+  std::vector<Buf> ch_stream4;         // kernels_chain4.h: half-stage streams [layer*5 + kind] (CH_MID, CH_POST of the face model; empty Buf otherwise)
   std::vector<Buf> ch_stream, ch_aux;  // packed weight streams [layout * L*5 + layer*5 + kind] (layout 0: 4-wave LDS slices, 1: 8-wave; kinds: a2p_lib_run.h CH_*) / bias blocks [layer*5 + kind]
   int ch_nw = 4;                       // waves per chain workgroup of the forward being enqueued (4 or 8; chain_pick_nw)
   struct ChainTune {                   // per forward size (rows): which workgroup shape is faster ON THIS BOX, measured in situ
@@ -676,6 +680,7 @@ extern "C" int a2p_ctx_destroy(a2p_ctx* c) {
   for (Buf* b : all) buf_free(*b);
   for (int i = 0; i < 7; ++i) buf_free(c->conv_wt[i]);
   for (auto& b : c->ch_stream) buf_free(b);
+  for (auto& b : c->ch_stream4) buf_free(b);
   for (auto& kv : c->ch_tune)
     for (auto& sm : kv.second.samples) { (void)hipEventDestroy(std::get<1>(sm)); (void)hipEventDestroy(std::get<2>(sm)); }
   for (auto& b : c->ch_aux) buf_free(b);

@@ -147,13 +147,38 @@ static int chain_pack(a2p_ctx* c, int idx, const std::vector<ChainPackDesc>& des
   return 0;
 }
 
+// kernels_chain4.h: HALF stages (128 output columns x 32 k) in the order gemm<NTG, NKC> consumes them: k-chunk-major inside a group
+// of `group` tiles
+static void pk4_gemm(std::vector<ChainPackDesc>& v, const void* W, int ldw, int nrows, int k0, int K, int omap, int group, int tile0 = 0, int ntiles = -1) {
+  const int nt = ntiles < 0 ? (nrows + 127) / 128 : ntiles;
+  for (int t0 = 0; t0 < nt; t0 += group)
+    for (int kc = 0; kc < K / 32; ++kc)
+      for (int t = t0; t < t0 + group && t < nt; ++t)
+        v.push_back({reinterpret_cast<const h16_t*>(W), ldw, (tile0 + t) * 128, k0 + kc * 32, nrows, omap});
+}
+static int chain4_pack(a2p_ctx* c, int idx, const std::vector<ChainPackDesc>& descs, hipStream_t s) {
+  const size_t pad = 2 * CHAIN_STREAM_PAD;   // the register ring runs CHAIN4_PF half stages past the end
+  Buf dd;
+  CHK(buf_alloc_tmp(dd, descs.size() * sizeof(ChainPackDesc)));
+  HIPCHK(hipMemcpyAsync(dd.p, descs.data(), descs.size() * sizeof(ChainPackDesc), hipMemcpyHostToDevice, s));
+  Buf& st = c->ch_stream4[idx];
+  CHK(buf_alloc(st, (descs.size() + pad) * CHAIN4_HS_ELEMS * 2));
+  chain4_pack_kernel<<<(int)descs.size(), 256, 0, s>>>(reinterpret_cast<const ChainPackDesc*>(dd.p), reinterpret_cast<h16_t*>(st.p));
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipStreamSynchronize(s));
+  buf_free(dd);
+  return 0;
+}
+
 // pre-pack every chain's weight stream in consumption order (called from a2p_finalize_weights)
 static int chain_build_streams(a2p_ctx* c, hipStream_t s) {
   const int d = c->d, ff = c->ff, L = c->L;
   if (c->ch_stream.size() != (size_t)L * 2 * CH_KINDS) {  // first build; later builds (weight updates) refill the same buffers
     c->ch_stream.assign((size_t)L * 2 * CH_KINDS, Buf());
     c->ch_aux.assign((size_t)L * CH_KINDS, Buf());
+    c->ch_stream4.assign((size_t)L * CH_KINDS, Buf());
   }
+  const bool v4 = d == 512 && ff == 1024 && !c->pose && c->opt.chain_v != 1;   // tall chain kernels: face model only
   auto pf = [&](int l) { return "seqTransDecoder.stack." + std::to_string(l) + "."; };
   auto add_pre = [&](std::vector<ChainPackDesc>& v, int l) {  // [Q|K] then V of layer l's self attention
     const Buf& inw = c->wt.at(pf(l) + "self_attn.in_proj_weight");
@@ -194,6 +219,24 @@ static int chain_build_streams(a2p_ctx* c, hipStream_t s) {
       aux.push_back({W32(c, "final_layer.bias"), c->C});
     }
     CHK(chain_pack(c, ch_index(l, CH_POST), q, aux, s));
+    if (v4) {   // the same chains for kernels_chain4.h (MID; POST of every layer that has a successor)
+      std::vector<ChainPackDesc> m4;
+      pk4_gemm(m4, c->wt.at(pf(l) + "self_attn.out_proj.weight").p, d, d, 0, d, 0, 4);
+      pk4_gemm(m4, c->wt.at(pf(l) + "multihead_attn.in_proj_weight").p, d, d, 0, d, 1, 2);   // rows [0, d): the query projection, in pairs
+      CHK(chain4_pack(c, ch_index(l, CH_MID), m4, s));
+      if (l + 1 < L) {
+        std::vector<ChainPackDesc> q4;
+        pk4_gemm(q4, c->wt.at(pf(l) + "multihead_attn.out_proj.weight").p, d, d, 0, d, 0, 4);
+        for (int h = 0; h < FTn; ++h) {
+          pk4_gemm(q4, w1.p, d, ff, 0, d, 0, 1, h, 1);              // linear1, hidden columns [128 h, 128 h + 128)
+          pk4_gemm(q4, w2.p, ff, d, h * 128, 128, 0, 4);            // linear2 partial over that hidden chunk, 4 output tiles
+        }
+        const Buf& inw = c->wt.at(pf(l + 1) + "self_attn.in_proj_weight");
+        pk4_gemm(q4, inw.p, d, 2 * d, 0, d, 1, 2);                  // [Q|K] of the next layer, in pairs
+        pk4_gemm(q4, c->offT(inw, (int64_t)2 * d * d), d, d, 0, d, 1, 2);   // V
+        CHK(chain4_pack(c, ch_index(l, CH_POST), q4, s));
+      }
+    }
     if (c->pose) {   // CHAIN_MIDPOST: out_proj of the audio cross attention | query projection of multihead_attn2 (k-major group: its
       // tiles stay in registers until the panel can be overwritten) | everything of the POST stream
       std::vector<ChainPackDesc> mp;
@@ -211,6 +254,7 @@ static void chain_base(a2p_ctx* c, ChainP& p, int N, int T, int idx, int aux_flo
   p.M = N * T; p.rows_per_seq = T; p.x = c->x.f(); p.cst = reinterpret_cast<const f32x4*>(c->rope_cst.p); p.cs_npos = c->rope_npos;
   p.ain = reinterpret_cast<const h16_t*>(c->ao.p); p.ld_ain = c->d;
   p.stream = reinterpret_cast<const h16_t*>(c->ch_stream[(size_t)(c->ch_nw == 8) * c->L * CH_KINDS + idx].p);
+  p.stream4 = c->ch_stream4.empty() ? nullptr : reinterpret_cast<const h16_t*>(c->ch_stream4[idx].p);
   p.aux = c->ch_aux[idx].f(); p.aux_kb = (aux_floats + 255) / 256;
   if (c->clk.p) {  // A2P_CHAIN_CLK=1: every chain launch of a forward gets its own 8 x 4 slot (a2p_debug_read "clk")
 #ifdef A2P_STAMPS   // diagnostic build (scratch/phase_probe.py): launch A2P_STAMP_LAUNCH of every forward writes its phase stamps behind the clk slots
@@ -257,6 +301,7 @@ static int chain_pick_nw(a2p_ctx* c, int64_t rows, hipEvent_t* e0, hipEvent_t* e
   if (c->opt.chain_nw) return c->opt.chain_nw == 8 ? 8 : 4;
   if (!c->opt.chain_tune) {
     const int mt = c->opt.chain_mt;
+    if (mt == 5 && c->d == 512 && c->opt.chain_v != 1 && !c->ch_stream4.empty()) return 8;   // 80 rows: the tall kernels (8 waves) have it
     return (mt && ((mt > 4 && c->d == 512) || mt > 5)) ? 4 : 8;   // forced panel heights the 8-wave kernels do not have
   }
   if (c->opt.chain_mt) {  // a forced panel height the 8-wave kernels do not have
@@ -291,7 +336,47 @@ static int chain_pick_nw(a2p_ctx* c, int64_t rows, hipEvent_t* e0, hipEvent_t* e
   return t.choice;
 }
 
+// Tall chain kernels (kernels_chain4.h): 64 / 80-row panels, weights straight into registers, epilogue operands from LDS.
+// Contract: face model (d = 512), MID or POST-with-successor, FiLM present, frame count a multiple of 8 and >= the panel height.
+// Rule: forwards of >= 16 sequences (B >= 8 under guidance is 16 sequences of 600 frames = 37.5 rows per CU: the 48-row panels of
+// kernels_chain.h are one round there; from 75 rows per CU on -- B = 16 -- an 80-row panel is one round where 48-row panels are two).
+static bool chain4_wanted(const a2p_ctx* c, int mode, const ChainP& p) {
+  if (c->opt.chain_v == 1 || p.stream4 == nullptr || c->d != 512 || c->ch_nw != 8) return false;
+  if (!(mode == CHAIN_MID || (mode == CHAIN_POST && p.has_next == 1))) return false;
+  if (p.film_o == nullptr || (mode == CHAIN_POST && p.film_f == nullptr)) return false;
+  if ((p.rows_per_seq & 7) || p.rows_per_seq < 80) return false;
+  if (c->opt.chain_v == 4) return true;
+  return p.M >= 16 * 600 * 2;   // >= 75 rows per CU
+}
+static int launch_chain4(a2p_ctx* c, int mode, const ChainP& p0, hipStream_t s) {
+  ChainP p = p0;
+  p.stream = p.stream4;
+  int mt = c->opt.chain_mt;
+  if (mt < 3 || mt > 5) {   // fewest rounds over the 256 CUs, then the shorter panel
+    int best = 1 << 30;
+    for (int m = 3; m <= 5; ++m) {
+      const int blocks = (p.M + 16 * m - 1) / (16 * m);
+      const int cost = ((blocks + 255) / 256) * (16 + 4 * m);
+      if (cost < best) { best = cost; mt = m; }
+    }
+  }
+  const int grid = (p.M + 16 * mt - 1) / (16 * mt);
+  KernelTimer kt(c, A2P_KERNEL_CHAIN, mode == CHAIN_MID ? A2P_KERNEL_CHAIN_MID : A2P_KERNEL_CHAIN_POST);
+#define A2P_CHAIN4(MT)                                                                          \
+  do {                                                                                          \
+    if (mode == CHAIN_MID) A2P_LAUNCH(kt, (chain4_kernel<MT, CHAIN_MID>), grid, 512, s, p);     \
+    else A2P_LAUNCH(kt, (chain4_kernel<MT, CHAIN_POST>), grid, 512, s, p);                      \
+  } while (0)
+  if (mt == 3) A2P_CHAIN4(3);
+  else if (mt == 4) A2P_CHAIN4(4);
+  else A2P_CHAIN4(5);
+#undef A2P_CHAIN4
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
 static int launch_chain(a2p_ctx* c, int mode, const ChainP& p, hipStream_t s) {
+  if (chain4_wanted(c, mode, p)) return launch_chain4(c, mode, p, s);
   const bool env_mt = c->opt.chain_mt != 0;  // tuning / test override of the panel height (rows = 16 * MT)
   int mt = c->opt.chain_mt;
   // panel heights instantiated per width (LDS: the [16*MT][d] bf16 panel + hidden chunk + >= 3 ring slots must fit 160 KiB)

@@ -1,0 +1,470 @@
+// Row-panel chain kernels, TALL form (round 5): the MID / POST chains of kernels_chain.h (FiLMTransformerDecoderLayer.forward,
+// transformer_modules.py:178-267) for forwards of >= 16 sequences of the face model (d = 512), where a CU owes >= 75 rows and a
+// 48-row panel streams every weight byte for too few of them (16 KiB of weights per 192 MFMA cycles
+// against the 64 B/clk L2 -> CU path; B=32 runs three rounds of 48 / 64-row panels).  Same arithmetic, same column ownership,
+// same accumulation order and LayerNorm tree as the 8-wave form of kernels_chain.h -- the outputs are bit-identical
+// (tests/test_hip_round5.py) -- restructured around four facts:
+//
+//   * PANELS OF 64 / 80 ROWS.  80 rows x 512 columns x 16 bit = 80 KiB of LDS: there is no room left for the 80 KiB weight
+//     ring of kernels_chain.h, so the WEIGHTS GO STRAIGHT FROM L2 INTO VGPRs (a weight fragment has exactly one consumer wave: each
+//     wave owns 16 of a tile's 128 output columns for all rows).  The stream is repacked in HALF stages of 8 KiB
+//     ([128 output columns] x [32 k] = one MFMA k-chunk, [wave][lane][8 values]: one 1 KiB global_load_dwordx4 per wave IS the A
+//     operand of MT MFMAs) in k-chunk-major order inside a tile group, and runs through an 8-deep register ring (32 VGPRs) of
+//     ordinary loads whose s_waitcnt vmcnt(N) hipcc places itself.
+//   * THE RESIDUAL ROWS DO NOT LIVE IN REGISTERS ACROSS THE GEMMS.  They are read where the FiLM + residual epilogue folds them
+//     into the accumulators (the accumulators BECOME the rows), and stored back before the feed-forward block ("parked", 2 KiB per
+//     row through L2) -- 80 rows x 512 columns are 80 registers per lane, which the FFN needs for its linear2 partials.
+//   * EPILOGUE OPERANDS COME FROM LDS.  The ring's 80 KiB are gone, so the per-column operands of every epilogue -- out_proj /
+//     linear2 biases, LayerNorm gamma / beta, the FiLM scale / shift rows of the (at most two) sequences a panel touches: 28 KiB --
+//     are DMA'd next to the attention-output panel at kernel start.  In kernels_chain.h each of them is a global load at a
+//     "turn-around" of the chain: ~11 dependent L2 round trips per POST kernel with the matrix pipe idle, 0.5-1 us each at B=8 and
+//     several times that at B=32 (r03 phase stamps: FiLM 2.5 -> 7.9 us, LayerNorm + rotary 4 -> 17 us per 48-row panel).
+//   * STORED GEMMs ([Q|K], V^T, Q) RUN IN PAIRS OF TILES, k-chunk-major: the panel fragments of a k-chunk are read once for both
+//     tiles (8 waves each read every panel row: the LDS port is the second roof of these phases) and the pair is what the paired
+//     column map writes as 64-byte runs anyway.
+//
+// One workgroup = 8 waves (two 256-register waves per SIMD) per CU.  Host contract: d = 512, ff = 1024, FiLM present, rows_per_seq
+// >= 16 * MT (a panel touches at most two sequences) and a multiple of 8 (staged V^T store); everything else takes kernels_chain.h.
+#pragma once
+#include "kernels_chain.h"
+
+#pragma clang fp contract(off)
+
+#define CHAIN4_PF 8            // half stages in flight per wave (register ring); every GEMM of a chain consumes a multiple of it
+#define CHAIN4_HS_ELEMS 4096   // 128 output columns x 32 k: 8 KiB
+
+template <int MT>
+struct Chain4Lds {
+  static constexpr int D = 512, BM = 16 * MT, AUX_F = 2560, EPI_F = 7168;
+  // 16-bit elements: panelA [BM][512], panelH [BM][128], LayerNorm partials [2][8][BM] fp32, aux [AUX_F] fp32, epilogue block [EPI_F] fp32
+  static constexpr int ELEMS = BM * D + BM * 128 + 32 * BM + 2 * AUX_F + 2 * EPI_F;
+  static_assert(ELEMS * 2 <= 160 * 1024, "panel too tall for the LDS");
+};
+// epilogue block (fp32 offsets)
+enum { E4_BIAS_O = 0, E4_BIAS_2 = 512, E4_LNA_G = 1024, E4_LNA_B = 1536, E4_LNB_G = 2048, E4_LNB_B = 2560, E4_FILM_O = 3072, E4_FILM_F = 5120 };
+// (FiLM blocks: [sequence A: scale 512 | shift 512][sequence B: scale 512 | shift 512])
+
+// one half stage of a packed stream: [wave 0..7][lane 0..63][8 k-values] -- lane (l15, g) of wave w gets
+// W[col(w, l15)][k0 + g*8 .. +8], the weight operand of v_mfma_f32_16x16x32 for this k-chunk.  Column ownership as chain_pack_kernel
+// with 8 waves (32-column group w >> 1, sub-tile w & 1, paired map for stored tiles).
+__global__ __launch_bounds__(256) void chain4_pack_kernel(const ChainPackDesc* __restrict__ descs, h16_t* __restrict__ dst) {
+  const ChainPackDesc d = descs[blockIdx.x];
+  uint4* out = reinterpret_cast<uint4*>(dst + (int64_t)blockIdx.x * CHAIN4_HS_ELEMS);
+  for (int q = threadIdx.x; q < 512; q += 256) {
+    const int w = q >> 6, lane = q & 63, i = lane & 15, g = lane >> 4;
+    const int w4 = w >> 1, J = w & 1, tile = d.row0 >> 7;
+    const int row = d.omap ? (tile >> 1) * 256 + w4 * 64 + J * 32 + (tile & 1) * 16 + i : d.row0 + w4 * 32 + (i >> 2) * 8 + J * 4 + (i & 3);
+    uint4 v = make_uint4(0, 0, 0, 0);
+    if (row < d.nrows) v = *reinterpret_cast<const uint4*>(d.W + (int64_t)row * d.ldw + d.k0 + g * 8);
+    out[q] = v;
+  }
+}
+
+template <int MT, int MODE>
+__device__ __forceinline__ void chain4_body(const ChainP& p, h16_t* const smem, const int m0) {
+  constexpr int D = 512, NW = 8, CW = 16, BM = 16 * MT, NT = 4, KC = D / 32, FT = 8, HLD = 128, PF = CHAIN4_PF;
+  constexpr int AUX_F = Chain4Lds<MT>::AUX_F;
+  h16_t* const panelA = smem;
+  h16_t* const panelH = panelA + BM * D;
+  float* const red = reinterpret_cast<float*>(panelH + BM * HLD);   // [2][8][BM] LayerNorm partial sums, one per wave
+  float* const aux = red + 16 * BM;                                   // [AUX_F] per-tile biases of the stored / FFN GEMMs
+  float* const epi = aux + AUX_F;                                     // [EPI_F] epilogue operands (E4_*)
+  const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6), l15 = lane & 15, g = lane >> 4;
+  const int W4 = wid >> 1, J0 = wid & 1;
+
+  // ---- weight stream: register ring of PF half stages --------------------------------------------------------------------
+  uint32_t woff = (uint32_t)(wid * 64 + lane) * 16;   // byte offset of this lane's 16 bytes of the next half stage to load
+  h16x8 wr[PF];
+  auto w_issue = [&](int slot) __attribute__((always_inline)) {
+    wr[slot] = *reinterpret_cast<const h16x8*>(reinterpret_cast<const char*>(p.stream) + woff);   // uniform base + 32-bit offset
+    woff += CHAIN4_HS_ELEMS * 2;    // the host pads the stream behind the last half stage
+  };
+
+  // ---- helpers -----------------------------------------------------------------------------------------------------------
+  auto col_of = [&](int t) __attribute__((always_inline)) { return t * 128 + W4 * 32 + g * 8 + J0 * 4; };
+  auto obase = [&](int t) __attribute__((always_inline)) { return (t >> 1) * 256 + W4 * 64 + J0 * 32 + (t & 1) * 16; };
+  auto x_rbase = [&](int m, int tiled) __attribute__((always_inline)) -> uint32_t {   // float offset of this lane's 4 columns of tile 0 of row m
+    const uint32_t a = (uint32_t)(((m >> 4) * (D / 16) + W4 * 2 + J0) * 256 + (g * 16 + (m & 15)) * 4);
+    const uint32_t b = (uint32_t)(m * D + W4 * 32 + g * 8 + J0 * 4);
+    return tiled ? a : b;
+  };
+  auto x_tstride = [&](int tiled) __attribute__((always_inline)) -> uint32_t { return tiled ? 2048u : 128u; };
+  auto ld4 = [&](const float* base, uint32_t elem) __attribute__((always_inline)) {
+    return *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(base) + (elem << 2));
+  };
+  auto st4 = [&](float* base, uint32_t elem, f32x4 v) __attribute__((always_inline)) {
+    *reinterpret_cast<f32x4*>(reinterpret_cast<char*>(base) + (elem << 2)) = v;
+  };
+  auto lds_off = [&](const void* q) __attribute__((always_inline)) { return (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) void*)q; };
+  int row_m[MT], fsel[MT], pos[MT];
+  const int seqA = m0 / p.rows_per_seq;
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) {
+    int m = m0 + mt * 16 + l15;
+    m = m < p.M ? m : p.M - 1;
+    row_m[mt] = m;
+    const int sq = m / p.rows_per_seq;
+    fsel[mt] = sq != seqA ? 1024 : 0;                 // second sequence of the panel: its FiLM rows sit 1024 floats further
+    pos[mt] = m - sq * p.rows_per_seq;
+  }
+  // fragment of k-chunk c (32 k-values) of panel rows mt*16 + l15: 16-byte piece (c*4 + g) ^ l15 of the row (XOR swizzle)
+  uint32_t aswz[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) aswz[i] = (uint32_t)(((i * 4) ^ (g ^ l15)) << 4);
+  const int pswz = (((W4 * 4 + g) ^ l15) << 3) | (J0 * 4);   // element offset inside a 128-column tile of this lane's 4 output columns
+
+  // acc[t][mt] += P[:, 0 : 32*NKC] x (the next NKC*NTG half stages)^T for NTG tiles, k-chunk-major (half stage = c*NTG + t).
+  // The panel fragments of k-chunk c+1 are read while the NTG*MT MFMAs of chunk c issue; ring slots are compile-time.
+  // swap = false: D = C^T, lane holds 4 consecutive columns n of row m = l15; swap = true: D = C (transposed V^T store).
+  auto gemm = [&](auto ntg_c, auto nkc_c, auto& acc, const h16_t* P, int pld, bool swap) __attribute__((always_inline)) {
+    constexpr int NTG = decltype(ntg_c)::value, NKC = decltype(nkc_c)::value;
+    static_assert((NTG * NKC) % PF == 0 && PF % NTG == 0, "ring phase");
+    const char* rp = reinterpret_cast<const char*>(P) + l15 * pld * 2;
+    const int rstep = 32 * pld;   // bytes between the 16-row blocks of a panel
+    h16x8 a[2][MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) a[0][mt] = *reinterpret_cast<const h16x8*>(rp + aswz[0] + mt * rstep);
+#pragma unroll
+    for (int c = 0; c < NKC; ++c) {
+      if (c + 1 < NKC) {
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+          a[(c + 1) & 1][mt] = *reinterpret_cast<const h16x8*>(rp + aswz[(c + 1) & 3] + ((c + 1) >> 2) * 256 + mt * rstep);
+      }
+#pragma unroll
+      for (int t = 0; t < NTG; ++t) {
+        const int slot = (c * NTG + t) % PF;
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+          if (swap) acc[t][mt] = A2P_MFMA16(a[c & 1][mt], wr[slot], acc[t][mt]);
+          else acc[t][mt] = A2P_MFMA16(wr[slot], a[c & 1][mt], acc[t][mt]);
+        }
+        w_issue(slot);
+      }
+      // issue order of the chunk: [MFMA, fragment read] x MT first, then MFMAs with the weight loads between the tiles
+#pragma unroll
+      for (int i = 0; i < NTG * MT; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        if (c + 1 < NKC && i < MT) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        if (i % MT == MT - 1) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+      }
+    }
+  };
+
+  // ---- kernel start: attention-output panel + aux + epilogue operands by LDS-DMA, weight ring primed ---------------------
+  {
+    for (int r0 = wid; r0 < BM; r0 += NW) {   // one 1 KiB row per wave instruction
+      int m = m0 + r0;
+      m = m < p.M ? m : p.M - 1;
+      m = (p.src_rows > 0 && m >= p.src_rows) ? m - p.src_rows : m;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(p.ain + (int64_t)m * p.ld_ain + ((lane ^ (r0 & 15)) << 3)),
+                                       (__attribute__((address_space(3))) void*)(panelA + r0 * D), 16, 0, 0);
+    }
+    for (int kb = wid; kb < p.aux_kb; kb += NW) chain_glds16(p.aux + kb * 256 + lane * 4, aux + kb * 256);
+    // epilogue block: 28 pieces of 1 KiB (256 floats); piece q -> source pointer + destination offset
+    const int nseq = p.M / p.rows_per_seq;
+    const int seqB = seqA + 1 < nseq ? seqA + 1 : seqA;
+    for (int q = wid; q < 28; q += NW) {
+      const float* src;
+      int dst;
+      if (q < 12) {   // six 512-float vectors, two pieces each
+        const int v = q >> 1, h = q & 1;
+        const float* base = v == 0 ? p.bias_o : v == 1 ? p.bias_2 : v == 2 ? p.lnA_g : v == 3 ? p.lnA_b : v == 4 ? p.lnB_g : p.lnB_b;
+        if (base == nullptr) base = p.bias_o;   // (MID: no bias_2 / lnB: never read)
+        src = base + h * 256;
+        dst = v * 512 + h * 256;
+      } else {        // FiLM rows: (film_o | film_f) x (sequence A | B) x (scale | shift) x 2 pieces
+        const int r = q - 12, set = r >> 3, sq = (r >> 2) & 1, part = (r >> 1) & 1, h = r & 1;
+        const float* film = set == 0 ? p.film_o : (p.film_f ? p.film_f : p.film_o);
+        src = film + (int64_t)(sq ? seqB : seqA) * p.film_seq_stride + (part ? p.film_shift_off : 0) + h * 256;
+        dst = (set == 0 ? E4_FILM_O : E4_FILM_F) + sq * 1024 + part * 512 + h * 256;
+      }
+      chain_glds16(src + lane * 4, epi + dst);
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < PF; ++i) w_issue(i);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the DMA pieces have landed for this wave (once per kernel: the ring's first loads too)
+  chain_bar();                                        // ... and for every other wave
+
+  // ---- epilogues ---------------------------------------------------------------------------------------------------------
+  // FiLM affine + residual, IN PLACE: R[t][mt] = x_old + (scale + 1) * (R + bias) + shift   (transformer_modules.py:122-124,193).
+  // bias / scale / shift from the LDS block; the old rows from global memory, one tile ahead of the arithmetic.
+  auto film_res = [&](f32x4(&R)[NT][MT], int e_bias, int e_film, const float* xs, int tiled, bool use_src) __attribute__((always_inline)) {
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    uint32_t xb[MT];
+    const uint32_t ts = x_tstride(tiled);
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+      const int ms = (use_src && p.src_rows > 0 && row_m[mt] >= p.src_rows) ? row_m[mt] - p.src_rows : row_m[mt];
+      xb[mt] = x_rbase(ms, tiled);
+    }
+    f32x4 xo[2][MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) xo[0][mt] = ld4(xs, xb[mt]);
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      if (t + 1 < NT) {
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) xo[(t + 1) & 1][mt] = ld4(xs, xb[mt] + (t + 1) * ts);
+      }
+      const f32x4 b = *reinterpret_cast<const f32x4*>(epi + e_bias + col_of(t));
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) {
+        const f32x4 sc = *reinterpret_cast<const f32x4*>(epi + e_film + fsel[mt] + col_of(t));
+        const f32x4 sh = *reinterpret_cast<const f32x4*>(epi + e_film + fsel[mt] + 512 + col_of(t));
+        const f32x4 y = R[t][mt] + b, s1 = sc + 1.0f;
+        f32x4 xr = xo[t & 1][mt];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) xr[e] += fmaf(s1[e], y[e], sh[e]);
+        R[t][mt] = xr;
+        asm volatile("" : "+v"(R[t][mt]));   // the result is pinned here (hipcc otherwise sinks the arithmetic to the first use of the rows)
+      }
+      __builtin_amdgcn_sched_barrier(0);     // one tile at a time
+    }
+  };
+  float ln_mean[MT], ln_rstd[MT];
+  auto group_partials = [&](const float* q) __attribute__((always_inline)) {
+    return ((q[0] + q[BM]) + (q[2 * BM] + q[3 * BM])) + ((q[4 * BM] + q[5 * BM]) + (q[6 * BM] + q[7 * BM]));
+  };
+  auto ln_stats = [&](const f32x4(&R)[NT][MT]) __attribute__((always_inline)) {
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+      float v = 0.f;
+#pragma unroll
+      for (int t = 0; t < NT; ++t) v += (R[t][mt][0] + R[t][mt][1]) + (R[t][mt][2] + R[t][mt][3]);
+      v += __shfl_xor(v, 16, 64);
+      v += __shfl_xor(v, 32, 64);
+      if (g == 0) red[wid * BM + mt * 16 + l15] = v;
+    }
+    chain_bar();
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+      const int r = mt * 16 + l15;
+      ln_mean[mt] = group_partials(red + r) * (1.0f / D);
+      float q = 0.f;
+#pragma unroll
+      for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float dlt = R[t][mt][e] - ln_mean[mt];
+          q = fmaf(dlt, dlt, q);
+        }
+      q += __shfl_xor(q, 16, 64);
+      q += __shfl_xor(q, 32, 64);
+      if (g == 0) red[8 * BM + wid * BM + r] = q;
+    }
+    chain_bar();
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+      const float var = group_partials(red + 8 * BM + mt * 16 + l15) * (1.0f / D);
+      ln_rstd[mt] = 1.0f / sqrtf(var + 1e-5f);
+    }
+  };
+  // normalised (optionally rotated, rotary_embedding_torch.py:46-66) rows -> 16-bit A panel.  gamma / beta from the LDS block; the
+  // rotary entries (MT per tile, global: the panel-layout table, 256 contiguous bytes per lane group) one tile ahead of their use
+  auto ln_write = [&](const f32x4(&R)[NT][MT], int e_gamma, auto rope_c) __attribute__((always_inline)) {
+    constexpr bool ROPE = decltype(rope_c)::value;
+    f32x4 cs[2][ROPE ? MT : 1];
+    auto load_cs = [&](int t) __attribute__((always_inline)) {
+      if constexpr (ROPE) {
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+          cs[t & 1][mt] = ld4(reinterpret_cast<const float*>(p.cst), ((uint32_t)(col_of(t) >> 2) * (uint32_t)p.cs_npos + (uint32_t)pos[mt]) << 2);
+      }
+    };
+    load_cs(0);
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      __builtin_amdgcn_sched_barrier(0);     // at most two tiles' rotary entries in flight
+      if (t + 1 < NT) load_cs(t + 1);
+      const f32x4 ga = *reinterpret_cast<const f32x4*>(epi + e_gamma + col_of(t));
+      const f32x4 be = *reinterpret_cast<const f32x4*>(epi + e_gamma + 512 + col_of(t));
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) {
+        const float rs = ln_rstd[mt], nm = -ln_mean[mt] * rs;
+        float v0 = fmaf(fmaf(R[t][mt][0], rs, nm), ga[0], be[0]);
+        float v1 = fmaf(fmaf(R[t][mt][1], rs, nm), ga[1], be[1]);
+        float v2 = fmaf(fmaf(R[t][mt][2], rs, nm), ga[2], be[2]);
+        float v3 = fmaf(fmaf(R[t][mt][3], rs, nm), ga[3], be[3]);
+        if constexpr (ROPE) {
+          const f32x4 c = cs[t & 1][mt];
+          const float r0 = fmaf(v0, c[0], -(v1 * c[1])), r1 = fmaf(v1, c[0], v0 * c[1]);
+          const float r2 = fmaf(v2, c[2], -(v3 * c[3])), r3 = fmaf(v3, c[2], v2 * c[3]);
+          v0 = r0; v1 = r1; v2 = r2; v3 = r3;
+        }
+        *reinterpret_cast<h16x4*>(panelA + (mt * 16 + l15) * D + t * 128 + pswz) = h16x4{(h16_t)v0, (h16_t)v1, (h16_t)v2, (h16_t)v3};
+      }
+    }
+    chain_bar();   // the panel is complete before any wave's fragment reads
+  };
+  auto load_x = [&](f32x4(&R)[NT][MT], const float* xs, int tiled) __attribute__((always_inline)) {
+    const uint32_t ts = x_tstride(tiled);
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+      const uint32_t xb = x_rbase(row_m[mt], tiled);
+#pragma unroll
+      for (int t = 0; t < NT; ++t) R[t][mt] = ld4(xs, xb + t * ts);
+    }
+  };
+  auto store_x = [&](const f32x4(&R)[NT][MT], int tiled) __attribute__((always_inline)) {
+    const uint32_t ts = x_tstride(tiled);
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+      if (m0 + mt * 16 + l15 >= p.M) continue;
+      const uint32_t xb = x_rbase(row_m[mt], tiled);
+#pragma unroll
+      for (int t = 0; t < NT; ++t) st4(p.x, xb + t * ts, R[t][mt]);
+    }
+  };
+  // D-deep GEMM over NPAIR pairs of output tiles with a 16-bit store per pair (kernels_chain.h gemm_store, 8-wave forms): row-major
+  // pairs leave as 16 rows x 64 contiguous bytes per instruction through a wave-private slice of the idle hidden-chunk buffer,
+  // V^T tiles as 16-byte pieces of 8 consecutive frames.  Fully unrolled: across a loop back-edge hipcc waits for ALL ring loads.
+  auto gemm_store = [&](auto npair_c, const float* bias_lds, h16_t* out, int64_t ldo, auto transposed_c) __attribute__((always_inline)) {
+    constexpr int NPAIR = decltype(npair_c)::value;
+    constexpr bool TR = decltype(transposed_c)::value;
+    constexpr int VP = (CW * BM / 8 + 63) / 64;
+    h16_t* const stg = panelH + wid * (CW * BM);
+    uint32_t voff[VP];
+    bool vok[VP];
+    if constexpr (TR) {
+#pragma unroll
+      for (int i = 0; i < VP; ++i) {
+        const int q = lane + 64 * i, c = q / (BM / 8), m = m0 + (q % (BM / 8)) * 8;
+        const int sq = m / p.rows_per_seq;
+        vok[i] = q < CW * BM / 8 && m < p.M;
+        voff[i] = (uint32_t)sq * (uint32_t)p.vt_seq_stride + (uint32_t)(m - sq * p.rows_per_seq) + (uint32_t)c * (uint32_t)ldo;
+      }
+    }
+#pragma unroll
+    for (int pr = 0; pr < NPAIR; ++pr) {
+      f32x4 acc[2][MT];
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const int t = 2 * pr + h;
+        if constexpr (!TR) {
+          const f32x4 b = *reinterpret_cast<const f32x4*>(bias_lds + obase(t) + g * 4);
+#pragma unroll
+          for (int mt = 0; mt < MT; ++mt) acc[h][mt] = b;
+        } else {
+          const float b = bias_lds[obase(t) + l15];
+#pragma unroll
+          for (int mt = 0; mt < MT; ++mt) acc[h][mt] = f32x4{b, b, b, b};
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      gemm(std::integral_constant<int, 2>{}, std::integral_constant<int, KC>{}, acc, panelA, D, TR);
+      __builtin_amdgcn_sched_barrier(0);
+      if constexpr (!TR) {
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+          const f32x4 v0 = acc[0][mt], v1 = acc[1][mt];
+          const h16x4 lo = {(h16_t)v0[0], (h16_t)v0[1], (h16_t)v0[2], (h16_t)v0[3]};
+          const h16x4 hi = {(h16_t)v1[0], (h16_t)v1[1], (h16_t)v1[2], (h16_t)v1[3]};
+          const int hsw = (l15 >> 2) & 1;   // half-row swizzle of the [16][32] staging tile (kernels_chain.h)
+          asm volatile("ds_write_b64 %0, %2\n\tds_write_b64 %1, %3" ::"v"(lds_off(stg + l15 * 32 + hsw * 16 + g * 4)),
+                       "v"(lds_off(stg + l15 * 32 + (hsw ^ 1) * 16 + g * 4)), "v"(lo), "v"(hi)
+                       : "memory");
+          h16x8 w;
+          const int prow = lane >> 2, pp = lane & 3;
+          asm volatile("s_waitcnt lgkmcnt(0)\n\tds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)"
+                       : "=v"(w)
+                       : "v"(lds_off(stg + prow * 32 + (((pp >> 1) ^ ((prow >> 2) & 1)) * 2 + (pp & 1)) * 8))
+                       : "memory");
+          const int m = m0 + mt * 16 + (lane >> 2);
+          if (m < p.M)
+            *reinterpret_cast<h16x8*>(reinterpret_cast<char*>(out) + (((uint32_t)m * (uint32_t)ldo + (uint32_t)(obase(2 * pr) + (lane & 3) * 8)) << 1)) = w;
+        }
+      } else {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+#pragma unroll
+          for (int mt = 0; mt < MT; ++mt) {
+            const f32x4 v = acc[h][mt];
+            const h16x4 o = {(h16_t)v[0], (h16_t)v[1], (h16_t)v[2], (h16_t)v[3]};
+            asm volatile("ds_write_b64 %0, %1" ::"v"(lds_off(stg + l15 * BM + mt * 16 + g * 4)), "v"(o) : "memory");
+          }
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+          for (int i = 0; i < VP; ++i) {
+            h16x8 v;
+            asm volatile("ds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(lds_off(stg + (lane + 64 * i) * 8)) : "memory");
+            if (vok[i]) *reinterpret_cast<h16x8*>(reinterpret_cast<char*>(out) + ((voff[i] + (uint32_t)obase(2 * pr + h) * (uint32_t)ldo) << 1)) = v;
+          }
+        }
+      }
+    }
+  };
+
+  // =========================================================================================================================
+  const std::false_type F{};
+  const std::true_type Tt{};
+  f32x4 R[NT][MT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) R[t][mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+  __builtin_amdgcn_sched_barrier(0);
+  gemm(std::integral_constant<int, NT>{}, std::integral_constant<int, KC>{}, R, panelA, D, false);   // out_proj of the attention that produced `ain`
+  __builtin_amdgcn_sched_barrier(0);
+  film_res(R, E4_BIAS_O, E4_FILM_O, p.xsrc ? p.xsrc : p.x, p.x_in_tiled, true);
+  ln_stats(R);   // (its barriers also order the panel rewrite behind every wave's out_proj reads)
+  if constexpr (MODE == CHAIN_MID) {
+    ln_write(R, E4_LNA_G, Tt);
+    gemm_store(std::integral_constant<int, NT / 2>{}, aux, p.q_out, p.ld_q, F);
+    store_x(R, p.x_out_tiled);
+  } else {
+    ln_write(R, E4_LNA_G, F);
+    store_x(R, p.x_out_tiled);            // parked: the feed-forward block runs without the residual rows in registers
+    __builtin_amdgcn_sched_barrier(0);
+    // Feed forward, split-K over the 8 hidden chunks: linear1 chunk -> GELU -> LDS -> linear2 partial
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) R[t][mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll 2
+    for (int h = 0; h < FT; ++h) {
+      f32x4 acc[1][MT];
+      {
+        const f32x4 b = *reinterpret_cast<const f32x4*>(aux + h * 128 + W4 * 32 + g * 8 + J0 * 4);
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) acc[0][mt] = b;
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      gemm(std::integral_constant<int, 1>{}, std::integral_constant<int, KC>{}, acc, panelA, D, false);
+      __builtin_amdgcn_sched_barrier(0);
+      if (h > 0) chain_bar();   // every wave finished the linear2 partial of the previous chunk
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) {
+        const f32x4 v = acc[0][mt];
+        *reinterpret_cast<h16x4*>(panelH + (mt * 16 + l15) * HLD + pswz) =
+            h16x4{(h16_t)act_gelu_fast(v[0]), (h16_t)act_gelu_fast(v[1]), (h16_t)act_gelu_fast(v[2]), (h16_t)act_gelu_fast(v[3])};
+      }
+      chain_bar();              // the hidden chunk is complete
+      __builtin_amdgcn_sched_barrier(0);
+      gemm(std::integral_constant<int, NT>{}, std::integral_constant<int, 4>{}, R, panelH, HLD, false);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    // the parked rows come back from where store_x left them (same workgroup, same lanes: program order makes them visible)
+    film_res(R, E4_BIAS_2, E4_FILM_F, p.x, p.x_out_tiled, false);
+    // next layer's PRE work: norm1 -> rotary -> [Q|K] ; norm1 -> V^T     (aux: bias_qk right behind bias_1, then bias_v)
+    ln_stats(R);
+    ln_write(R, E4_LNB_G, Tt);
+    store_x(R, p.x_out_tiled);            // the finished rows; the 16*MT row registers are free during the [Q|K] GEMM
+    __builtin_amdgcn_sched_barrier(0);
+    gemm_store(std::integral_constant<int, NT>{}, aux + FT * 128, p.qk_out, p.ld_qk, F);
+    chain_bar();                          // every wave is done reading the rotated panel
+    load_x(R, p.x, p.x_out_tiled);        // back from where store_x left them
+    ln_write(R, E4_LNB_G, F);
+    gemm_store(std::integral_constant<int, NT / 2>{}, aux + FT * 128 + 2 * D, p.vt_out, p.ld_vt, Tt);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the ring's run-ahead loads target this wave's registers
+}
+
+template <int MT, int MODE>
+__global__ __launch_bounds__(512, 2) void chain4_kernel(const ChainP p) {
+  __shared__ __attribute__((aligned(16))) h16_t smem[Chain4Lds<MT>::ELEMS];
+  chain4_body<MT, MODE>(p, smem, blockIdx.x * (16 * MT));
+}
+#pragma clang fp contract(fast)
