@@ -216,6 +216,8 @@ struct a2p_ctx {
   Buf tail_w, tail_b;                  // fused output tail of the body model (kernels_tail.h): packed MFMA weight operands, [8][256] biases
   int64_t tail_woff[8] = {};
   bool tail_fused = false;
+  int64_t ch4_launches = 0;            // launches of the tall chain kernels (a2p_debug_read "chain4_launches")
+  std::vector<Buf> ch_stream4w;        // POST streams with 256-column hidden chunks [layer]
   std::vector<Buf> ch_stream4;         // kernels_chain4.h: half-stage streams [layer*5 + kind] (CH_MID, CH_POST of the face model; empty Buf otherwise)
   std::vector<Buf> ch_stream, ch_aux;  // packed weight streams [layout * L*5 + layer*5 + kind] (layout 0: 4-wave LDS slices, 1: 8-wave; kinds: a2p_lib_run.h CH_*) / bias blocks [layer*5 + kind]
   int ch_nw = 4;                       // waves per chain workgroup of the forward being enqueued (4 or 8; chain_pick_nw)
@@ -681,6 +683,7 @@ extern "C" int a2p_ctx_destroy(a2p_ctx* c) {
   for (int i = 0; i < 7; ++i) buf_free(c->conv_wt[i]);
   for (auto& b : c->ch_stream) buf_free(b);
   for (auto& b : c->ch_stream4) buf_free(b);
+  for (auto& b : c->ch_stream4w) buf_free(b);
   for (auto& kv : c->ch_tune)
     for (auto& sm : kv.second.samples) { (void)hipEventDestroy(std::get<1>(sm)); (void)hipEventDestroy(std::get<2>(sm)); }
   for (auto& b : c->ch_aux) buf_free(b);

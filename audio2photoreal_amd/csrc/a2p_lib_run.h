@@ -156,12 +156,11 @@ static void pk4_gemm(std::vector<ChainPackDesc>& v, const void* W, int ldw, int 
       for (int t = t0; t < t0 + group && t < nt; ++t)
         v.push_back({reinterpret_cast<const h16_t*>(W), ldw, (tile0 + t) * 128, k0 + kc * 32, nrows, omap});
 }
-static int chain4_pack(a2p_ctx* c, int idx, const std::vector<ChainPackDesc>& descs, hipStream_t s) {
+static int chain4_pack(a2p_ctx* c, Buf& st, const std::vector<ChainPackDesc>& descs, hipStream_t s) {
   const size_t pad = 2 * CHAIN_STREAM_PAD;   // the register ring runs CHAIN4_PF half stages past the end
   Buf dd;
   CHK(buf_alloc_tmp(dd, descs.size() * sizeof(ChainPackDesc)));
   HIPCHK(hipMemcpyAsync(dd.p, descs.data(), descs.size() * sizeof(ChainPackDesc), hipMemcpyHostToDevice, s));
-  Buf& st = c->ch_stream4[idx];
   CHK(buf_alloc(st, (descs.size() + pad) * CHAIN4_HS_ELEMS * 2));
   chain4_pack_kernel<<<(int)descs.size(), 256, 0, s>>>(reinterpret_cast<const ChainPackDesc*>(dd.p), reinterpret_cast<h16_t*>(st.p));
   HIPCHK(hipGetLastError());
@@ -177,8 +176,9 @@ static int chain_build_streams(a2p_ctx* c, hipStream_t s) {
     c->ch_stream.assign((size_t)L * 2 * CH_KINDS, Buf());
     c->ch_aux.assign((size_t)L * CH_KINDS, Buf());
     c->ch_stream4.assign((size_t)L * CH_KINDS, Buf());
+    c->ch_stream4w.assign((size_t)L, Buf());
   }
-  const bool v4 = d == 512 && ff == 1024 && !c->pose && c->opt.chain_v != 1;   // tall chain kernels: face model only
+  const bool v4 = d == 512 && ff == 1024 && !c->pose;   // tall chain kernels: face model only (built even under A2P_CHAIN_V=1: the switch is run-time)
   auto pf = [&](int l) { return "seqTransDecoder.stack." + std::to_string(l) + "."; };
   auto add_pre = [&](std::vector<ChainPackDesc>& v, int l) {  // [Q|K] then V of layer l's self attention
     const Buf& inw = c->wt.at(pf(l) + "self_attn.in_proj_weight");
@@ -222,19 +222,22 @@ static int chain_build_streams(a2p_ctx* c, hipStream_t s) {
     if (v4) {   // the same chains for kernels_chain4.h (MID; POST of every layer that has a successor)
       std::vector<ChainPackDesc> m4;
       pk4_gemm(m4, c->wt.at(pf(l) + "self_attn.out_proj.weight").p, d, d, 0, d, 0, 4);
-      pk4_gemm(m4, c->wt.at(pf(l) + "multihead_attn.in_proj_weight").p, d, d, 0, d, 1, 2);   // rows [0, d): the query projection, in pairs
-      CHK(chain4_pack(c, ch_index(l, CH_MID), m4, s));
+      pk4_gemm(m4, c->wt.at(pf(l) + "multihead_attn.in_proj_weight").p, d, d, 0, d, 1, 4);   // rows [0, d): the query projection, one group of four tiles
+      CHK(chain4_pack(c, c->ch_stream4[ch_index(l, CH_MID)], m4, s));
       if (l + 1 < L) {
-        std::vector<ChainPackDesc> q4;
-        pk4_gemm(q4, c->wt.at(pf(l) + "multihead_attn.out_proj.weight").p, d, d, 0, d, 0, 4);
-        for (int h = 0; h < FTn; ++h) {
-          pk4_gemm(q4, w1.p, d, ff, 0, d, 0, 1, h, 1);              // linear1, hidden columns [128 h, 128 h + 128)
-          pk4_gemm(q4, w2.p, ff, d, h * 128, 128, 0, 4);            // linear2 partial over that hidden chunk, 4 output tiles
-        }
         const Buf& inw = c->wt.at(pf(l + 1) + "self_attn.in_proj_weight");
-        pk4_gemm(q4, inw.p, d, 2 * d, 0, d, 1, 2);                  // [Q|K] of the next layer, in pairs
-        pk4_gemm(q4, c->offT(inw, (int64_t)2 * d * d), d, d, 0, d, 1, 2);   // V
-        CHK(chain4_pack(c, ch_index(l, CH_POST), q4, s));
+        for (int hc = 128; hc <= 256; hc += 128) {   // hidden chunk of the feed-forward block: 128 (80-row panels) | 256 (<= 64 rows): Chain4Lds::HC
+          std::vector<ChainPackDesc> q4;
+          pk4_gemm(q4, c->wt.at(pf(l) + "multihead_attn.out_proj.weight").p, d, d, 0, d, 0, 4);
+          const int nh = hc / 128;
+          for (int h = 0; h < ff / hc; ++h) {
+            pk4_gemm(q4, w1.p, d, ff, 0, d, 0, nh, h * nh, nh);       // linear1, hidden columns [hc h, hc h + hc): nh tiles, k-chunk-major
+            pk4_gemm(q4, w2.p, ff, d, h * hc, hc, 0, 4);              // linear2 partial over that hidden chunk, 4 output tiles
+          }
+          pk4_gemm(q4, inw.p, d, 2 * d, 0, d, 1, 4);                  // [Q|K] of the next layer, in groups of four tiles
+          pk4_gemm(q4, c->offT(inw, (int64_t)2 * d * d), d, d, 0, d, 1, 4);   // V
+          CHK(chain4_pack(c, hc == 128 ? c->ch_stream4[ch_index(l, CH_POST)] : c->ch_stream4w[l], q4, s));
+        }
       }
     }
     if (c->pose) {   // CHAIN_MIDPOST: out_proj of the audio cross attention | query projection of multihead_attn2 (k-major group: its
@@ -255,6 +258,7 @@ static void chain_base(a2p_ctx* c, ChainP& p, int N, int T, int idx, int aux_flo
   p.ain = reinterpret_cast<const h16_t*>(c->ao.p); p.ld_ain = c->d;
   p.stream = reinterpret_cast<const h16_t*>(c->ch_stream[(size_t)(c->ch_nw == 8) * c->L * CH_KINDS + idx].p);
   p.stream4 = c->ch_stream4.empty() ? nullptr : reinterpret_cast<const h16_t*>(c->ch_stream4[idx].p);
+  p.stream4w = (c->ch_stream4w.empty() || idx % CH_KINDS != CH_POST) ? nullptr : reinterpret_cast<const h16_t*>(c->ch_stream4w[idx / CH_KINDS].p);
   p.aux = c->ch_aux[idx].f(); p.aux_kb = (aux_floats + 255) / 256;
   if (c->clk.p) {  // A2P_CHAIN_CLK=1: every chain launch of a forward gets its own 8 x 4 slot (a2p_debug_read "clk")
 #ifdef A2P_STAMPS   // diagnostic build (scratch/phase_probe.py): launch A2P_STAMP_LAUNCH of every forward writes its phase stamps behind the clk slots
@@ -301,7 +305,7 @@ static int chain_pick_nw(a2p_ctx* c, int64_t rows, hipEvent_t* e0, hipEvent_t* e
   if (c->opt.chain_nw) return c->opt.chain_nw == 8 ? 8 : 4;
   if (!c->opt.chain_tune) {
     const int mt = c->opt.chain_mt;
-    if (mt == 5 && c->d == 512 && c->opt.chain_v != 1 && !c->ch_stream4.empty()) return 8;   // 80 rows: the tall kernels (8 waves) have it
+    if (mt == 5 && c->d == 512 && c->opt.chain_v != 1 && !c->ch_stream4.empty() && c->ch_stream4[ch_index(0, CH_MID)].p) return 8;   // 80 rows: the tall kernels (8 waves) have it
     return (mt && ((mt > 4 && c->d == 512) || mt > 5)) ? 4 : 8;   // forced panel heights the 8-wave kernels do not have
   }
   if (c->opt.chain_mt) {  // a forced panel height the 8-wave kernels do not have
@@ -345,12 +349,12 @@ static bool chain4_wanted(const a2p_ctx* c, int mode, const ChainP& p) {
   if (!(mode == CHAIN_MID || (mode == CHAIN_POST && p.has_next == 1))) return false;
   if (p.film_o == nullptr || (mode == CHAIN_POST && p.film_f == nullptr)) return false;
   if ((p.rows_per_seq & 7) || p.rows_per_seq < 80) return false;
-  if (c->opt.chain_v == 4) return true;
-  return p.M >= 16 * 600 * 2;   // >= 75 rows per CU
+  // faster than kernels_chain.h at every size measured (profiles/r05_tall_chain_*: B=8 556 -> 583 steps/s with 48-row panels that
+  // keep their rows in registers, B=16 330 -> 372 and B=32 188 -> 198 with 80-row panels): the default wherever the contract holds
+  return true;
 }
 static int launch_chain4(a2p_ctx* c, int mode, const ChainP& p0, hipStream_t s) {
   ChainP p = p0;
-  p.stream = p.stream4;
   int mt = c->opt.chain_mt;
   if (mt < 3 || mt > 5) {   // fewest rounds over the 256 CUs, then the shorter panel
     int best = 1 << 30;
@@ -360,7 +364,9 @@ static int launch_chain4(a2p_ctx* c, int mode, const ChainP& p0, hipStream_t s) 
       if (cost < best) { best = cost; mt = m; }
     }
   }
+  p.stream = (mode == CHAIN_POST && mt <= 4) ? p.stream4w : p.stream4;   // POST: the stream of the panel height's hidden-chunk width
   const int grid = (p.M + 16 * mt - 1) / (16 * mt);
+  ++c->ch4_launches;
   KernelTimer kt(c, A2P_KERNEL_CHAIN, mode == CHAIN_MID ? A2P_KERNEL_CHAIN_MID : A2P_KERNEL_CHAIN_POST);
 #define A2P_CHAIN4(MT)                                                                          \
   do {                                                                                          \
@@ -1349,6 +1355,11 @@ extern "C" int a2p_debug_read(a2p_ctx* c, const char* name, void* host, int64_t 
   if (n == "chain_nw") {   // int32: waves per chain workgroup of the last chain forward (4 | 8; bench.py reports it)
     ARG(bytes >= 4, "chain_nw is one int32");
     *reinterpret_cast<int32_t*>(host) = c->ch_nw;
+    return 0;
+  }
+  if (n == "chain4_launches") {   // int64: launches of the tall chain kernels (kernels_chain4.h) on this context so far (tests, bench)
+    ARG(bytes >= 8, "chain4_launches is one int64");
+    *reinterpret_cast<int64_t*>(host) = c->ch4_launches;
     return 0;
   }
   const Buf* b = n == "film" ? &c->film : n == "ktail" ? &c->ktail : n == "vtail" ? &c->vtail : n == "tvec" ? &c->tvec

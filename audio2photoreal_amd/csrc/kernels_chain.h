@@ -79,6 +79,7 @@ struct ChainP {
   // layout in place; the first kernel of a forward reads row-major (input projection), the last one writes row-major.
   int x_in_tiled, x_out_tiled;
   const h16_t* stream;   // packed weight stream of this chain
+  const h16_t* stream4w; // POST only: the kernels_chain4.h stream with 256-column hidden chunks (panels of <= 64 rows)
   const h16_t* stream4;  // the same chain's stream in the half-stage register layout of kernels_chain4.h (NULL: not built for this chain)
   const float* aux;       // per-tile biases of this chain, aux_kb KiB: POST [bias_1 | bias_qk' | bias_v'], MID [bias_q], PRE [bias_qk | bias_v]
   // MID / POST: attention output panel

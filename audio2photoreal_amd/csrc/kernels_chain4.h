@@ -36,8 +36,12 @@
 template <int MT>
 struct Chain4Lds {
   static constexpr int D = 512, BM = 16 * MT, AUX_F = 2560, EPI_F = 7168;
-  // 16-bit elements: panelA [BM][512], panelH [BM][128], LayerNorm partials [2][8][BM] fp32, aux [AUX_F] fp32, epilogue block [EPI_F] fp32
-  static constexpr int ELEMS = BM * D + BM * 128 + 32 * BM + 2 * AUX_F + 2 * EPI_F;
+  // hidden chunk of the feed-forward block: 256 columns where the LDS has room (<= 64 rows), 128 at 80 rows.  256: linear1 computes
+  // two hidden tiles per panel-fragment read (8 waves each read every panel row: with one tile the LDS port is linear1's roof) and the
+  // block has 8 workgroup barriers instead of 16.  The host packs the stream accordingly (a2p_lib_run.h: two POST streams).
+  static constexpr int HC = MT <= 4 ? 256 : 128;
+  // 16-bit elements: panelA [BM][512], panelH [BM][HC], LayerNorm partials [2][8][BM] fp32, aux [AUX_F] fp32, epilogue block [EPI_F] fp32
+  static constexpr int ELEMS = BM * D + BM * HC + 32 * BM + 2 * AUX_F + 2 * EPI_F;
   static_assert(ELEMS * 2 <= 160 * 1024, "panel too tall for the LDS");
 };
 // epilogue block (fp32 offsets)
@@ -62,7 +66,7 @@ __global__ __launch_bounds__(256) void chain4_pack_kernel(const ChainPackDesc* _
 
 template <int MT, int MODE>
 __device__ __forceinline__ void chain4_body(const ChainP& p, h16_t* const smem, const int m0) {
-  constexpr int D = 512, NW = 8, CW = 16, BM = 16 * MT, NT = 4, KC = D / 32, FT = 8, HLD = 128, PF = CHAIN4_PF;
+  constexpr int D = 512, NW = 8, CW = 16, BM = 16 * MT, NT = 4, KC = D / 32, FT = 8, HLD = Chain4Lds<MT>::HC, NH = HLD / 128, PF = CHAIN4_PF;
   constexpr int AUX_F = Chain4Lds<MT>::AUX_F;
   h16_t* const panelA = smem;
   h16_t* const panelH = panelA + BM * D;
@@ -71,6 +75,14 @@ __device__ __forceinline__ void chain4_body(const ChainP& p, h16_t* const smem, 
   float* const epi = aux + AUX_F;                                     // [EPI_F] epilogue operands (E4_*)
   const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6), l15 = lane & 15, g = lane >> 4;
   const int W4 = wid >> 1, J0 = wid & 1;
+#ifdef A2P_STAMPS   // diagnostic build (scratch/phase_probe4.py): 100 MHz phase stamps of workgroups 0 and 101 into p.fin_out
+  auto stamp = [&](int i) __attribute__((always_inline)) {
+    if (tid == 0 && (blockIdx.x == 0 || blockIdx.x == 101)) reinterpret_cast<unsigned long long*>(p.fin_out)[(blockIdx.x ? 32 : 0) + i] = wall_clock64();
+  };
+#else
+  auto stamp = [&](int) __attribute__((always_inline)) {};
+#endif
+  stamp(0);
 
   // ---- weight stream: register ring of PF half stages --------------------------------------------------------------------
   uint32_t woff = (uint32_t)(wid * 64 + lane) * 16;   // byte offset of this lane's 16 bytes of the next half stage to load
@@ -186,6 +198,7 @@ __device__ __forceinline__ void chain4_body(const ChainP& p, h16_t* const smem, 
   for (int i = 0; i < PF; ++i) w_issue(i);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the DMA pieces have landed for this wave (once per kernel: the ring's first loads too)
   chain_bar();                                        // ... and for every other wave
+  stamp(1);
 
   // ---- epilogues ---------------------------------------------------------------------------------------------------------
   // FiLM affine + residual, IN PLACE: R[t][mt] = x_old + (scale + 1) * (R + bias) + shift   (transformer_modules.py:122-124,193).
@@ -318,11 +331,14 @@ __device__ __forceinline__ void chain4_body(const ChainP& p, h16_t* const smem, 
       for (int t = 0; t < NT; ++t) st4(p.x, xb + t * ts, R[t][mt]);
     }
   };
-  // D-deep GEMM over NPAIR pairs of output tiles with a 16-bit store per pair (kernels_chain.h gemm_store, 8-wave forms): row-major
-  // pairs leave as 16 rows x 64 contiguous bytes per instruction through a wave-private slice of the idle hidden-chunk buffer,
-  // V^T tiles as 16-byte pieces of 8 consecutive frames.  Fully unrolled: across a loop back-edge hipcc waits for ALL ring loads.
-  auto gemm_store = [&](auto npair_c, const float* bias_lds, h16_t* out, int64_t ldo, auto transposed_c) __attribute__((always_inline)) {
-    constexpr int NPAIR = decltype(npair_c)::value;
+  // D-deep GEMM over NGRP groups of FOUR output tiles with 16-bit stores (kernels_chain.h gemm_store, 8-wave forms): the two tile
+  // pairs of a group leave as 16 rows x 64 contiguous bytes per instruction through a wave-private slice of the idle hidden-chunk
+  // buffer (paired column map), V^T tiles as 16-byte pieces of 8 consecutive frames.  Groups of four, not pairs: every burst of stores
+  // sits in front of the ring's next loads in the (in-order) memory queue, i.e. a store acknowledgement -- 1-3 us at B=32 -- is exposed
+  // per burst whenever the ring (8 half stages = 0.6 us of MFMAs) runs dry behind it: first version, pairs, [Q|K] phase 27.8 us for a
+  // 10 us GEMM (profiles/r05_tall_chain_phase_stamps_v0.txt).  Fully unrolled: across a loop back-edge hipcc waits for ALL ring loads.
+  auto gemm_store = [&](auto ngrp_c, const float* bias_lds, h16_t* out, int64_t ldo, auto transposed_c) __attribute__((always_inline)) {
+    constexpr int NGRP = decltype(ngrp_c)::value;
     constexpr bool TR = decltype(transposed_c)::value;
     constexpr int VP = (CW * BM / 8 + 63) / 64;
     h16_t* const stg = panelH + wid * (CW * BM);
@@ -338,11 +354,11 @@ __device__ __forceinline__ void chain4_body(const ChainP& p, h16_t* const smem, 
       }
     }
 #pragma unroll
-    for (int pr = 0; pr < NPAIR; ++pr) {
-      f32x4 acc[2][MT];
+    for (int gr = 0; gr < NGRP; ++gr) {
+      f32x4 acc[4][MT];
 #pragma unroll
-      for (int h = 0; h < 2; ++h) {
-        const int t = 2 * pr + h;
+      for (int h = 0; h < 4; ++h) {
+        const int t = 4 * gr + h;
         if constexpr (!TR) {
           const f32x4 b = *reinterpret_cast<const f32x4*>(bias_lds + obase(t) + g * 4);
 #pragma unroll
@@ -354,31 +370,33 @@ __device__ __forceinline__ void chain4_body(const ChainP& p, h16_t* const smem, 
         }
       }
       __builtin_amdgcn_sched_barrier(0);
-      gemm(std::integral_constant<int, 2>{}, std::integral_constant<int, KC>{}, acc, panelA, D, TR);
+      gemm(std::integral_constant<int, 4>{}, std::integral_constant<int, KC>{}, acc, panelA, D, TR);
       __builtin_amdgcn_sched_barrier(0);
       if constexpr (!TR) {
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt) {
-          const f32x4 v0 = acc[0][mt], v1 = acc[1][mt];
-          const h16x4 lo = {(h16_t)v0[0], (h16_t)v0[1], (h16_t)v0[2], (h16_t)v0[3]};
-          const h16x4 hi = {(h16_t)v1[0], (h16_t)v1[1], (h16_t)v1[2], (h16_t)v1[3]};
-          const int hsw = (l15 >> 2) & 1;   // half-row swizzle of the [16][32] staging tile (kernels_chain.h)
-          asm volatile("ds_write_b64 %0, %2\n\tds_write_b64 %1, %3" ::"v"(lds_off(stg + l15 * 32 + hsw * 16 + g * 4)),
-                       "v"(lds_off(stg + l15 * 32 + (hsw ^ 1) * 16 + g * 4)), "v"(lo), "v"(hi)
-                       : "memory");
-          h16x8 w;
-          const int prow = lane >> 2, pp = lane & 3;
-          asm volatile("s_waitcnt lgkmcnt(0)\n\tds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)"
-                       : "=v"(w)
-                       : "v"(lds_off(stg + prow * 32 + (((pp >> 1) ^ ((prow >> 2) & 1)) * 2 + (pp & 1)) * 8))
-                       : "memory");
-          const int m = m0 + mt * 16 + (lane >> 2);
-          if (m < p.M)
-            *reinterpret_cast<h16x8*>(reinterpret_cast<char*>(out) + (((uint32_t)m * (uint32_t)ldo + (uint32_t)(obase(2 * pr) + (lane & 3) * 8)) << 1)) = w;
-        }
+        for (int pr = 0; pr < 2; ++pr)
+#pragma unroll
+          for (int mt = 0; mt < MT; ++mt) {
+            const f32x4 v0 = acc[2 * pr][mt], v1 = acc[2 * pr + 1][mt];
+            const h16x4 lo = {(h16_t)v0[0], (h16_t)v0[1], (h16_t)v0[2], (h16_t)v0[3]};
+            const h16x4 hi = {(h16_t)v1[0], (h16_t)v1[1], (h16_t)v1[2], (h16_t)v1[3]};
+            const int hsw = (l15 >> 2) & 1;   // half-row swizzle of the [16][32] staging tile (kernels_chain.h)
+            asm volatile("ds_write_b64 %0, %2\n\tds_write_b64 %1, %3" ::"v"(lds_off(stg + l15 * 32 + hsw * 16 + g * 4)),
+                         "v"(lds_off(stg + l15 * 32 + (hsw ^ 1) * 16 + g * 4)), "v"(lo), "v"(hi)
+                         : "memory");
+            h16x8 w;
+            const int prow = lane >> 2, pp = lane & 3;
+            asm volatile("s_waitcnt lgkmcnt(0)\n\tds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)"
+                         : "=v"(w)
+                         : "v"(lds_off(stg + prow * 32 + (((pp >> 1) ^ ((prow >> 2) & 1)) * 2 + (pp & 1)) * 8))
+                         : "memory");
+            const int m = m0 + mt * 16 + (lane >> 2);
+            if (m < p.M)
+              *reinterpret_cast<h16x8*>(reinterpret_cast<char*>(out) + (((uint32_t)m * (uint32_t)ldo + (uint32_t)(obase(4 * gr + 2 * pr) + (lane & 3) * 8)) << 1)) = w;
+          }
       } else {
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {
+        for (int h = 0; h < 4; ++h) {
 #pragma unroll
           for (int mt = 0; mt < MT; ++mt) {
             const f32x4 v = acc[h][mt];
@@ -390,7 +408,7 @@ __device__ __forceinline__ void chain4_body(const ChainP& p, h16_t* const smem, 
           for (int i = 0; i < VP; ++i) {
             h16x8 v;
             asm volatile("ds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(lds_off(stg + (lane + 64 * i) * 8)) : "memory");
-            if (vok[i]) *reinterpret_cast<h16x8*>(reinterpret_cast<char*>(out) + ((voff[i] + (uint32_t)obase(2 * pr + h) * (uint32_t)ldo) << 1)) = v;
+            if (vok[i]) *reinterpret_cast<h16x8*>(reinterpret_cast<char*>(out) + ((voff[i] + (uint32_t)obase(4 * gr + h) * (uint32_t)ldo) << 1)) = v;
           }
         }
       }
@@ -408,56 +426,104 @@ __device__ __forceinline__ void chain4_body(const ChainP& p, h16_t* const smem, 
   __builtin_amdgcn_sched_barrier(0);
   gemm(std::integral_constant<int, NT>{}, std::integral_constant<int, KC>{}, R, panelA, D, false);   // out_proj of the attention that produced `ain`
   __builtin_amdgcn_sched_barrier(0);
+  stamp(2);
   film_res(R, E4_BIAS_O, E4_FILM_O, p.xsrc ? p.xsrc : p.x, p.x_in_tiled, true);
+  stamp(3);
   ln_stats(R);   // (its barriers also order the panel rewrite behind every wave's out_proj reads)
+  stamp(4);
   if constexpr (MODE == CHAIN_MID) {
     ln_write(R, E4_LNA_G, Tt);
-    gemm_store(std::integral_constant<int, NT / 2>{}, aux, p.q_out, p.ld_q, F);
+    stamp(5);
+    gemm_store(std::integral_constant<int, 1>{}, aux, p.q_out, p.ld_q, F);
+    stamp(6);
     store_x(R, p.x_out_tiled);
+    stamp(7);
   } else {
+    // 64 / 80-row panels: the rows are PARKED (stored, re-read) around the feed-forward block and again around the [Q|K] GEMM -- 80 registers
+    // per lane that the linear2 partials / the four-tile groups need.  At 48 rows they stay in registers from load to the final
+    // store (X), as in kernels_chain.h: no extra traffic, and no store in front of a GEMM's weight loads.
+    constexpr bool PARK = MT >= 4;   // (64 rows without parking: 91 registers spilled)
     ln_write(R, E4_LNA_G, F);
-    store_x(R, p.x_out_tiled);            // parked: the feed-forward block runs without the residual rows in registers
+    [[maybe_unused]] f32x4 X[PARK ? 1 : NT][PARK ? 1 : MT];
+    if constexpr (PARK) {
+      store_x(R, p.x_out_tiled);
+    } else {
+#pragma unroll
+      for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) X[t][mt] = R[t][mt];
+    }
     __builtin_amdgcn_sched_barrier(0);
-    // Feed forward, split-K over the 8 hidden chunks: linear1 chunk -> GELU -> LDS -> linear2 partial
+    stamp(5);
+    // Feed forward, split-K over the hidden chunks of HLD columns: linear1 chunk (NH tiles, k-chunk-major) -> GELU -> LDS -> linear2
+    // partial.  Fully unrolled: across a loop back-edge hipcc waits for ALL ring loads (one exposed L2 round trip per iteration).
 #pragma unroll
     for (int t = 0; t < NT; ++t)
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt) R[t][mt] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll 2
-    for (int h = 0; h < FT; ++h) {
-      f32x4 acc[1][MT];
-      {
-        const f32x4 b = *reinterpret_cast<const f32x4*>(aux + h * 128 + W4 * 32 + g * 8 + J0 * 4);
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt) acc[0][mt] = b;
+    for (int h = 0; h < FT / NH; ++h) {
+      f32x4 acc[NH][MT];
+#pragma unroll
+      for (int tt = 0; tt < NH; ++tt) {
+        const f32x4 b = *reinterpret_cast<const f32x4*>(aux + (h * NH + tt) * 128 + W4 * 32 + g * 8 + J0 * 4);
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) acc[tt][mt] = b;
       }
       __builtin_amdgcn_sched_barrier(0);
-      gemm(std::integral_constant<int, 1>{}, std::integral_constant<int, KC>{}, acc, panelA, D, false);
+      gemm(std::integral_constant<int, NH>{}, std::integral_constant<int, KC>{}, acc, panelA, D, false);
       __builtin_amdgcn_sched_barrier(0);
       if (h > 0) chain_bar();   // every wave finished the linear2 partial of the previous chunk
 #pragma unroll
-      for (int mt = 0; mt < MT; ++mt) {
-        const f32x4 v = acc[0][mt];
-        *reinterpret_cast<h16x4*>(panelH + (mt * 16 + l15) * HLD + pswz) =
-            h16x4{(h16_t)act_gelu_fast(v[0]), (h16_t)act_gelu_fast(v[1]), (h16_t)act_gelu_fast(v[2]), (h16_t)act_gelu_fast(v[3])};
-      }
+      for (int tt = 0; tt < NH; ++tt)
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+          const f32x4 v = acc[tt][mt];
+          *reinterpret_cast<h16x4*>(panelH + (mt * 16 + l15) * HLD + tt * 128 + pswz) =
+              h16x4{(h16_t)act_gelu_fast(v[0]), (h16_t)act_gelu_fast(v[1]), (h16_t)act_gelu_fast(v[2]), (h16_t)act_gelu_fast(v[3])};
+        }
       chain_bar();              // the hidden chunk is complete
       __builtin_amdgcn_sched_barrier(0);
-      gemm(std::integral_constant<int, NT>{}, std::integral_constant<int, 4>{}, R, panelH, HLD, false);
+      gemm(std::integral_constant<int, NT>{}, std::integral_constant<int, HLD / 32>{}, R, panelH, HLD, false);
       __builtin_amdgcn_sched_barrier(0);
     }
-    // the parked rows come back from where store_x left them (same workgroup, same lanes: program order makes them visible)
-    film_res(R, E4_BIAS_2, E4_FILM_F, p.x, p.x_out_tiled, false);
+    stamp(6);
+    if constexpr (PARK) {
+      // the parked rows come back from where store_x left them (same workgroup, same lanes: program order makes them visible)
+      film_res(R, E4_BIAS_2, E4_FILM_F, p.x, p.x_out_tiled, false);
+    } else {   // FiLM affine + residual on the register rows (film_res's arithmetic, operands from the LDS block)
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+        const f32x4 b = *reinterpret_cast<const f32x4*>(epi + E4_BIAS_2 + col_of(t));
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+          const f32x4 sc = *reinterpret_cast<const f32x4*>(epi + E4_FILM_F + fsel[mt] + col_of(t));
+          const f32x4 sh = *reinterpret_cast<const f32x4*>(epi + E4_FILM_F + fsel[mt] + 512 + col_of(t));
+          const f32x4 y = R[t][mt] + b, s1 = sc + 1.0f;
+          f32x4 xr = X[t][mt];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) xr[e] += fmaf(s1[e], y[e], sh[e]);
+          R[t][mt] = xr;
+        }
+      }
+    }
+    stamp(7);
     // next layer's PRE work: norm1 -> rotary -> [Q|K] ; norm1 -> V^T     (aux: bias_qk right behind bias_1, then bias_v)
     ln_stats(R);
     ln_write(R, E4_LNB_G, Tt);
-    store_x(R, p.x_out_tiled);            // the finished rows; the 16*MT row registers are free during the [Q|K] GEMM
+    stamp(8);
+    if constexpr (PARK) store_x(R, p.x_out_tiled);   // the finished rows; their registers are free during the [Q|K] GEMM
     __builtin_amdgcn_sched_barrier(0);
-    gemm_store(std::integral_constant<int, NT>{}, aux + FT * 128, p.qk_out, p.ld_qk, F);
+    stamp(9);
+    gemm_store(std::integral_constant<int, 2>{}, aux + FT * 128, p.qk_out, p.ld_qk, F);
     chain_bar();                          // every wave is done reading the rotated panel
-    load_x(R, p.x, p.x_out_tiled);        // back from where store_x left them
+    stamp(10);
+    if constexpr (PARK) load_x(R, p.x, p.x_out_tiled);   // back from where store_x left them
     ln_write(R, E4_LNB_G, F);
-    gemm_store(std::integral_constant<int, NT / 2>{}, aux + FT * 128 + 2 * D, p.vt_out, p.ld_vt, Tt);
+    stamp(11);
+    gemm_store(std::integral_constant<int, 1>{}, aux + FT * 128 + 2 * D, p.vt_out, p.ld_vt, Tt);
+    if constexpr (!PARK) store_x(R, p.x_out_tiled);  // last: loads return in issue order behind stores
+    stamp(12);
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the ring's run-ahead loads target this wave's registers
 }

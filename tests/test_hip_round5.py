@@ -35,7 +35,13 @@ def test_tall_chain_kernels_are_bit_identical_to_the_48_row_kernels(dev, B, T, m
     cfg = ClassifierFreeSampleModel(model.to(dev).eval())
     y = {"cond_embed": inp["cond_embed"].to(dev), "scale": torch.full((B,), 10.0, device=dev)}
     t = torch.tensor(([901, 417, 33, 650] * 4)[:B], device=dev)
-    outs = {}
+    import ctypes as C
+
+    def tall_launches():
+        n = C.c_int64(0)
+        _lib.check(model._lib().a2p_debug_read(model._ctx, b"chain4_launches", C.byref(n), 8), "a2p_debug_read")
+        return int(n.value)
+    outs, launched = {}, {}
     for name, v in (("gen1", "1"), ("tall", "4")):
         monkeypatch.setenv("A2P_CHAIN_V", v)
         if mt:
@@ -44,12 +50,17 @@ def test_tall_chain_kernels_are_bit_identical_to_the_48_row_kernels(dev, B, T, m
             monkeypatch.delenv("A2P_CHAIN_MT", raising=False)
             if 2 * B * T < 1100:
                 monkeypatch.setenv("A2P_CHAIN_ROWS", "1")
+        before = tall_launches() if model._ctx is not None else 0
         outs[name] = cfg(inp["x_T"].to(dev), t, y).cpu()
+        launched[name] = tall_launches() - before
     for k in ("A2P_CHAIN_V", "A2P_CHAIN_MT", "A2P_CHAIN_ROWS"):
         monkeypatch.delenv(k, raising=False)
     model.check_finite()
     model.release()
     diff = float((outs["tall"] - outs["gen1"]).abs().max())
     record(f"tall_chain/{precision}/B{B}_T{T}_mt{mt}", max_abs_diff=diff)
+    # the two runs really were different kernels: 8 MID + 7 POST launches of the tall family per guided forward (the last layer's POST
+    # carries final_layer and stays with kernels_chain.h), none under A2P_CHAIN_V=1
+    assert launched == {"gen1": 0, "tall": 15}, launched
     assert torch.isfinite(outs["tall"]).all()
     assert torch.equal(outs["tall"], outs["gen1"]), diff
