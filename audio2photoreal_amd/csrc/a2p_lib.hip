@@ -162,7 +162,7 @@ struct A2POpts {
   int ksplit_qt = 0;        // A2P_KSPLIT_QT=1|2: 16-query tiles per wave of the key-split attention
   int force_ksplit = 0;     // A2P_ATTN_KSPLIT=1: every 16-bit attention launch takes the key-split kernel (tests)
   int chain_v = 0;          // A2P_CHAIN_V=4: tall chain kernels (kernels_chain4.h) wherever their contract holds; A2P_CHAIN_V=1: never; 0: the
-                            // library's rule (launch_chain: forwards of >= 16 sequences of the face model)
+                            // faster of the two families ON THIS BOX, measured during the first forwards of a size (chain_pick_family)
   int attn2 = 0;            // A2P_ATTN2=1: the query-split 16-bit attention launches take attn2_kernel (kernels_attn2.h: one 8-wave workgroup per CU,
                             // 48 + 32 queries per SIMD, unit-level software pipeline); 0: attn_kernel
   int no_fused_kf = 0;      // A2P_NO_FUSED_KF=1: body model: MID2 | keyframe attention | POST as three launches instead of one (A/B, tests)
@@ -226,6 +226,8 @@ struct a2p_ctx {
     std::vector<std::tuple<int, hipEvent_t, hipEvent_t>> samples;
   };
   std::map<int64_t, ChainTune> ch_tune;
+  std::map<int64_t, ChainTune> ch_tune4;   // per forward size: kernels_chain.h (1) or kernels_chain4.h (4), measured in situ (chain_pick_family)
+  int ch_fam_mid = 4, ch_fam_post = 4;     // chain kernel families of the forward being enqueued (MID kernels, POST kernels)
   Buf hidden, kc, vtc, k2c, vt2c, slot_cond, slot_unc, slot_cfg;
   Buf nonfinite;         // device flag of a2p_check_finite (one int, OR-ed by step_tail_kernel)
   Buf clk;               // A2P_CHAIN_CLK=1: 64 chain launches x 8 blocks x {memtime, realtime} x {begin, end}
@@ -684,8 +686,9 @@ extern "C" int a2p_ctx_destroy(a2p_ctx* c) {
   for (auto& b : c->ch_stream) buf_free(b);
   for (auto& b : c->ch_stream4) buf_free(b);
   for (auto& b : c->ch_stream4w) buf_free(b);
-  for (auto& kv : c->ch_tune)
-    for (auto& sm : kv.second.samples) { (void)hipEventDestroy(std::get<1>(sm)); (void)hipEventDestroy(std::get<2>(sm)); }
+  for (auto* m : {&c->ch_tune, &c->ch_tune4})
+    for (auto& kv : *m)
+      for (auto& sm : kv.second.samples) { (void)hipEventDestroy(std::get<1>(sm)); (void)hipEventDestroy(std::get<2>(sm)); }
   for (auto& b : c->ch_aux) buf_free(b);
   for (void* slab : c->arena.slabs) (void)hipFree(slab);
   for (int i = 0; i < 8; ++i) {

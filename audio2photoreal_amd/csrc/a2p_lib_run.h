@@ -340,6 +340,54 @@ static int chain_pick_nw(a2p_ctx* c, int64_t rows, hipEvent_t* e0, hipEvent_t* e
   return t.choice;
 }
 
+// Chain kernel FAMILY of a forward, per chain: kernels_chain.h (1) or kernels_chain4.h (4) for the MID kernels and for the POST
+// kernels.  The two families produce the same bits (tests/test_hip_round5.py), so the choice is invisible in the results -- and
+// which one is faster depends on the BOX and on the chain: on most MI355X boxes leased this round the tall family leads everywhere
+// (B=8: 552 -> 594 steps/s; B=16 +13 %, B=32 +6 %); on a minority -- the boxes that also run the memory-heavy PRE kernel 30 % slow,
+// DESIGN.md section 6 "box-to-box spread" -- the tall POST kernel with its parked rows LOSES (B=32: 330 vs 278 us) while the tall MID
+// kernel still wins (88 vs 106 us) (profiles/r05_tall_chain_same_box_*.txt, r05_family_calibration.txt).  So it is measured in situ,
+// like round 3's workgroup shape: forward 0 of a size is warm-up, forwards 1..8 run the four (MID, POST) combinations twice with an
+// event pair around the decoder stack, forward 9 keeps the fastest.  A2P_CHAIN_V=1 | 4 forces one family for both.
+static const int kFamConfigs[4][2] = {{1, 1}, {4, 4}, {4, 1}, {1, 4}};
+static const int kTuneForwards4 = 9;
+static void chain_pick_family(a2p_ctx* c, int64_t rows, hipEvent_t* e0, hipEvent_t* e1) {
+  *e0 = *e1 = nullptr;
+  auto set = [&](int cfg) { c->ch_fam_mid = kFamConfigs[cfg][0]; c->ch_fam_post = kFamConfigs[cfg][1]; };
+  if (c->opt.chain_v == 1 || c->ch_stream4.empty() || c->d != 512 || c->ch_nw != 8) return set(0);
+  if (c->opt.chain_v == 4) return set(1);
+  auto& t = c->ch_tune4[rows];
+  if (t.choice) return set(t.choice - 1);
+  const int call = t.calls++;
+  if (call < kTuneForwards4) {
+    const int cfg = call == 0 ? 1 : (call - 1) & 3;
+    if (call >= 1 && hipEventCreate(e0) == hipSuccess && hipEventCreate(e1) == hipSuccess) t.samples.emplace_back(cfg, *e0, *e1);
+    else *e0 = *e1 = nullptr;
+    return set(cfg);
+  }
+  double sum[4] = {0, 0, 0, 0};
+  int cnt[4] = {0, 0, 0, 0};
+  for (auto& sm : t.samples) {
+    float ms = 0.f;
+    if (hipEventSynchronize(std::get<2>(sm)) == hipSuccess && hipEventElapsedTime(&ms, std::get<1>(sm), std::get<2>(sm)) == hipSuccess) {
+      sum[std::get<0>(sm)] += ms;
+      ++cnt[std::get<0>(sm)];
+    }
+    (void)hipEventDestroy(std::get<1>(sm));
+    (void)hipEventDestroy(std::get<2>(sm));
+  }
+  t.samples.clear();
+  int best = 1;   // (no measurement: the tall family)
+  double bt = 1e30;
+  for (int i = 0; i < 4; ++i)
+    if (cnt[i] && sum[i] / cnt[i] < bt) { bt = sum[i] / cnt[i]; best = i; }
+  t.choice = best + 1;
+  if (c->opt.tune_verbose)
+    fprintf(stderr, "[a2p] chain kernel families (MID, POST) for %lld rows, ms per decoder stack: (1,1) %.3f  (4,4) %.3f  (4,1) %.3f  (1,4) %.3f -> (%d,%d)\n",
+            (long long)rows, cnt[0] ? sum[0] / cnt[0] : -1.0, cnt[1] ? sum[1] / cnt[1] : -1.0, cnt[2] ? sum[2] / cnt[2] : -1.0,
+            cnt[3] ? sum[3] / cnt[3] : -1.0, kFamConfigs[best][0], kFamConfigs[best][1]);
+  set(best);
+}
+
 // Tall chain kernels (kernels_chain4.h): 64 / 80-row panels, weights straight into registers, epilogue operands from LDS.
 // Contract: face model (d = 512), MID or POST-with-successor, FiLM present, frame count a multiple of 8 and >= the panel height.
 // Rule: forwards of >= 16 sequences (B >= 8 under guidance is 16 sequences of 600 frames = 37.5 rows per CU: the 48-row panels of
@@ -349,9 +397,7 @@ static bool chain4_wanted(const a2p_ctx* c, int mode, const ChainP& p) {
   if (!(mode == CHAIN_MID || (mode == CHAIN_POST && p.has_next == 1))) return false;
   if (p.film_o == nullptr || (mode == CHAIN_POST && p.film_f == nullptr)) return false;
   if ((p.rows_per_seq & 7) || p.rows_per_seq < 80) return false;
-  // faster than kernels_chain.h at every size measured (profiles/r05_tall_chain_*: B=8 556 -> 583 steps/s with 48-row panels that
-  // keep their rows in registers, B=16 330 -> 372 and B=32 188 -> 198 with 80-row panels): the default wherever the contract holds
-  return true;
+  return (mode == CHAIN_MID ? c->ch_fam_mid : c->ch_fam_post) == 4;   // the family of this forward's chain (chain_pick_family: forced, or measured on this box)
 }
 static int launch_chain4(a2p_ctx* c, int mode, const ChainP& p0, hipStream_t s) {
   ChainP p = p0;
@@ -364,7 +410,7 @@ static int launch_chain4(a2p_ctx* c, int mode, const ChainP& p0, hipStream_t s) 
       if (cost < best) { best = cost; mt = m; }
     }
   }
-  p.stream = (mode == CHAIN_POST && mt <= 4) ? p.stream4w : p.stream4;   // POST: the stream of the panel height's hidden-chunk width
+  p.stream = (mode == CHAIN_POST && mt <= 4) ? p.stream4w : p.stream4;   // POST: the stream of the panel height's hidden-chunk width (Chain4Lds::HC)
   const int grid = (p.M + 16 * mt - 1) / (16 * mt);
   ++c->ch4_launches;
   KernelTimer kt(c, A2P_KERNEL_CHAIN, mode == CHAIN_MID ? A2P_KERNEL_CHAIN_MID : A2P_KERNEL_CHAIN_POST);
@@ -893,6 +939,8 @@ static int forward_body(a2p_ctx* c, const float* x_in, const int64_t* t_orig, in
   hipEvent_t tune0 = nullptr, tune1 = nullptr;
   if (use_chain) {
     c->ch_nw = chain_pick_nw(c, (int64_t)N * T, &tune0, &tune1);
+    if (!tune0) chain_pick_family(c, (int64_t)N * T, &tune0, &tune1);   // (one calibration at a time)
+    else c->ch_fam_mid = c->ch_fam_post = 1;
     if (tune0) HIPCHK(hipEventRecord(tune0, s));
   }
   CrossKV kv, kv2;
@@ -1355,6 +1403,11 @@ extern "C" int a2p_debug_read(a2p_ctx* c, const char* name, void* host, int64_t 
   if (n == "chain_nw") {   // int32: waves per chain workgroup of the last chain forward (4 | 8; bench.py reports it)
     ARG(bytes >= 4, "chain_nw is one int32");
     *reinterpret_cast<int32_t*>(host) = c->ch_nw;
+    return 0;
+  }
+  if (n == "chain_family") {   // int32: chain kernel family of the last chain forward (10 x MID + POST; 1 = kernels_chain.h, 4 = kernels_chain4.h)
+    ARG(bytes >= 4, "chain_family is one int32");
+    *reinterpret_cast<int32_t*>(host) = c->ch_fam_mid * 10 + c->ch_fam_post;   // 11 | 44 | 41 | 14
     return 0;
   }
   if (n == "chain4_launches") {   // int64: launches of the tall chain kernels (kernels_chain4.h) on this context so far (tests, bench)

@@ -70,6 +70,21 @@ def box_record(dev):
     rec = {"name": pr.name, "gcn_arch": getattr(pr, "gcnArchName", None), "cus": pr.multi_processor_count,
            "hbm_gb": round(pr.total_memory / 2 ** 30, 1), "l2_mb": round(getattr(pr, "L2_cache_size", 0) / 2 ** 20, 1),
            "clock_mhz": getattr(pr, "clock_rate", 0) // 1000 or None, "mem_clock_mhz": getattr(pr, "memory_clock_rate", 0) // 1000 or None}
+    try:   # what the memory system of THIS box delivers: 1 GiB device-to-device copies (read + write), best of 5
+        n = 1 << 28
+        a, b = torch.empty(n, dtype=torch.float32, device=dev), torch.empty(n, dtype=torch.float32, device=dev)
+        a.fill_(1.0)
+        best = 1e9
+        for _ in range(5):
+            torch.cuda.synchronize(dev)
+            t0 = time.perf_counter()
+            b.copy_(a)
+            torch.cuda.synchronize(dev)
+            best = min(best, time.perf_counter() - t0)
+        rec["hbm_copy_gbs"] = round(2 * 4 * n / best / 1e9, 1)
+        del a, b
+    except Exception as e:   # noqa: BLE001 -- a report field
+        rec["hbm_copy_gbs"] = f"unavailable ({type(e).__name__})"
     for key, cmd in (("smi", ["rocm-smi", "--showclocks", "--showpower", "--showmaxpower", "--showperflevel", "--showcomputepartition",
                               "--showmemorypartition", "--json"]),):
         try:
@@ -255,6 +270,19 @@ def chain_workgroup_waves(case):
     return int(nw.value)
 
 
+def chain_family(case):
+    """Chain kernel family the library settled on for this workload on this box (two digits, MID then POST: 1 = kernels_chain.h, 4 = the tall kernels_chain4.h;
+    csrc/a2p_lib_run.h chain_pick_family: measured during the first forwards; both produce identical bits)."""
+    import ctypes as C
+    from audio2photoreal_amd import _lib
+    v = C.c_int32(0)
+    try:
+        _lib.check(case.model._lib().a2p_debug_read(case.model._ctx, b"chain_family", C.byref(v), 4), "a2p_debug_read")
+    except Exception:   # noqa: BLE001 -- a report field
+        return None
+    return int(v.value)
+
+
 def leg_record(case, steps, warmup, repeats, ksteps=3):
     """Sub-record of a secondary workload (same measurement as the headline, fewer fields)."""
     case.setup()
@@ -268,7 +296,8 @@ def leg_record(case, steps, warmup, repeats, ksteps=3):
             "decoder_tflops": round(case.step_flops() * steps / dt / 1e12, 2),
             "decoder_mfma_frac": round(case.step_flops() * steps / dt / 1e12 / peak, 4),
             "roofline": roofline, "kernels": kernels, "prepare_s": round(case.prepare_s, 4),
-            "chain_workgroup_waves": chain_workgroup_waves(case) if "chain" in kernels else None}
+            "chain_workgroup_waves": chain_workgroup_waves(case) if "chain" in kernels else None,
+            "chain_family": chain_family(case) if "chain" in kernels else None}
 
 
 # ----------------------------------------------------------------------------------------------------------------------
@@ -786,6 +815,7 @@ def main():
         kernels, roofline = kernel_breakdown(case, min(a.steps, 5))
         if "chain" in kernels:
             roofline["chain_workgroup_waves"] = chain_workgroup_waves(case)
+            roofline["chain_family"] = chain_family(case)
         # HBM bytes per launch of the dominant class from the rocprofv3 PMC passes (FETCH_SIZE doubled per the gfx950 note of
         # MI355X_MICROARCH.md + WRITE_SIZE; scratch/run_pmc.sh writes the file) -- null when not collected for this workload
         tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
