@@ -224,8 +224,7 @@ static int chain_build_streams(a2p_ctx* c, hipStream_t s) {
       pk4_gemm(m4, c->wt.at(pf(l) + "self_attn.out_proj.weight").p, d, d, 0, d, 0, 4);
       pk4_gemm(m4, c->wt.at(pf(l) + "multihead_attn.in_proj_weight").p, d, d, 0, d, 1, 4);   // rows [0, d): the query projection, one group of four tiles
       CHK(chain4_pack(c, c->ch_stream4[ch_index(l, CH_MID)], m4, s));
-      if (l + 1 < L) {
-        const Buf& inw = c->wt.at(pf(l + 1) + "self_attn.in_proj_weight");
+      if (l + 1 < L || c->tail32) {   // (the last layer too, unless final_layer is fused into its POST kernel: A2P_TAIL16)
         for (int hc = 128; hc <= 256; hc += 128) {   // hidden chunk of the feed-forward block: 128 (80-row panels) | 256 (<= 64 rows): Chain4Lds::HC
           std::vector<ChainPackDesc> q4;
           pk4_gemm(q4, c->wt.at(pf(l) + "multihead_attn.out_proj.weight").p, d, d, 0, d, 0, 4);
@@ -234,8 +233,11 @@ static int chain_build_streams(a2p_ctx* c, hipStream_t s) {
             pk4_gemm(q4, w1.p, d, ff, 0, d, 0, nh, h * nh, nh);       // linear1, hidden columns [hc h, hc h + hc): nh tiles, k-chunk-major
             pk4_gemm(q4, w2.p, ff, d, h * hc, hc, 0, 4);              // linear2 partial over that hidden chunk, 4 output tiles
           }
-          pk4_gemm(q4, inw.p, d, 2 * d, 0, d, 1, 4);                  // [Q|K] of the next layer, in groups of four tiles
-          pk4_gemm(q4, c->offT(inw, (int64_t)2 * d * d), d, d, 0, d, 1, 4);   // V
+          if (l + 1 < L) {
+            const Buf& inw = c->wt.at(pf(l + 1) + "self_attn.in_proj_weight");
+            pk4_gemm(q4, inw.p, d, 2 * d, 0, d, 1, 4);                  // [Q|K] of the next layer, in groups of four tiles
+            pk4_gemm(q4, c->offT(inw, (int64_t)2 * d * d), d, d, 0, d, 1, 4);   // V
+          }
           CHK(chain4_pack(c, hc == 128 ? c->ch_stream4[ch_index(l, CH_POST)] : c->ch_stream4w[l], q4, s));
         }
       }
@@ -394,7 +396,7 @@ static void chain_pick_family(a2p_ctx* c, int64_t rows, hipEvent_t* e0, hipEvent
 // kernels_chain.h are one round there; from 75 rows per CU on -- B = 16 -- an 80-row panel is one round where 48-row panels are two).
 static bool chain4_wanted(const a2p_ctx* c, int mode, const ChainP& p) {
   if (c->opt.chain_v == 1 || p.stream4 == nullptr || c->d != 512 || c->ch_nw != 8) return false;
-  if (!(mode == CHAIN_MID || (mode == CHAIN_POST && p.has_next == 1))) return false;
+  if (!(mode == CHAIN_MID || (mode == CHAIN_POST && p.has_next <= 1))) return false;   // (has_next == 2: final_layer fused, kernels_chain.h only)
   if (p.film_o == nullptr || (mode == CHAIN_POST && p.film_f == nullptr)) return false;
   if ((p.rows_per_seq & 7) || p.rows_per_seq < 80) return false;
   return (mode == CHAIN_MID ? c->ch_fam_mid : c->ch_fam_post) == 4;   // the family of this forward's chain (chain_pick_family: forced, or measured on this box)

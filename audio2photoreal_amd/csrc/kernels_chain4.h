@@ -445,8 +445,10 @@ __device__ __forceinline__ void chain4_body(const ChainP& p, h16_t* const smem, 
     constexpr bool PARK = MT >= 4;   // (64 rows without parking: 91 registers spilled)
     ln_write(R, E4_LNA_G, F);
     [[maybe_unused]] f32x4 X[PARK ? 1 : NT][PARK ? 1 : MT];
+    // (parked in the tiled layout whatever the final layout is: a 16-row block occupies the same bytes in both, and the workgroup owns
+    // whole blocks -- the last layer writes its rows back row-major)
     if constexpr (PARK) {
-      store_x(R, p.x_out_tiled);
+      store_x(R, 1);
     } else {
 #pragma unroll
       for (int t = 0; t < NT; ++t)
@@ -490,7 +492,7 @@ __device__ __forceinline__ void chain4_body(const ChainP& p, h16_t* const smem, 
     stamp(6);
     if constexpr (PARK) {
       // the parked rows come back from where store_x left them (same workgroup, same lanes: program order makes them visible)
-      film_res(R, E4_BIAS_2, E4_FILM_F, p.x, p.x_out_tiled, false);
+      film_res(R, E4_BIAS_2, E4_FILM_F, p.x, 1, false);
     } else {   // FiLM affine + residual on the register rows (film_res's arithmetic, operands from the LDS block)
 #pragma unroll
       for (int t = 0; t < NT; ++t) {
@@ -508,6 +510,15 @@ __device__ __forceinline__ void chain4_body(const ChainP& p, h16_t* const smem, 
       }
     }
     stamp(7);
+    if (!p.has_next) {   // last decoder layer (final_layer runs on its own exact-island path): the rows go back in the caller's layout
+      // parked rows were re-read in the TILED layout just now and the final layout is row-major: inside a 16-row block the two
+      // layouts put different lanes' data on the same bytes, so no wave may store before every wave has its parked rows back
+      // (first version without this barrier: wrong rows in every parked case, tests/test_hip_round5.py)
+      if constexpr (PARK) chain_bar();
+      store_x(R, p.x_out_tiled);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      return;
+    }
     // next layer's PRE work: norm1 -> rotary -> [Q|K] ; norm1 -> V^T     (aux: bias_qk right behind bias_1, then bias_v)
     ln_stats(R);
     ln_write(R, E4_LNB_G, Tt);
