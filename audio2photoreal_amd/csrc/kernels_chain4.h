@@ -31,6 +31,12 @@
 #pragma clang fp contract(off)
 
 #define CHAIN4_PF 8            // half stages in flight per wave (register ring); every GEMM of a chain consumes a multiple of it
+#ifndef CHAIN4_PF_MID
+#define CHAIN4_PF_MID 8        // ... of the MID kernels (which have registers to spare)
+#endif
+#ifndef CHAIN4_PF_POST3
+#define CHAIN4_PF_POST3 8
+#endif
 #define CHAIN4_HS_ELEMS 4096   // 128 output columns x 32 k: 8 KiB
 
 template <int MT>
@@ -47,6 +53,29 @@ struct Chain4Lds {
 // epilogue block (fp32 offsets)
 enum { E4_BIAS_O = 0, E4_BIAS_2 = 512, E4_LNA_G = 1024, E4_LNA_B = 1536, E4_LNB_G = 2048, E4_LNB_B = 2560, E4_FILM_O = 3072, E4_FILM_F = 5120 };
 // (FiLM blocks: [sequence A: scale 512 | shift 512][sequence B: scale 512 | shift 512])
+
+// compile-time loop (the LDS reads below carry their offsets as instruction immediates)
+template <class F, int... I>
+__device__ __forceinline__ void chain4_static_for_impl(F&& f, std::integer_sequence<int, I...>) { (f(std::integral_constant<int, I>{}), ...); }
+template <int N, class F>
+__device__ __forceinline__ void chain4_static_for(F&& f) { chain4_static_for_impl(f, std::make_integer_sequence<int, N>{}); }
+
+// ds_read_b128 the compiler does not track: no s_waitcnt is inserted for the result -- chain4_lds_wait is the wait
+template <int OFF>
+__device__ __forceinline__ h16x8 chain4_lds_rd(uint32_t addr) {
+  static_assert(OFF >= 0 && OFF < 65536, "ds offset field");
+  h16x8 v;
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF));
+  return v;
+}
+// wait until at most N LDS operations are outstanding; the fragments pass through the statement, so no consumer can be scheduled above it
+template <int N, int MT>
+__device__ __forceinline__ void chain4_lds_wait(h16x8 (&a)[MT]) {
+  static_assert(MT >= 3 && MT <= 5, "panel height");
+  if constexpr (MT == 3) asm volatile("s_waitcnt lgkmcnt(%3)" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]) : "n"(N));
+  else if constexpr (MT == 4) asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]) : "n"(N));
+  else asm volatile("s_waitcnt lgkmcnt(%5)" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]) : "n"(N));
+}
 
 // one half stage of a packed stream: [wave 0..7][lane 0..63][8 k-values] -- lane (l15, g) of wave w gets
 // W[col(w, l15)][k0 + g*8 .. +8], the weight operand of v_mfma_f32_16x16x32 for this k-chunk.  Column ownership as chain_pack_kernel
@@ -66,7 +95,7 @@ __global__ __launch_bounds__(256) void chain4_pack_kernel(const ChainPackDesc* _
 
 template <int MT, int MODE>
 __device__ __forceinline__ void chain4_body(const ChainP& p, h16_t* const smem, const int m0) {
-  constexpr int D = 512, NW = 8, CW = 16, BM = 16 * MT, NT = 4, KC = D / 32, FT = 8, HLD = Chain4Lds<MT>::HC, NH = HLD / 128, PF = CHAIN4_PF;
+  constexpr int D = 512, NW = 8, CW = 16, BM = 16 * MT, NT = 4, KC = D / 32, FT = 8, HLD = Chain4Lds<MT>::HC, NH = HLD / 128, PF = MODE == CHAIN_MID ? CHAIN4_PF_MID : (MT == 3 ? CHAIN4_PF_POST3 : CHAIN4_PF);
   constexpr int AUX_F = Chain4Lds<MT>::AUX_F;
   h16_t* const panelA = smem;
   h16_t* const panelH = panelA + BM * D;
@@ -126,39 +155,89 @@ __device__ __forceinline__ void chain4_body(const ChainP& p, h16_t* const smem, 
   const int pswz = (((W4 * 4 + g) ^ l15) << 3) | (J0 * 4);   // element offset inside a 128-column tile of this lane's 4 output columns
 
   // acc[t][mt] += P[:, 0 : 32*NKC] x (the next NKC*NTG half stages)^T for NTG tiles, k-chunk-major (half stage = c*NTG + t).
-  // The panel fragments of k-chunk c+1 are read while the NTG*MT MFMAs of chunk c issue; ring slots are compile-time.
+  // The panel fragments of k-chunk c+1 are meant to be read while the NTG*MT MFMAs of chunk c issue.  As ordinary loads hipcc
+  // sinks every ds_read_b128 in front of its first MFMA with an s_waitcnt lgkmcnt(0) between them, whatever the source order or
+  // the sched_group_barrier pattern says -- MT exposed LDS round trips per k-chunk, and with one tile per wave (linear1 of the
+  // 80-row POST kernel) the fragment is re-read for every MFMA (profiles/r05_chain4_isa_census.txt: a third of that kernel's MFMAs
+  // sat directly behind such a wait).  ASM_FRAGS: the reads are inline asm, issued one chunk ahead and waited for with a counted
+  // lgkmcnt (the newest MT may still be in flight).  Measured on one box (profiles/r05_chain4_asm_frags_ab.txt): 80-row POST
+  // -4.5 %, but the 48-row kernels and every MID kernel +2..3 % (the second wave of the SIMD already covered the round trips there and
+  // the double-buffered fragments cost registers), so only that kernel takes it.  Ring slots are compile-time.
   // swap = false: D = C^T, lane holds 4 consecutive columns n of row m = l15; swap = true: D = C (transposed V^T store).
-  auto gemm = [&](auto ntg_c, auto nkc_c, auto& acc, const h16_t* P, int pld, bool swap) __attribute__((always_inline)) {
-    constexpr int NTG = decltype(ntg_c)::value, NKC = decltype(nkc_c)::value;
+  auto gemm = [&](auto ntg_c, auto nkc_c, auto pld_c, auto& acc, const h16_t* P, bool swap) __attribute__((always_inline)) {
+    constexpr int NTG = decltype(ntg_c)::value, NKC = decltype(nkc_c)::value, PLD = decltype(pld_c)::value;
     static_assert((NTG * NKC) % PF == 0 && PF % NTG == 0, "ring phase");
-    const char* rp = reinterpret_cast<const char*>(P) + l15 * pld * 2;
-    const int rstep = 32 * pld;   // bytes between the 16-row blocks of a panel
-    h16x8 a[2][MT];
+    constexpr bool ASM_FRAGS = MT == 5 && MODE == CHAIN_POST;
+    if constexpr (ASM_FRAGS) {
+      constexpr int RSTEP = 32 * PLD;   // bytes between the 16-row blocks of a panel
+      const uint32_t rp = lds_off(P) + (uint32_t)(l15 * PLD * 2);
+      uint32_t ab[4];
 #pragma unroll
-    for (int mt = 0; mt < MT; ++mt) a[0][mt] = *reinterpret_cast<const h16x8*>(rp + aswz[0] + mt * rstep);
-#pragma unroll
-    for (int c = 0; c < NKC; ++c) {
-      if (c + 1 < NKC) {
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt)
-          a[(c + 1) & 1][mt] = *reinterpret_cast<const h16x8*>(rp + aswz[(c + 1) & 3] + ((c + 1) >> 2) * 256 + mt * rstep);
-      }
-#pragma unroll
-      for (int t = 0; t < NTG; ++t) {
-        const int slot = (c * NTG + t) % PF;
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt) {
-          if (swap) acc[t][mt] = A2P_MFMA16(a[c & 1][mt], wr[slot], acc[t][mt]);
-          else acc[t][mt] = A2P_MFMA16(wr[slot], a[c & 1][mt], acc[t][mt]);
+      for (int i = 0; i < 4; ++i) ab[i] = rp + aswz[i];
+      h16x8 a[2][MT];
+      auto rd_chunk = [&](auto c_c) __attribute__((always_inline)) {
+        constexpr int C = decltype(c_c)::value;
+        chain4_static_for<MT>([&](auto mt_c) __attribute__((always_inline)) {
+          constexpr int M = decltype(mt_c)::value, OFF = (C >> 2) * 256 + M * RSTEP;
+          if constexpr (OFF < 65536) a[C & 1][M] = chain4_lds_rd<OFF>(ab[C & 3]);
+          else a[C & 1][M] = chain4_lds_rd<OFF - 65536>(ab[C & 3] + 65536u);
+        });
+      };
+      rd_chunk(std::integral_constant<int, 0>{});
+      chain4_static_for<NKC>([&](auto c_c) __attribute__((always_inline)) {
+        constexpr int c = decltype(c_c)::value;
+        if constexpr (c + 1 < NKC) {
+          rd_chunk(std::integral_constant<int, c + 1>{});
+          chain4_lds_wait<MT>(a[c & 1]);
+        } else {
+          chain4_lds_wait<0>(a[c & 1]);
         }
-        w_issue(slot);
-      }
-      // issue order of the chunk: [MFMA, fragment read] x MT first, then MFMAs with the weight loads between the tiles
 #pragma unroll
-      for (int i = 0; i < NTG * MT; ++i) {
-        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-        if (c + 1 < NKC && i < MT) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-        if (i % MT == MT - 1) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+        for (int t = 0; t < NTG; ++t) {
+          const int slot = (c * NTG + t) % PF;
+#pragma unroll
+          for (int mt = 0; mt < MT; ++mt) {
+            if (swap) acc[t][mt] = A2P_MFMA16(a[c & 1][mt], wr[slot], acc[t][mt]);
+            else acc[t][mt] = A2P_MFMA16(wr[slot], a[c & 1][mt], acc[t][mt]);
+          }
+          w_issue(slot);
+        }
+        // issue order of the chunk: the MT MFMAs of a tile, then the weight load that refills its ring slot
+#pragma unroll
+        for (int i = 0; i < NTG; ++i) {
+          __builtin_amdgcn_sched_group_barrier(0x008, MT, 0);
+          __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+        }
+      });
+    } else {
+      const char* rp = reinterpret_cast<const char*>(P) + l15 * PLD * 2;
+      constexpr int rstep = 32 * PLD;
+      h16x8 a[2][MT];
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) a[0][mt] = *reinterpret_cast<const h16x8*>(rp + aswz[0] + mt * rstep);
+#pragma unroll
+      for (int c = 0; c < NKC; ++c) {
+        if (c + 1 < NKC) {
+#pragma unroll
+          for (int mt = 0; mt < MT; ++mt)
+            a[(c + 1) & 1][mt] = *reinterpret_cast<const h16x8*>(rp + aswz[(c + 1) & 3] + ((c + 1) >> 2) * 256 + mt * rstep);
+        }
+#pragma unroll
+        for (int t = 0; t < NTG; ++t) {
+          const int slot = (c * NTG + t) % PF;
+#pragma unroll
+          for (int mt = 0; mt < MT; ++mt) {
+            if (swap) acc[t][mt] = A2P_MFMA16(a[c & 1][mt], wr[slot], acc[t][mt]);
+            else acc[t][mt] = A2P_MFMA16(wr[slot], a[c & 1][mt], acc[t][mt]);
+          }
+          w_issue(slot);
+        }
+#pragma unroll
+        for (int i = 0; i < NTG * MT; ++i) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+          if (c + 1 < NKC && i < MT) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+          if (i % MT == MT - 1) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+        }
       }
     }
   };
@@ -370,7 +449,7 @@ __device__ __forceinline__ void chain4_body(const ChainP& p, h16_t* const smem, 
         }
       }
       __builtin_amdgcn_sched_barrier(0);
-      gemm(std::integral_constant<int, 4>{}, std::integral_constant<int, KC>{}, acc, panelA, D, TR);
+      gemm(std::integral_constant<int, 4>{}, std::integral_constant<int, KC>{}, std::integral_constant<int, D>{}, acc, panelA, TR);
       __builtin_amdgcn_sched_barrier(0);
       if constexpr (!TR) {
 #pragma unroll
@@ -424,7 +503,7 @@ __device__ __forceinline__ void chain4_body(const ChainP& p, h16_t* const smem, 
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) R[t][mt] = f32x4{0.f, 0.f, 0.f, 0.f};
   __builtin_amdgcn_sched_barrier(0);
-  gemm(std::integral_constant<int, NT>{}, std::integral_constant<int, KC>{}, R, panelA, D, false);   // out_proj of the attention that produced `ain`
+  gemm(std::integral_constant<int, NT>{}, std::integral_constant<int, KC>{}, std::integral_constant<int, D>{}, R, panelA, false);   // out_proj of the attention that produced `ain`
   __builtin_amdgcn_sched_barrier(0);
   stamp(2);
   film_res(R, E4_BIAS_O, E4_FILM_O, p.xsrc ? p.xsrc : p.x, p.x_in_tiled, true);
@@ -473,7 +552,7 @@ __device__ __forceinline__ void chain4_body(const ChainP& p, h16_t* const smem, 
         for (int mt = 0; mt < MT; ++mt) acc[tt][mt] = b;
       }
       __builtin_amdgcn_sched_barrier(0);
-      gemm(std::integral_constant<int, NH>{}, std::integral_constant<int, KC>{}, acc, panelA, D, false);
+      gemm(std::integral_constant<int, NH>{}, std::integral_constant<int, KC>{}, std::integral_constant<int, D>{}, acc, panelA, false);
       __builtin_amdgcn_sched_barrier(0);
       if (h > 0) chain_bar();   // every wave finished the linear2 partial of the previous chunk
 #pragma unroll
@@ -486,7 +565,7 @@ __device__ __forceinline__ void chain4_body(const ChainP& p, h16_t* const smem, 
         }
       chain_bar();              // the hidden chunk is complete
       __builtin_amdgcn_sched_barrier(0);
-      gemm(std::integral_constant<int, NT>{}, std::integral_constant<int, HLD / 32>{}, R, panelH, HLD, false);
+      gemm(std::integral_constant<int, NT>{}, std::integral_constant<int, HLD / 32>{}, std::integral_constant<int, HLD>{}, R, panelH, false);
       __builtin_amdgcn_sched_barrier(0);
     }
     stamp(6);

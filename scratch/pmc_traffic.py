@@ -7,10 +7,10 @@ def mean_by_kernel(path):
         agg[row["Kernel_Name"]] += float(row["Counter_Value"]); cnt[row["Kernel_Name"]] += 1
     return {k: agg[k] / cnt[k] for k in agg}, cnt
 fetch, n = mean_by_kernel(sys.argv[1]); write, _ = mean_by_kernel(sys.argv[2])
-classes = {"chain": "chain_kernel", "attn": "attn_kernel", "gemm": "gemm_kernel", "ln_rope": "ln_rope_kernel"}
+classes = {"chain": ("chain_kernel", "chain4_kernel"), "chain_tall": ("chain4_kernel",), "chain_gen1": ("chain_kernel",), "attn": ("attn_kernel",), "gemm": ("gemm_kernel",), "ln_rope": ("ln_rope_kernel",)}
 out, lines = {}, []
 for cls, pat in classes.items():
-    ks = [k for k in fetch if pat in k]
+    ks = [k for k in fetch if any(q in k for q in pat)]
     if not ks: continue
     tot = sum(n[k] for k in ks)
     f = sum(fetch[k] * n[k] for k in ks) / tot * 1024 * 2
