@@ -58,7 +58,7 @@ def test_front_end_sinc_and_600_frames_vs_oracle(dev):
     got = model.audio_frontend(audio.to(dev)).cpu()
     assert got.shape == (1, 1998, 2038)
     e = {"rel_l2": rel_l2(got, want), "max_norm": rel_max(got, want)}
-    record("frontend/sinc_T600", **e)
+    record("frontend/sinc_T600", **e, pinning="windowed-sinc resampler unpinned (torchaudio absent offline: published algorithm); everything behind it is pinned by frontend/golden")
     assert max(e.values()) < 1e-3, e
     # a 150-frame clip: one full chunk + a 30-frame remainder (model/diffusion.py:303 slices [i : i + 120])
     audio = synthetic_audio(SEED + 1, 2, 150)
@@ -116,7 +116,7 @@ def test_front_end_16bit_conv_stack_vs_oracle(dev, precision, tol):
     assert got.shape == want.shape and bool(torch.isfinite(got).all())
     e = {"rel_l2": rel_l2(got, want), "max_norm": rel_max(got, want),
          "audio_rel_l2": rel_l2(got[..., :1024], want[..., :1024]), "lip_rel_l2": rel_l2(got[..., 1024:], want[..., 1024:])}
-    record(f"frontend/sinc_T600_{precision}", **e)
+    record(f"frontend/sinc_T600_{precision}", **e, pinning="windowed-sinc resampler unpinned (torchaudio absent offline: published algorithm); everything behind it is pinned by frontend/golden")
     assert max(e.values()) < tol, e
     # fp32 front end on a 16-bit model stays available
     from audio2photoreal_amd.model.audio_frontend import NativeAudioFrontend
@@ -162,6 +162,7 @@ def test_front_end_with_fairseq_blocks_vs_oracle(dev, gname, precision, tol):
     got = model.audio_frontend(audio.to(dev)).cpu()
     assert got.shape == want.shape and bool(torch.isfinite(got).all())
     e = {"rel_l2": rel_l2(got, want), "audio_rel_l2": rel_l2(got[..., :1024], want[..., :1024]), "lip_rel_l2": rel_l2(got[..., 1024:], want[..., 1024:])}
-    record(f"frontend/fairseq_blocks/{gname}/{precision}", **e)
-    assert max(e.values()) < tol, e
+    # the checker here is the oracle's restatement of fairseq's PUBLISHED modules: fairseq is absent offline, no reference-run golden exists
+    record(f"frontend/fairseq_blocks/{gname}/{precision}", **e, pinning="unpinned (oracle restates the published fairseq blocks; no reference-generated golden)")
+    assert max(v for v in e.values() if isinstance(v, float)) < tol, e
     model.release()
