@@ -294,7 +294,7 @@ static void chain_set_out_proj(a2p_ctx* c, ChainP& p, const std::string& attn, c
 // 256-register waves per SIMD, panels of at most 48 / 64 rows).  Both give bit-identical results for both model widths
 // (kernels_chain.h: one shared LayerNorm reduction tree, no floating-point contraction; tests/test_hip_round2.py).
 // Which one is faster depends on the BOX, not on the code: on most MI355X boxes NW=4 leads by 3-5 % at B=8, on a sizeable
-// minority the 512-register kernels run 35 % slower inside the step (not in isolation) and NW=8 leads by 19 % (DESIGN.md
+// minority the 512-register kernels run 35 % slower inside the step (not in isolation) and NW=8 leads by 19 % (docs/lab_notebook_r1_r4.md
 // section 6).  So it is measured in situ: forwards 1..4 of a given size alternate the two shapes with an event pair around
 // the decoder stack (forward 0 is warm-up), forward 5 picks the faster average and the choice sticks.  A2P_CHAIN_NW=4|8 forces.
 // Round 4: the in-situ measurement is OPT-IN (A2P_CHAIN_TUNE=1).  The default is the 8-wave shape everywhere: deterministic per
@@ -346,7 +346,7 @@ static int chain_pick_nw(a2p_ctx* c, int64_t rows, hipEvent_t* e0, hipEvent_t* e
 // kernels.  The two families produce the same bits (tests/test_hip_round5.py), so the choice is invisible in the results -- and
 // which one is faster depends on the BOX and on the chain: on most MI355X boxes leased this round the tall family leads everywhere
 // (B=8: 552 -> 594 steps/s; B=16 +13 %, B=32 +6 %); on a minority -- the boxes that also run the memory-heavy PRE kernel 30 % slow,
-// DESIGN.md section 6 "box-to-box spread" -- the tall POST kernel with its parked rows LOSES (B=32: 330 vs 278 us) while the tall MID
+// docs/lab_notebook_r1_r4.md section 6 "box-to-box spread" -- the tall POST kernel with its parked rows LOSES (B=32: 330 vs 278 us) while the tall MID
 // kernel still wins (88 vs 106 us) (profiles/r05_tall_chain_same_box_*.txt, r05_family_calibration.txt).  So it is measured in situ,
 // like round 3's workgroup shape: forward 0 of a size is warm-up, forwards 1..8 run the four (MID, POST) combinations twice with an
 // event pair around the decoder stack, forward 9 keeps the fastest.  A2P_CHAIN_V=1 | 4 forces one family for both.
@@ -896,7 +896,7 @@ static int forward_body(a2p_ctx* c, const float* x_in, const int64_t* t_orig, in
   // the side stream next to input projection / norm1+QKV / self attention of layer 0 (-2..3 % step time).  On by default since
   // round 2 (A2P_NO_SIDE_STREAM=1 turns it off): in round 1, with the two queues active, 1-30 % of forwards on some boxes
   // differed for one sample; that was traced to tpath_post_kernel consuming a load right behind its s_waitcnt (kernels_misc.h,
-  // DESIGN.md "Reproducibility") and fixed there -- 0 / 1500 differing forwards in round 1, 0 / 600 + identical 60-step
+  // docs/lab_notebook_r1_r4.md "Reproducibility") and fixed there -- 0 / 1500 differing forwards in round 1, 0 / 600 + identical 60-step
   // trajectories in both 16-bit modes in round 2 (scratch/side_stress.py).
   // (the small path keeps the time path on the main stream: on the side stream it measured 1430 against 1497 steps/s at 480 rows --
   // the fork / join costs more than the 7 launches it hides)

@@ -39,7 +39,7 @@ struct AttnP {
                           // 1 = 1 + seq (conditional pass), 2 = 0 (unconditional), 3 = seq < slot_b ? 1 + seq : 0 (guidance: both)
   int tail_mod;        // sample = seq % tail_mod
   int kv_stream;       // 1: K/V slots other than 0 are read once per step (cached audio K/V): DMA them non-temporal so that
-                       // they do not evict the chain kernels' weight streams from L2 / MALL
+                       // they do not evict the chain kernels' weight streams from L2 / MALL (docs/lab_notebook_r1_r4.md section 4.2)
   int Tq, S_main, S_tail;
   float scale_log2e;   // log2(e) / sqrt(head_dim)
   // Workgroup -> (query block, head, sequence).  The grid is 1-D; with xcd_remap the 8 XCDs (block b runs on XCD b % 8) each

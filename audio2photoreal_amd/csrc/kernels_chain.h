@@ -32,7 +32,7 @@
 // 16x16x32 fragments per k-chunk.  Accumulator layout (operands swapped, D = C^T): lane (l15 = lane & 15,
 // g = lane >> 4) holds C[m = mt*16 + l15][n = ... + j*16 + g*4 + r], r = 0..3.
 //
-// Round 2 on top of that (each one bit-identical to the form it replaced; DESIGN.md section 4.1 has the measurements):
+// Round 2 on top of that (each one bit-identical to the form it replaced; docs/lab_notebook_r1_r4.md section 4.1 has the measurements):
 //   * two workgroup shapes, 4 waves x 512 registers or 8 waves x 256 (NW), same bits, chosen per box at run time;
 //   * out_proj and the linear2 partials run as k-major GROUP GEMMs over all output tiles (gemm_group): the panel fragments of a
 //     k-step are read once for the group, one pipeline ramp per group;
@@ -59,7 +59,7 @@ enum { CHAIN_PRE = 0, CHAIN_MID = 1, CHAIN_POST = 2, CHAIN_MIDPOST = 3 };
 // and the 1280-workgroup attention launch over 20 keys (9 us of dispatch for 2 us of work) disappears.
 // An in-kernel L2 look-ahead of the stream (one 4-byte-per-lane LDS-DMA per wave per stage touching the slice 8-16 stages
 // ahead of the DMA head) was measured and rejected: +30 % kernel time warm AND cold -- the L2 request count per line, not
-// the bytes, is what the extra instruction doubles (scratch/chain_bench).
+// the bytes, is what the extra instruction doubles (scratch/chain_bench, docs/lab_notebook_r1_r4.md section 4).
 #define CHAIN_STREAM_PAD 8  // stages the host appends to a stream: the DMA runs up to NS-1 (<= 5) stages past the end
 #define CHAIN_STAGE_ELEMS 8192  // 128 out-cols x 64 k bf16 = 16 KiB; 2048 elements (4 KiB) per wave
 
@@ -208,7 +208,7 @@ __device__ __forceinline__ void chain_bar() { asm volatile("s_waitcnt lgkmcnt(0)
 //   debug (scratch/chain_dbg.hip): 256 = stop after the out_proj epilogue, 512 = out_proj result discarded, 1024 = FFN result discarded
 // NW: waves per workgroup.  4 = one 512-register wave per SIMD; 8 = two 256-register waves per SIMD, each owning 16 of a
 // tile's 128 columns (half the accumulators, half the weight slice, its own DMA ring): a wave's LDS-DMA pieces and
-// fragment reads cost it 40-60 issue cycles each that its own MFMAs do not hide (measured additive),
+// fragment reads cost it 40-60 issue cycles each that its own MFMAs do not hide (measured additive, docs/lab_notebook_r1_r4.md section 4),
 // so the second wave on the SIMD is what overlaps them.
 // LDS footprint (bf16 elements) of one workgroup: [panelA BM x D][panelH BM x 128][LayerNorm partials][aux][weight ring]
 template <int D, int MT>

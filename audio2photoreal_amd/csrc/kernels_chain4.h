@@ -1,6 +1,6 @@
 // Row-panel chain kernels, TALL form (round 5): the MID / POST chains of kernels_chain.h (FiLMTransformerDecoderLayer.forward,
 // transformer_modules.py:178-267) for forwards of >= 16 sequences of the face model (d = 512), where a CU owes >= 75 rows and a
-// 48-row panel streams every weight byte for too few of them (16 KiB of weights per 192 MFMA cycles
+// 48-row panel streams every weight byte for too few of them (docs/lab_notebook_r1_r4.md section 4.1c: 16 KiB of weights per 192 MFMA cycles
 // against the 64 B/clk L2 -> CU path; B=32 runs three rounds of 48 / 64-row panels).  Same arithmetic, same column ownership,
 // same accumulation order and LayerNorm tree as the 8-wave form of kernels_chain.h -- the outputs are bit-identical
 // (tests/test_hip_round5.py) -- restructured around four facts:

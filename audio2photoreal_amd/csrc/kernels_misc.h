@@ -247,7 +247,7 @@ __global__ __launch_bounds__(256) void tpath_post_kernel(TPathP p) {
   // The rotary (cos, sin) pairs are fetched first and pinned in registers: they are not consumed until after both
   // LayerNorm reductions, so the loads have long landed by then.  (With the fetch next to its first use, the first VALU
   // after the s_waitcnt -- a packed f32 op selecting the high dword of the returning dwordx2 -- was observed to read 0
-  // in lanes 48-63 when another stream's kernel loaded the memory system; see DESIGN.md section 6, "Reproducibility".)
+  // in lanes 48-63 when another stream's kernel loaded the memory system; see docs/lab_notebook_r1_r4.md section 6, "Reproducibility".)
   float2 t[NPL / 2];
 #pragma unroll
   for (int i = 0; i < NPL / 2; ++i) t[i] = p.cs[(int64_t)pos * (d / 2) + lane * (NPL / 2) + i];

@@ -13,7 +13,7 @@
 // the 256 CUs, 95 us.  128-row blocks need both LDS buffers at 128 channels -- the 256-channel operands pass through in two halves
 // under accumulators that stay in registers -- and give 192 workgroups: one round.)
 //
-// Arithmetic: the exact island of the 16-bit modes -- every operand is a (hi, lo) pair of 16-bit values
+// Arithmetic: the exact island of the 16-bit modes (docs/lab_notebook_r1_r4.md section 4.3b) -- every operand is a (hi, lo) pair of 16-bit values
 // and a . w = a_hi w_hi + a_lo w_hi + a_hi w_lo in fp32 accumulators (the dropped a_lo w_lo is 2^-22 relative with IEEE half).
 // Activations live in LDS as [row][hi: CP | lo: CP] 16-bit rows, 16-byte chunks XOR-swizzled by (row & 15) (conflict-free
 // ds_read_b128 of 16 consecutive rows, also when a tap shifts the rows); weights stream from L2 as ready-made MFMA operands

@@ -94,6 +94,34 @@ def box_record(dev):
             rec[key] = {k: v for k, v in card.items() if any(w in k.lower() for w in ("sclk", "mclk", "fclk", "socclk", "power", "partition", "performance"))}
         except Exception as e:   # noqa: BLE001 -- a report field
             rec[key] = f"unavailable ({type(e).__name__})"
+    # KFD topology of the GPU node(s) (harvesting shows up as simd_count / cu_count / array geometry; num_xcc; firmware versions) and the
+    # board's VBIOS / serial-independent ids: the per-box data the review asked to correlate with the two speed groups
+    try:
+        import glob
+        nodes = []
+        for f in sorted(glob.glob("/sys/class/kfd/kfd/topology/nodes/*/properties")):
+            kv = dict(l.split(None, 1) for l in open(f).read().splitlines() if " " in l)
+            if int(kv.get("simd_count", "0")) == 0:
+                continue
+            keep = ("simd_count", "cu_count", "array_count", "simd_arrays_per_engine", "cu_per_simd_array", "simd_per_cu", "num_xcc", "max_waves_per_simd",
+                    "lds_size_in_kb", "max_engine_clk_fcompute", "fw_version", "sdma_fw_version", "gfx_target_version", "num_sdma_engines",
+                    "num_cp_queues", "local_mem_size", "capability", "debug_prop")
+            nodes.append({k: kv[k].strip() for k in keep if k in kv})
+        rec["kfd"] = nodes
+    except Exception as e:   # noqa: BLE001 -- a report field
+        rec["kfd"] = f"unavailable ({type(e).__name__})"
+    try:
+        import glob
+        vb = [open(f).read().strip() for f in sorted(glob.glob("/sys/class/drm/card*/device/vbios_version"))]
+        rec["vbios"] = sorted(set(vb))
+    except Exception as e:   # noqa: BLE001
+        rec["vbios"] = f"unavailable ({type(e).__name__})"
+    try:
+        out = subprocess.run(["rocm-smi", "--showhw"], capture_output=True, text=True, timeout=20).stdout
+        rows = [" ".join(l.split()) for l in out.splitlines() if l.strip() and not set(l.strip()) <= set("=-")]
+        rec["showhw"] = rows[:6]
+    except Exception as e:   # noqa: BLE001
+        rec["showhw"] = f"unavailable ({type(e).__name__})"
     return rec
 
 

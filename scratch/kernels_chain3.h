@@ -1,7 +1,7 @@
 // EXPERIMENT (round 4; scratch, not product -- built only by scratch/chain3_bench.hip): row-panel chain kernels, third generation:
 // TWO workgroups per CU.  Bit-identical to kernels_chain.h (14 GPU test cases at 0.0 while it was wired into the library, commit
 // "Chain kernels generation 3"), measured EQUAL-TO-SLOWER inside the step (B=32: 207-225 vs 200 us per chain launch; B=16 equal;
-// B=8 and the body model slower) and removed from the library again -- profiles/r04_chain3_bench*.txt, DESIGN.md section 4.1c.
+// B=8 and the body model slower) and removed from the library again -- profiles/r04_chain3_bench*.txt, docs/lab_notebook_r1_r4.md section 4.1c.
 //
 // The same three chains as kernels_chain.h (PRE / MID / POST of FiLMTransformerDecoderLayer.forward,
 // transformer_modules.py:178-267) and the same bits.  What rounds 1-3 measured: a chain launch spends

@@ -1,6 +1,6 @@
 """Round-3 GPU tests (`pytest -m gpu`): the multi-GPU control flow of bench.py on the GPU that exists, a device-tensor all_gather
 that lights up on a node with >= 2 GPUs, the small-forward kernels and the key-split attention.  (The bit-identity tests of the
-generation-2 / -3 chain kernels left with those kernels in round 4: neither beat generation 1 inside the step)"""
+generation-2 / -3 chain kernels left with those kernels in round 4: neither beat generation 1 inside the step, docs/lab_notebook_r1_r4.md 4.1c.)"""
 import json
 import os
 import socket
