@@ -419,7 +419,8 @@ static int launch_chain4(a2p_ctx* c, int mode, const ChainP& p0, hipStream_t s) 
 #define A2P_CHAIN4(MT)                                                                          \
   do {                                                                                          \
     if (mode == CHAIN_MID) A2P_LAUNCH(kt, (chain4_kernel<MT, CHAIN_MID>), grid, 512, s, p);     \
-    else A2P_LAUNCH(kt, (chain4_kernel<MT, CHAIN_POST>), grid, 512, s, p);                      \
+    else if (p.has_next) A2P_LAUNCH(kt, (chain4_kernel<MT, CHAIN_POST>), grid, 512, s, p);      \
+    else A2P_LAUNCH(kt, (chain4_kernel<MT, CHAIN_POST, true>), grid, 512, s, p);                \
   } while (0)
   if (mt == 3) A2P_CHAIN4(3);
   else if (mt == 4) A2P_CHAIN4(4);

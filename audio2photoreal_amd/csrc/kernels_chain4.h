@@ -31,6 +31,9 @@
 #pragma clang fp contract(off)
 
 #define CHAIN4_PF 8            // half stages in flight per wave (register ring); every GEMM of a chain consumes a multiple of it
+#ifndef CHAIN4_ASM_ALL
+#define CHAIN4_ASM_ALL 0     // A/B builds: inline-asm panel-fragment reads in every tall kernel (default: the 80-row POST kernel only)
+#endif
 #ifndef CHAIN4_PF_MID
 #define CHAIN4_PF_MID 8        // ... of the MID kernels (which have registers to spare)
 #endif
@@ -93,7 +96,7 @@ __global__ __launch_bounds__(256) void chain4_pack_kernel(const ChainPackDesc* _
   }
 }
 
-template <int MT, int MODE>
+template <int MT, int MODE, bool LAST>
 __device__ __forceinline__ void chain4_body(const ChainP& p, h16_t* const smem, const int m0) {
   constexpr int D = 512, NW = 8, CW = 16, BM = 16 * MT, NT = 4, KC = D / 32, FT = 8, HLD = Chain4Lds<MT>::HC, NH = HLD / 128, PF = MODE == CHAIN_MID ? CHAIN4_PF_MID : (MT == 3 ? CHAIN4_PF_POST3 : CHAIN4_PF);
   constexpr int AUX_F = Chain4Lds<MT>::AUX_F;
@@ -167,7 +170,7 @@ __device__ __forceinline__ void chain4_body(const ChainP& p, h16_t* const smem, 
   auto gemm = [&](auto ntg_c, auto nkc_c, auto pld_c, auto& acc, const h16_t* P, bool swap) __attribute__((always_inline)) {
     constexpr int NTG = decltype(ntg_c)::value, NKC = decltype(nkc_c)::value, PLD = decltype(pld_c)::value;
     static_assert((NTG * NKC) % PF == 0 && PF % NTG == 0, "ring phase");
-    constexpr bool ASM_FRAGS = MT == 5 && MODE == CHAIN_POST;
+    constexpr bool ASM_FRAGS = CHAIN4_ASM_ALL || (MT == 5 && MODE == CHAIN_POST);
     if constexpr (ASM_FRAGS) {
       constexpr int RSTEP = 32 * PLD;   // bytes between the 16-row blocks of a panel
       const uint32_t rp = lds_off(P) + (uint32_t)(l15 * PLD * 2);
@@ -589,8 +592,10 @@ __device__ __forceinline__ void chain4_body(const ChainP& p, h16_t* const smem, 
       }
     }
     stamp(7);
-    if (!p.has_next) {   // last decoder layer (final_layer runs on its own exact-island path): the rows go back in the caller's layout
-      // parked rows were re-read in the TILED layout just now and the final layout is row-major: inside a 16-row block the two
+    if constexpr (LAST) {   // last decoder layer (final_layer runs on its own exact-island path): the rows go back in the caller's layout.
+      // Its own instantiation, not a run-time branch on p.has_next: with both continuations in one function hipcc spilled 70 registers of
+      // the 80-row kernel (17 without the branch) and its POST launches at B=32 went from 232 to 263 us.
+      // Parked rows were re-read in the TILED layout just now and the final layout is row-major: inside a 16-row block the two
       // layouts put different lanes' data on the same bytes, so no wave may store before every wave has its parked rows back
       // (first version without this barrier: wrong rows in every parked case, tests/test_hip_round5.py)
       if constexpr (PARK) chain_bar();
@@ -618,9 +623,10 @@ __device__ __forceinline__ void chain4_body(const ChainP& p, h16_t* const smem, 
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the ring's run-ahead loads target this wave's registers
 }
 
-template <int MT, int MODE>
+template <int MT, int MODE, bool LAST = false>   // LAST: the POST kernel behind the last decoder layer (ChainP::has_next == 0)
 __global__ __launch_bounds__(512, 2) void chain4_kernel(const ChainP p) {
+  static_assert(!LAST || MODE == CHAIN_POST, "only POST has a last-layer form");
   __shared__ __attribute__((aligned(16))) h16_t smem[Chain4Lds<MT>::ELEMS];
-  chain4_body<MT, MODE>(p, smem, blockIdx.x * (16 * MT));
+  chain4_body<MT, MODE, LAST>(p, smem, blockIdx.x * (16 * MT));
 }
 #pragma clang fp contract(fast)

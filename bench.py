@@ -100,7 +100,10 @@ def box_record(dev):
         import glob
         nodes = []
         for f in sorted(glob.glob("/sys/class/kfd/kfd/topology/nodes/*/properties")):
-            kv = dict(l.split(None, 1) for l in open(f).read().splitlines() if " " in l)
+            try:
+                kv = dict(l.split(None, 1) for l in open(f).read().splitlines() if " " in l)
+            except OSError:   # nodes of devices outside this container's cgroup are not readable
+                continue
             if int(kv.get("simd_count", "0")) == 0:
                 continue
             keep = ("simd_count", "cu_count", "array_count", "simd_arrays_per_engine", "cu_per_simd_array", "simd_per_cu", "num_xcc", "max_waves_per_simd",
@@ -311,6 +314,70 @@ def chain_family(case):
     return int(v.value)
 
 
+def load_probe(case, dev, seconds=0.7):
+    """Board power / core clock / junction temperature WHILE this workload's steps run (never inside a timed region): the host enqueues
+    `seconds` worth of steps, samples the hwmon sensors (sysfs; rocm-smi as the fallback) while the GPU works through them, then waits.
+    Round 5 found B=32 power-capped (1330 W of 1400, 2.19 GHz instead of 2.39: profiles/r05_power_clock_b8_b32.txt); with this record every
+    bench line says what ITS box did under ITS load (sampled by a second host thread while the steps run) -- the datum to correlate with the two speed groups of the leased boxes."""
+    import glob
+    import subprocess
+
+    def sample():
+        out = {}
+        for hw in glob.glob("/sys/class/drm/card*/device/hwmon/hwmon*"):
+            try:
+                for name, key, scale in (("power1_average", "power_w", 1e-6), ("power1_input", "power_w", 1e-6), ("freq1_input", "sclk_mhz", 1e-6),
+                                         ("temp2_input", "junction_c", 1e-3), ("temp1_input", "edge_c", 1e-3)):
+                    f = os.path.join(hw, name)
+                    if key not in out and os.path.exists(f):
+                        out[key] = round(float(open(f).read()) * scale, 1)
+            except (OSError, ValueError):
+                continue
+            if out:
+                return out
+        try:
+            txt = subprocess.run(["rocm-smi", "--showpower", "--showclocks", "--showtemp"], capture_output=True, text=True, timeout=10).stdout
+            import re
+            for key, pat in (("power_w", r"Power \(W\): ([\d.]+)"), ("sclk_mhz", r"sclk clock level: \d+: \((\d+)Mhz\)"), ("junction_c", r"junction\) \(C\): ([\d.]+)")):
+                m = re.search(pat, txt)
+                if m:
+                    out[key] = float(m.group(1))
+        except Exception:   # noqa: BLE001 -- a report field
+            pass
+        return out
+
+    try:
+        import threading
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        case.run_steps(10)
+        torch.cuda.synchronize(dev)
+        per = (time.perf_counter() - t0) / 10
+        n = max(20, min(2000, int(seconds / max(per, 1e-5))))
+        idle = sample()
+        samples, stop = [], threading.Event()
+
+        def sampler():   # a host thread beside the enqueueing one (which blocks on the launch queue's depth, so it cannot sample itself)
+            while not stop.is_set():
+                samples.append((time.perf_counter(), sample()))
+                time.sleep(0.03)
+
+        th = threading.Thread(target=sampler, daemon=True)
+        t_start = time.perf_counter()
+        th.start()
+        case.run_steps(n)
+        torch.cuda.synchronize(dev)
+        t_end = time.perf_counter()
+        stop.set()
+        th.join(timeout=2.0)
+        warm = [smp for t, smp in samples if t_start + 0.35 * (t_end - t_start) <= t <= t_end - 0.02 and smp]   # the power manager has settled
+        keys = sorted({k for smp in warm for k in smp})
+        return {"steps": n, "seconds": round(t_end - t_start, 3), "idle_before": idle, "samples": len(warm),
+                **{k: {"min": min(smp[k] for smp in warm if k in smp), "max": max(smp[k] for smp in warm if k in smp)} for k in keys}}
+    except Exception as e:   # noqa: BLE001 -- a report field
+        return f"unavailable ({type(e).__name__}: {e})"
+
+
 def leg_record(case, steps, warmup, repeats, ksteps=3):
     """Sub-record of a secondary workload (same measurement as the headline, fewer fields)."""
     case.setup()
@@ -325,7 +392,8 @@ def leg_record(case, steps, warmup, repeats, ksteps=3):
             "decoder_mfma_frac": round(case.step_flops() * steps / dt / 1e12 / peak, 4),
             "roofline": roofline, "kernels": kernels, "prepare_s": round(case.prepare_s, 4),
             "chain_workgroup_waves": chain_workgroup_waves(case) if "chain" in kernels else None,
-            "chain_family": chain_family(case) if "chain" in kernels else None}
+            "chain_family": chain_family(case) if "chain" in kernels else None,
+            "under_load": load_probe(case, case.dev) if "chain" in kernels else None}
 
 
 # ----------------------------------------------------------------------------------------------------------------------
@@ -839,6 +907,7 @@ def main():
         assert allx.shape[0] == total and bool(torch.isfinite(allx).all())
 
     kernels, roofline = {}, None
+    under_load = load_probe(case, dev) if rank == 0 else None   # after the timed regions: power / clock / temperature while the steps run
     if rank == 0 and not a.no_kernel_timing:
         kernels, roofline = kernel_breakdown(case, min(a.steps, 5))
         if "chain" in kernels:
@@ -909,7 +978,7 @@ def main():
             "collectives": ({"backend": dist.get_backend(), "ranks": dist.get_world_size(), "gather": os.environ.get("A2P_GATHER", "ring"),
                              "gather_rows": int(allx.shape[0]), "gather_bytes_per_rank": int(mine.numel() * mine.element_size())}
                             if world > 1 else None),
-            "box": box_record(dev),
+            "box": box_record(dev), "under_load": under_load,
             "roofline": roofline, "kernels": kernels, "cpu_baseline": cpu, "parity": parity, "legs": legs or None,
         }
         print(json.dumps(line), flush=True)
