@@ -322,17 +322,30 @@ def load_probe(case, dev, seconds=0.7):
     import glob
     import subprocess
 
+    # the hwmon directory of THIS device: a node's sysfs lists all of its GPUs, also those outside the container's cgroup (first version
+    # read a neighbour's idle sensors), so the card is matched by PCI address; no match -> rocm-smi (which only sees the visible device)
+    hwmon = None
+    try:
+        pr = torch.cuda.get_device_properties(dev)
+        bdf = f"{getattr(pr, 'pci_domain_id', 0):04x}:{pr.pci_bus_id:02x}:{pr.pci_device_id:02x}.0"
+        for card in glob.glob("/sys/class/drm/card*/device"):
+            if os.path.basename(os.path.realpath(card)).lower() == bdf:
+                hw = glob.glob(os.path.join(card, "hwmon", "hwmon*"))
+                hwmon = hw[0] if hw else None
+    except Exception:   # noqa: BLE001 -- a report field
+        hwmon = None
+
     def sample():
         out = {}
-        for hw in glob.glob("/sys/class/drm/card*/device/hwmon/hwmon*"):
+        if hwmon is not None:
             try:
                 for name, key, scale in (("power1_average", "power_w", 1e-6), ("power1_input", "power_w", 1e-6), ("freq1_input", "sclk_mhz", 1e-6),
                                          ("temp2_input", "junction_c", 1e-3), ("temp1_input", "edge_c", 1e-3)):
-                    f = os.path.join(hw, name)
+                    f = os.path.join(hwmon, name)
                     if key not in out and os.path.exists(f):
                         out[key] = round(float(open(f).read()) * scale, 1)
             except (OSError, ValueError):
-                continue
+                out = {}
             if out:
                 return out
         try:
@@ -372,7 +385,7 @@ def load_probe(case, dev, seconds=0.7):
         th.join(timeout=2.0)
         warm = [smp for t, smp in samples if t_start + 0.35 * (t_end - t_start) <= t <= t_end - 0.02 and smp]   # the power manager has settled
         keys = sorted({k for smp in warm for k in smp})
-        return {"steps": n, "seconds": round(t_end - t_start, 3), "idle_before": idle, "samples": len(warm),
+        return {"steps": n, "seconds": round(t_end - t_start, 3), "source": "hwmon sysfs" if hwmon else "rocm-smi", "idle_before": idle, "samples": len(warm),
                 **{k: {"min": min(smp[k] for smp in warm if k in smp), "max": max(smp[k] for smp in warm if k in smp)} for k in keys}}
     except Exception as e:   # noqa: BLE001 -- a report field
         return f"unavailable ({type(e).__name__}: {e})"
@@ -907,7 +920,7 @@ def main():
         assert allx.shape[0] == total and bool(torch.isfinite(allx).all())
 
     kernels, roofline = {}, None
-    under_load = load_probe(case, dev) if rank == 0 else None   # after the timed regions: power / clock / temperature while the steps run
+    under_load = load_probe(case, dev) if rank == 0 and not a.no_kernel_timing else None   # after the timed regions (not under a profiler): power / clock / temperature while the steps run
     if rank == 0 and not a.no_kernel_timing:
         kernels, roofline = kernel_breakdown(case, min(a.steps, 5))
         if "chain" in kernels:
