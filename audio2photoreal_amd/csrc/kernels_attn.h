@@ -131,8 +131,11 @@ __device__ __forceinline__ float attn_rowgroup_max(float v) {
 // waves per SIMD the register allocation is held to: 3 for the 16-bit and the fp32 dh <= 64 kernels.  The fp32 dh = 128 kernel (the
 // lip regressor of the audio front end: once per clip, 4 heads; 67 KB of LDS per workgroup) asks for 1: at 2 it spills 59 registers,
 // and a request of 3 was silently dropped by hipcc (the code it compiled was the occupancy-1 code all along)
+#ifndef A2P_ATTN_F32_MINWAVES
+#define A2P_ATTN_F32_MINWAVES 3   // fp32 parity mode, head dim 64: 3 waves per SIMD spill 42 registers; 2 waves (208 registers, no spills) measured SLOWER: 96.6 vs 101.4 steps/s (profiles/r05_fp32_attn_occupancy_ab.txt)
+#endif
 template <typename T, int DH>
-constexpr int attn_min_waves() { return (sizeof(T) == 4 && DH == 128) ? 1 : 3; }
+constexpr int attn_min_waves() { return (sizeof(T) == 4 && DH == 128) ? 1 : (sizeof(T) == 4 && DH == 64) ? A2P_ATTN_F32_MINWAVES : 3; }
 
 template <typename T, int DH, int ABL = 0, int NWV = 4>
 __global__ __launch_bounds__(64 * NWV, (attn_min_waves<T, DH>())) void attn_kernel(AttnP p) {

@@ -1,15 +1,25 @@
 #!/bin/bash
-# round 5, call 30: evidence of the final kernels (scratch/run_evidence_r05.sh: rocprofv3 stats, PMC traffic B=8, SQ counters, power, default bench) + PMC traffic at B=32 + full GPU suite
+# round 5, call 31: fp32 parity mode, attention at 2 waves per SIMD (no spills) vs 3 (42 spilled registers); under-load probe check
 R=${GRAFT_REPO_ROOT:-/root/repo}
 O=$R/gpurun_out; mkdir -p $O
 cd $R
-( time timeout -k 5 1200 python -m pytest tests -m gpu -q -x ) > $O/r05_c30_tests.log 2>&1; tail -5 $O/r05_c30_tests.log
-bash scratch/run_evidence_r05.sh > $O/r05_c30_evidence.log 2>&1; tail -c 1500 $O/r05_c30_evidence.log
-cd /tmp && export TMPDIR=/tmp
-B="python $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-kernel-timing --no-legs --no-parity --repeats 1 --batch 32"
-rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmcf_b32 -o p -- $B > $O/pmcf_b32.log 2>&1
-rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmcw_b32 -o p -- $B > $O/pmcw_b32.log 2>&1
-cd $R
-python scratch/pmc_traffic.py $O/pmcf_b32/p_counter_collection.csv $O/pmcw_b32/p_counter_collection.csv $O/r05_pmc_traffic_b32.json > $O/r05_pmc_traffic_b32.txt 2>&1
-rm -rf $O/pmcf_b32 $O/pmcw_b32
-head -8 $O/r05_pmc_traffic_b32.txt | cut -c1-160
+for lib in w3 w2 w3 w2; do
+  if [ $lib = w2 ]; then export A2P_LIB=$R/scratch/ab/liba2p_f32w2.so; else unset A2P_LIB; fi
+  timeout -k 5 300 python bench.py --precision fp32 --no-cpu-baseline --no-parity --no-legs --steps 40 --warmup 5 > $O/r05_c31_fp32_$lib.json 2> $O/r05_c31_fp32_$lib.err
+  python - <<PY
+import json
+try:
+    j=json.loads([l for l in open("$O/r05_c31_fp32_$lib.json") if l.startswith("{")][-1])
+    k=j["kernels"]
+    print("fp32 lib=$lib", j["value"], {n:(v.get("ms_per_step"), v.get("avg_launch_us")) for n,v in k.items() if isinstance(v,dict) and "ms_per_step" in v}, "load", j.get("under_load"))
+except Exception as e:
+    print("fp32 lib=$lib FAILED", e); print(open("$O/r05_c31_fp32_$lib.err").read()[-1500:])
+PY
+done 2>&1 | tee $O/r05_c31_ab.txt
+unset A2P_LIB
+timeout -k 5 300 python bench.py --no-cpu-baseline --no-parity --no-legs --steps 100 --warmup 10 > $O/r05_c31_b8.json 2> $O/r05_c31_b8.err
+python - <<PY
+import json
+j=json.loads([l for l in open("$O/r05_c31_b8.json") if l.startswith("{")][-1])
+print("B=8", j["value"], "load", j.get("under_load"))
+PY
