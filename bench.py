@@ -108,7 +108,7 @@ def box_record(dev):
                 continue
             keep = ("simd_count", "cu_count", "array_count", "simd_arrays_per_engine", "cu_per_simd_array", "simd_per_cu", "num_xcc", "max_waves_per_simd",
                     "lds_size_in_kb", "max_engine_clk_fcompute", "fw_version", "sdma_fw_version", "gfx_target_version", "num_sdma_engines",
-                    "num_cp_queues", "local_mem_size", "capability", "debug_prop")
+                    "num_cp_queues", "local_mem_size", "capability", "debug_prop", "unique_id", "location_id", "domain", "drm_render_minor")
             nodes.append({k: kv[k].strip() for k in keep if k in kv})
         rec["kfd"] = nodes
     except Exception as e:   # noqa: BLE001 -- a report field
@@ -120,9 +120,9 @@ def box_record(dev):
     except Exception as e:   # noqa: BLE001
         rec["vbios"] = f"unavailable ({type(e).__name__})"
     try:
-        out = subprocess.run(["rocm-smi", "--showhw"], capture_output=True, text=True, timeout=20).stdout
+        out = subprocess.run(["rocm-smi", "--showhw", "--showuniqueid", "--showserial"], capture_output=True, text=True, timeout=20).stdout
         rows = [" ".join(l.split()) for l in out.splitlines() if l.strip() and not set(l.strip()) <= set("=-")]
-        rec["showhw"] = rows[:6]
+        rec["showhw"] = [r for r in rows if "ROCm System" not in r and "End of ROCm" not in r][:8]
     except Exception as e:   # noqa: BLE001
         rec["showhw"] = f"unavailable ({type(e).__name__})"
     return rec
