@@ -557,6 +557,7 @@ __device__ __forceinline__ void chain4_body(const ChainP& p, h16_t* const smem, 
       __builtin_amdgcn_sched_barrier(0);
       gemm(std::integral_constant<int, NH>{}, std::integral_constant<int, KC>{}, std::integral_constant<int, D>{}, acc, panelA, false);
       __builtin_amdgcn_sched_barrier(0);
+      if (13 + 3 * h < 32) stamp(13 + 3 * h);       // (stamped builds: linear1 of this hidden chunk done in wave 0)
       if (h > 0) chain_bar();   // every wave finished the linear2 partial of the previous chunk
 #pragma unroll
       for (int tt = 0; tt < NH; ++tt)
@@ -567,9 +568,11 @@ __device__ __forceinline__ void chain4_body(const ChainP& p, h16_t* const smem, 
               h16x4{(h16_t)act_gelu_fast(v[0]), (h16_t)act_gelu_fast(v[1]), (h16_t)act_gelu_fast(v[2]), (h16_t)act_gelu_fast(v[3])};
         }
       chain_bar();              // the hidden chunk is complete
+      if (14 + 3 * h < 32) stamp(14 + 3 * h);       // (GELU + both barriers)
       __builtin_amdgcn_sched_barrier(0);
       gemm(std::integral_constant<int, NT>{}, std::integral_constant<int, HLD / 32>{}, std::integral_constant<int, HLD>{}, R, panelH, false);
       __builtin_amdgcn_sched_barrier(0);
+      if (15 + 3 * h < 32) stamp(15 + 3 * h);       // (linear2 partial)
     }
     stamp(6);
     if constexpr (PARK) {

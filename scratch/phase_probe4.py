@@ -23,7 +23,7 @@ for ver in ("1", "4"):
     _lib.check(case.model._lib().a2p_debug_read(case.model._ctx, b"clk", a.ctypes.data_as(C.c_void_p), a.nbytes), "clk")
     st = a[64 * 32: 64 * 32 + 64].astype(np.float64) * 0.01     # us
     for blk in (0, 1):
-        h = st[blk * 32: blk * 32 + 13]
+        h = st[blk * 32: blk * 32 + 32]
         names = G4M if (ver == "4" and os.environ.get("A2P_STAMP_LAUNCH") in ("1", "2", "3")) else G4P
         if ver == "1":
             parts = [f"{G1[i - 1]}={h[i] - h[i - 1]:.2f}" for i in range(1, 13) if h[i] > 0 and h[i - 1] > 0]
@@ -35,4 +35,12 @@ for ver in ("1", "4"):
                     parts.append(f"{n}={h[i] - h[prev]:.2f}")
                     prev = i
             tot = h[prev] - h[0]
+            if names is G4P and h[13] > 0:   # feed-forward block, per hidden chunk: linear1 | GELU + barriers | linear2 (wave 0's view)
+                ff, prev = [], 5
+                for c in range(6):
+                    i = 13 + 3 * c
+                    if i + 2 < 32 and h[i + 2] > 0:
+                        ff.append(f"[{h[i] - h[prev]:.2f} {h[i + 1] - h[i]:.2f} {h[i + 2] - h[i + 1]:.2f}]")
+                        prev = i + 2
+                parts.append("ffn chunks (lin1 gelu+bar lin2): " + " ".join(ff))
         print(f"B={B} gen {ver} block {'0' if blk == 0 else '101'}: total={tot:.2f} us | " + " ".join(parts), flush=True)
