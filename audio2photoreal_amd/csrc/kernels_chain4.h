@@ -35,7 +35,8 @@
 #define CHAIN4_ASM_ALL 0     // A/B builds: inline-asm panel-fragment reads in every tall kernel (default: the 80-row POST kernel only)
 #endif
 #ifndef CHAIN4_PF_MID
-#define CHAIN4_PF_MID 8        // ... of the MID kernels (which have registers to spare)
+#define CHAIN4_PF_MID 16       // ... of the 48-row MID kernel, which has the registers (208 used): 27.2 -> 26.4 us at B=8 (profiles/r05_chain4_mid_ring16_ab.txt);
+                               // at 80 rows a 16-deep ring spills 37-71 registers (38 -> 52 us), at 64 rows it is unmeasured: both keep 8
 #endif
 #ifndef CHAIN4_PF_POST3
 #define CHAIN4_PF_POST3 8
@@ -98,7 +99,7 @@ __global__ __launch_bounds__(256) void chain4_pack_kernel(const ChainPackDesc* _
 
 template <int MT, int MODE, bool LAST>
 __device__ __forceinline__ void chain4_body(const ChainP& p, h16_t* const smem, const int m0) {
-  constexpr int D = 512, NW = 8, CW = 16, BM = 16 * MT, NT = 4, KC = D / 32, FT = 8, HLD = Chain4Lds<MT>::HC, NH = HLD / 128, PF = MODE == CHAIN_MID ? CHAIN4_PF_MID : (MT == 3 ? CHAIN4_PF_POST3 : CHAIN4_PF);
+  constexpr int D = 512, NW = 8, CW = 16, BM = 16 * MT, NT = 4, KC = D / 32, FT = 8, HLD = Chain4Lds<MT>::HC, NH = HLD / 128, PF = (MODE == CHAIN_MID && MT == 3) ? CHAIN4_PF_MID : (MODE == CHAIN_POST && MT == 3) ? CHAIN4_PF_POST3 : CHAIN4_PF;
   constexpr int AUX_F = Chain4Lds<MT>::AUX_F;
   h16_t* const panelA = smem;
   h16_t* const panelH = panelA + BM * D;
