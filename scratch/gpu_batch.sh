@@ -1,20 +1,15 @@
 #!/bin/bash
-# round 5, call 33: 48-row MID kernel with the 16-deep ring in the library: bit-identity tests, smoke(), same-box B=8 A/B vs the previous build
+# round 5, call 34: final HEAD -- full GPU suite, smoke(), default bench line (-> profiles/r05_bench_default.json)
 R=${GRAFT_REPO_ROOT:-/root/repo}
 O=$R/gpurun_out; mkdir -p $O
 cd $R
-timeout -k 5 600 python -m pytest tests/test_hip_round5.py -m gpu -q > $O/r05_c33_tests.log 2>&1; grep -E "passed|failed|FAILED|AssertionError: " $O/r05_c33_tests.log | head
+( time timeout -k 5 1200 python -m pytest tests -m gpu -q -x ) > $O/r05_c34_tests.log 2>&1; tail -5 $O/r05_c34_tests.log
 timeout -k 5 300 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -2
-for lib in prev new prev new; do
-  if [ $lib = prev ]; then export A2P_LIB_F16=$R/scratch/ab/liba2p_prev_f16.so; else unset A2P_LIB_F16; fi
-  timeout -k 5 300 python bench.py --batch 8 --no-cpu-baseline --no-parity --no-legs --steps 100 --warmup 10 > $O/r05_c33_b8_$lib.json 2> $O/r05_c33_b8_$lib.err
-  python - <<PY
+timeout -k 5 900 python bench.py > $O/r05_c34_bench_default.json 2> $O/r05_c34_bench_default.err; python - <<PY
 import json
-try:
-    j=json.loads([l for l in open("$O/r05_c33_b8_$lib.json") if l.startswith("{")][-1])
-    k=j["kernels"]; sub=k.get("_sub_classes",{})
-    print("B=8 lib=$lib", j["value"], j["roofline"]["chain_family"], {n:v["avg_launch_us"] for n,v in sub.items()}, (j.get("under_load") or {}).get("power_w"), (j.get("under_load") or {}).get("sclk_mhz"))
-except Exception as e:
-    print("B=8 lib=$lib FAILED", e); print(open("$O/r05_c33_b8_$lib.err").read()[-1500:])
+j=json.loads([l for l in open("$O/r05_c34_bench_default.json") if l.startswith("{")][-1])
+print(j["value"], j["ms_per_step"], j["roofline"]["frac"], j["roofline"]["chain_family"], j["decoder_mfma_frac"], {n:(l.get("value"), l.get("decoder_mfma_frac")) for n,l in j["legs"].items()})
+print("under_load", j.get("under_load")); print("b32 under_load", j["legs"]["b32"].get("under_load"))
+print({n:(v["avg_launch_us"], v.get("mfma_frac")) for n,v in j["legs"]["b32"]["kernels"]["_sub_classes"].items()})
+print(json.dumps(j["box"])[:1800])
 PY
-done 2>&1 | tee $O/r05_c33_ab.txt
