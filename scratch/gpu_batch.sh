@@ -1,15 +1,19 @@
 #!/bin/bash
-# round 5, call 34: final HEAD -- full GPU suite, smoke(), default bench line (-> profiles/r05_bench_default.json)
+# round 5, calls 35+: one short B=8 / B=16 / B=32 line per box with the box and under-load records (profiles/r05_boxes.md)
 R=${GRAFT_REPO_ROOT:-/root/repo}
 O=$R/gpurun_out; mkdir -p $O
+TAG=${1:-c35}
 cd $R
-( time timeout -k 5 1200 python -m pytest tests -m gpu -q -x ) > $O/r05_c34_tests.log 2>&1; tail -5 $O/r05_c34_tests.log
-timeout -k 5 300 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -2
-timeout -k 5 900 python bench.py > $O/r05_c34_bench_default.json 2> $O/r05_c34_bench_default.err; python - <<PY
+for b in ${BATCHES:-8 16 32}; do
+  timeout -k 5 300 python bench.py --batch $b --no-cpu-baseline --no-parity --no-legs --steps 100 --warmup 10 > $O/r05_${TAG}_b$b.json 2> $O/r05_${TAG}_b$b.err
+  python - <<PY
 import json
-j=json.loads([l for l in open("$O/r05_c34_bench_default.json") if l.startswith("{")][-1])
-print(j["value"], j["ms_per_step"], j["roofline"]["frac"], j["roofline"]["chain_family"], j["decoder_mfma_frac"], {n:(l.get("value"), l.get("decoder_mfma_frac")) for n,l in j["legs"].items()})
-print("under_load", j.get("under_load")); print("b32 under_load", j["legs"]["b32"].get("under_load"))
-print({n:(v["avg_launch_us"], v.get("mfma_frac")) for n,v in j["legs"]["b32"]["kernels"]["_sub_classes"].items()})
-print(json.dumps(j["box"])[:1800])
+try:
+    j=json.loads([l for l in open("$O/r05_${TAG}_b$b.json") if l.startswith("{")][-1])
+    sub=j["kernels"].get("_sub_classes",{}); ul=j.get("under_load") or {}; bx=j["box"]
+    uid=[r for r in (bx.get("showhw") or []) if "Unique ID" in r]
+    print("B=$b", j["value"], j["roofline"]["chain_family"], {n:v["avg_launch_us"] for n,v in sub.items()}, ul.get("power_w"), ul.get("sclk_mhz"), ul.get("junction_c"), uid)
+except Exception as e:
+    print("B=$b FAILED", e); print(open("$O/r05_${TAG}_b$b.err").read()[-800:])
 PY
+done
