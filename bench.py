@@ -175,9 +175,11 @@ class Case:
         torch.cuda.synchronize()
         self.prepare_s = time.perf_counter() - t0
         with torch.no_grad():
-            # warm-up forwards (with A2P_CHAIN_TUNE=1 the library also measures which chain-kernel workgroup shape is faster on
-            # THIS box during the first 6 forwards of a given size: csrc/a2p_lib_run.h chain_pick_nw)
-            for _ in range(6):
+            # warm-up forwards: the library measures which chain-kernel family (MID / POST: kernels_chain.h or the tall kernels) is faster on
+            # THIS box during the first 10 forwards of a given size (csrc/a2p_lib_run.h chain_pick_family; with A2P_CHAIN_TUNE=1 another 6
+            # for the workgroup shape, chain_pick_nw) -- all of them here, so that no timed step carries a calibration event wait whatever
+            # --warmup the caller passes
+            for _ in range(18):
                 self.cfg(self.x, self.steps_idx[0], self.y)
         torch.cuda.synchronize()
 
