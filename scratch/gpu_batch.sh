@@ -1,19 +1,18 @@
 #!/bin/bash
-# round 5, calls 35+: one short B=8 / B=16 / B=32 line per box with the box and under-load records (profiles/r05_boxes.md)
+# round 5, call 51: attn_kernel<half,64> with s_setprio(1) around its MFMA clusters (compile-time variant, A2P_ATTN_PRIO=0|1 forces) -- same-box A/B
 R=${GRAFT_REPO_ROOT:-/root/repo}
 O=$R/gpurun_out; mkdir -p $O
-TAG=${1:-c35}
 cd $R
-for b in ${BATCHES:-8 16 32}; do
-  timeout -k 5 300 python bench.py --batch $b --no-cpu-baseline --no-parity --no-legs --steps 100 --warmup 10 > $O/r05_${TAG}_b$b.json 2> $O/r05_${TAG}_b$b.err
+timeout -k 5 600 python -m pytest tests/test_hip_parity.py -m gpu -q -k "attention" > $O/r05_c51_tests.log 2>&1; tail -2 $O/r05_c51_tests.log
+for b in 8 16; do for pr in 0 1 0 1; do
+  A2P_ATTN_PRIO=$pr timeout -k 5 300 python bench.py --batch $b --no-cpu-baseline --no-parity --no-legs --steps 100 --warmup 10 > $O/r05_c51_b${b}_p$pr.json 2> $O/r05_c51_b${b}_p$pr.err
   python - <<PY
 import json
 try:
-    j=json.loads([l for l in open("$O/r05_${TAG}_b$b.json") if l.startswith("{")][-1])
-    sub=j["kernels"].get("_sub_classes",{}); ul=j.get("under_load") or {}; bx=j["box"]
-    uid=[r for r in (bx.get("showhw") or []) if "Unique ID" in r]
-    print("B=$b", j["value"], j["roofline"]["chain_family"], {n:v["avg_launch_us"] for n,v in sub.items()}, ul.get("power_w"), ul.get("sclk_mhz"), ul.get("junction_c"), uid)
+    j=json.loads([l for l in open("$O/r05_c51_b${b}_p$pr.json") if l.startswith("{")][-1])
+    k=j["kernels"]
+    print("B=$b prio=$pr", j["value"], "attn self/cross us", k["attn_self"]["avg_launch_us"], k["attn_cross"]["avg_launch_us"], "chain", k["chain"]["avg_launch_us"])
 except Exception as e:
-    print("B=$b FAILED", e); print(open("$O/r05_${TAG}_b$b.err").read()[-800:])
+    print("B=$b prio=$pr FAILED", e); print(open("$O/r05_c51_b${b}_p$pr.err").read()[-1200:])
 PY
-done
+done; done 2>&1 | tee $O/r05_c51_ab.txt
