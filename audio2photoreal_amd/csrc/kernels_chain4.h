@@ -41,6 +41,9 @@
 #ifndef CHAIN4_PF_POST3
 #define CHAIN4_PF_POST3 8
 #endif
+#ifndef CHAIN4_PARK3
+#define CHAIN4_PARK3 0         // 48-row POST kernel with parked rows (frees 48 registers, e.g. for a 16-deep ring: CHAIN4_PF_POST3=16)
+#endif
 #define CHAIN4_HS_ELEMS 4096   // 128 output columns x 32 k: 8 KiB
 
 template <int MT>
@@ -525,7 +528,7 @@ __device__ __forceinline__ void chain4_body(const ChainP& p, h16_t* const smem, 
     // 64 / 80-row panels: the rows are PARKED (stored, re-read) around the feed-forward block and again around the [Q|K] GEMM -- 80 registers
     // per lane that the linear2 partials / the four-tile groups need.  At 48 rows they stay in registers from load to the final
     // store (X), as in kernels_chain.h: no extra traffic, and no store in front of a GEMM's weight loads.
-    constexpr bool PARK = MT >= 4;   // (64 rows without parking: 91 registers spilled)
+    constexpr bool PARK = MT >= 4 || CHAIN4_PARK3;   // (64 rows without parking: 91 registers spilled)
     ln_write(R, E4_LNA_G, F);
     [[maybe_unused]] f32x4 X[PARK ? 1 : NT][PARK ? 1 : MT];
     // (parked in the tiled layout whatever the final layout is: a 16-row block occupies the same bytes in both, and the workgroup owns
