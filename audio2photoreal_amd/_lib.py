@@ -76,6 +76,7 @@ class A2PPrecisionWarning(UserWarning):
 # (profiles/r04_trained_like_budget.json, IEEE half, error of the ddim loop's return value: q/k rows x2 -> maximum 13.5, 5.1e-4;
 # every weight x2 -> 13.1, 9.3e-4; q/k rows x3 -> 29.3, 2.8e-3; the xavier fixtures reach 17.7 late in the ddim10 loop at 3.7e-4)
 LOGIT_ENVELOPE_FP16 = 20.0
+ERR_NONFINITE = -5     # include/a2p_hip.h A2P_ERR_NONFINITE (a2p_check_finite)
 
 
 _libs = {}

@@ -23,6 +23,7 @@ from __future__ import annotations
 
 import enum
 import math
+import threading
 from copy import deepcopy
 
 import numpy as np
@@ -126,6 +127,7 @@ class GaussianDiffusion:
         self.posterior_mean_coef1 = betas * np.sqrt(acp_prev) / (1.0 - acp)
         self.posterior_mean_coef2 = (1.0 - acp_prev) * np.sqrt(alphas) / (1.0 - acp)
         self._dev_cache = {}
+        self._escalation = threading.local()    # per-thread "the model escalated during this call" flag (_run_call)
 
     # ------------------------------------------------------------------ device tables
     def _variance_tables(self):
@@ -298,10 +300,12 @@ class GaussianDiffusion:
             except (StopIteration, AttributeError):
                 device = None
         rng = _rng_snapshot(device)
-        self._call_escalated = False
+        # the flag is per THREAD: two host threads may sample with one diffusion object (bench.py --pipeline runs the face and the body
+        # chain of a subject side by side); a `step_noise` callable must be a pure function of the step index -- it is called again
+        self._escalation.flag = False
         out = run()
-        if self._call_escalated:
-            self._call_escalated = False
+        if self._escalation.flag:
+            self._escalation.flag = False
             _rng_restore(device, rng)
             out = run()
         return out
@@ -352,7 +356,7 @@ class GaussianDiffusion:
         # non-progressive loops (p_sample_loop / ddim_sample_loop / plms_sample_loop) repeat the call; a consumer of the progressive
         # generators has already been handed those steps -- it gets the warning, and fp32 from its next call on.
         if callable(chk) and not deferred and chk() == "escalated":
-            self._call_escalated = True
+            self._escalation.flag = True
 
     def p_sample_loop_progressive(self, model, shape, noise=None, clip_denoised=True, denoised_fn=None, cond_fn=None,
                                   model_kwargs=None, device=None, progress=False, skip_timesteps=0, init_image=None,

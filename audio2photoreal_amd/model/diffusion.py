@@ -425,13 +425,25 @@ class FiLMTransformer(nn.Module):
             peak, outside = C.c_float(float("-inf")), C.c_int32(0)
             _lib.check(lib.a2p_precision_verdict(self._ctx, C.byref(peak), C.byref(outside), stream), "a2p_precision_verdict")
             self.last_logit_max = float(peak.value)
-            _lib.check(lib.a2p_check_finite(self._ctx, stream), "a2p_check_finite")
-        if not outside.value:
+            rc = lib.a2p_check_finite(self._ctx, stream)      # reads AND clears the device flag
+        # A 16-bit evaluation that overflowed to inf / nan is the hardest way of leaving the 16-bit envelope (the logit maximum may
+        # itself be nan then and compare as "inside"): with auto_escalate it must end in the fp32 answer like any other excursion, not
+        # in an exception.  Only the fp32 mode -- or a caller that switched escalation off -- raises.
+        nonfinite_16bit = rc == _lib.ERR_NONFINITE and self.precision != "fp32" and self.auto_escalate
+        if rc < 0 and not nonfinite_16bit:
+            _lib.check(rc, "a2p_check_finite")
+        elif rc < 0:
+            del _lib._failed[:]                               # the failure note of the call we just absorbed
+        if not outside.value and not nonfinite_16bit:
             return None
         import warnings
-        head = (f"attention logits reach {self.last_logit_max:.1f} (row maximum of q.k/sqrt(d_head)): beyond {_lib.LOGIT_ENVELOPE_FP16:g} the "
-                f"16-bit operand rounding of precision=\"{self.precision}\" costs more than the 1e-3 parity bar on the sampler's return "
-                "value (measured 2.8e-3 at 29, divergent at 54: profiles/r04_trained_like_budget.json)")
+        if nonfinite_16bit:
+            head = (f"a denoiser evaluation in precision=\"{self.precision}\" produced inf / nan (16-bit operand overflow; attention logit "
+                    f"maximum {self.last_logit_max:.1f})")
+        else:
+            head = (f"attention logits reach {self.last_logit_max:.1f} (row maximum of q.k/sqrt(d_head)): beyond {_lib.LOGIT_ENVELOPE_FP16:g} the "
+                    f"16-bit operand rounding of precision=\"{self.precision}\" costs more than the 1e-3 parity bar on the sampler's return "
+                    "value (measured 2.8e-3 at 29, divergent at 54: profiles/r04_trained_like_budget.json)")
         if not self.auto_escalate:
             warnings.warn(head + "; precision=\"fp32\" is exact there", _lib.A2PPrecisionWarning, stacklevel=2)
             return None

@@ -85,7 +85,7 @@ def gather_blocks(local: torch.Tensor, sizes: Sequence[int], group=None, mode: O
               link, one hop, no padding).  The payload here is ~2 MB per rank and latency-bound, which is
               the regime where N-1 serial ring hops cost more than N-1 parallel direct copies.
 
-    Both give identical bytes (tests/test_multiprocess_cpu.py)."""
+    Both give identical bytes (tests/test_host_cpu.py: ring vs p2p with 2 and 3 gloo ranks, an empty rank included)."""
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
         return local
     world, rank = dist.get_world_size(group), dist.get_rank(group)
@@ -127,36 +127,60 @@ def gather_samples(local: torch.Tensor, total: int, group=None) -> torch.Tensor:
     return gather_blocks(local, sizes, group)
 
 
-def agree_on_failure(failed: bool, group=None, device=None) -> List[int]:
-    """Control plane, 1 int per rank: the ranks that report `failed` (empty list = nobody).  One small all_gather in front of the
-    data-path collective so that an exception on one rank becomes an exception on all of them instead of a collective timeout."""
+def agree_flags(values: Sequence[int], group=None, device=None) -> List[List[int]]:
+    """Control plane, len(values) ints per rank: every rank's flags, in rank order.  ONE small all_gather in front of the data-path
+    collective.  `device`: where the flags live under backend "nccl" -- the device of THIS rank's communicator (the shard's device;
+    callers pass it explicitly: `torch.cuda.current_device()` is only a last resort, a rank that failed before it touched the GPU
+    may never have called `torch.cuda.set_device`)."""
     world = dist.get_world_size(group)
     backend = dist.get_backend(group)
-    dev = device if (backend == "nccl" and device is not None and device.type == "cuda") else \
-        (torch.device("cuda", torch.cuda.current_device()) if backend == "nccl" else torch.device("cpu"))
-    flag = torch.tensor([1 if failed else 0], dtype=torch.int32, device=dev)
+    if backend == "nccl":
+        dev = device if (device is not None and torch.device(device).type == "cuda") else torch.device("cuda", torch.cuda.current_device())
+    else:
+        dev = torch.device("cpu")
+    flag = torch.tensor([int(v) for v in values], dtype=torch.int32, device=dev)
     flags = [torch.zeros_like(flag) for _ in range(world)]
     dist.all_gather(flags, flag, group=group)
-    return [r for r in range(world) if int(flags[r].item()) != 0]
+    return [[int(v) for v in flags[r].tolist()] for r in range(world)]
 
 
-def _set_batch_hint(model, total: int):
-    """Tell the denoiser(s) behind `model` (a FiLMTransformer, possibly inside ClassifierFreeSampleModel-style wrappers) how large the
-    unsharded batch is: the HIP library picks its kernel family from that, not from the shard (include/a2p_hip.h a2p_set_batch_hint)."""
+def agree_on_failure(failed: bool, group=None, device=None) -> List[int]:
+    """The ranks that report `failed` (empty list = nobody): an exception on one rank becomes an exception on all of them instead of
+    a collective timeout."""
+    return [r for r, f in enumerate(agree_flags([1 if failed else 0], group, device)) if f[0] != 0]
+
+
+def _denoisers(model) -> list:
+    """The FiLMTransformer(s) behind `model` (possibly inside ClassifierFreeSampleModel-style wrappers)."""
     seen, out, m = set(), [], model
     while m is not None and id(m) not in seen:
         seen.add(id(m))
         if hasattr(m, "global_batch_hint"):
-            m.global_batch_hint = total
             out.append(m)
         m = getattr(m, "model", None)
+    return out
+
+
+def _set_batch_hint(model, total: int):
+    """Tell the denoiser(s) behind `model` how large the unsharded batch is: the HIP library picks its kernel family from that, not
+    from the shard (include/a2p_hip.h a2p_set_batch_hint)."""
+    out = _denoisers(model)
+    for m in out:
+        m.global_batch_hint = total
     return out
 
 
 def sample_parallel(sample_fn: Callable, model, shape: Sequence[int], model_kwargs: Dict,
                     noise: Optional[torch.Tensor] = None, step_noise=None, group=None, **kw) -> torch.Tensor:
     """Run `sample_fn` (e.g. diffusion.ddim_sample_loop / p_sample_loop) on this rank's block of the
-    global batch `shape[0]` and gather.  `noise` / `step_noise[i]` are full-batch tensors (or None)."""
+    global batch `shape[0]` and gather.  `noise` / `step_noise[i]` are full-batch tensors (or None); a callable `step_noise` must be a
+    pure function of the step index (it is called again when a shard is repeated).
+
+    Precision is a property of the BATCH, not of a shard: a 1-GPU run whose 16-bit logits leave the validated envelope escalates the
+    whole batch to fp32 (FiLMTransformer.check_finite), so when ANY shard escalated, every rank switches its replica to fp32 and
+    repeats its shard under the same random draws -- the 1/2/4/8-GPU results stay identical.  The verdicts travel in the same 8-byte
+    control-plane all_gather as the failure flags."""
+    from .diffusion.gaussian_diffusion import _rng_restore, _rng_snapshot
     world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
     rank = dist.get_rank(group) if world > 1 else 0
     total = shape[0]
@@ -170,30 +194,70 @@ def sample_parallel(sample_fn: Callable, model, shape: Sequence[int], model_kwar
             local_step = lambda n: step_noise(n)[lo:hi].contiguous()
         else:
             local_step = [s[lo:hi].contiguous() for s in step_noise]
+    dens = _denoisers(model)
+    dev = noise.device if noise is not None else None
+    if dev is None:
+        try:
+            dev = next(model.parameters()).device
+        except (StopIteration, AttributeError, TypeError):
+            dev = None
+    rng = _rng_snapshot(dev)
+
+    def run_shard():
+        if hi <= lo:
+            ref = noise if noise is not None else torch.zeros(1)
+            return torch.zeros((0,) + tuple(shape[1:]), dtype=torch.float32, device=ref.device)
+        extra = {} if local_step is None else {"step_noise": local_step}
+        hinted = _set_batch_hint(model, total if world > 1 else 0)   # every shard takes the kernel family of the unsharded run
+        try:
+            return sample_fn(model, local_shape, noise=local_noise, model_kwargs=kwargs, **extra, **kw)
+        finally:
+            for m in hinted:
+                m.global_batch_hint = 0
+
     # A failure on one rank (A2PError from the non-finite check, a bad input, ...) must not leave the others waiting in the final
-    # collective until it times out: every rank reports into one MAX-reduced flag first and all of them raise together.
+    # collective until it times out: every rank reports into one all_gather first and all of them raise together.
     err: Optional[BaseException] = None
     local = None
+    before = [getattr(m, "precision", None) for m in dens]
     try:
-        if hi > lo:
-            extra = {} if local_step is None else {"step_noise": local_step}
-            hinted = _set_batch_hint(model, total if world > 1 else 0)   # every shard takes the kernel family of the unsharded run
-            try:
-                local = sample_fn(model, local_shape, noise=local_noise, model_kwargs=kwargs, **extra, **kw)
-            finally:
-                for m in hinted:
-                    m.global_batch_hint = 0
-        else:
-            ref = noise if noise is not None else torch.zeros(1)
-            local = torch.zeros((0,) + tuple(shape[1:]), dtype=torch.float32, device=ref.device)
+        local = run_shard()
     except Exception as e:   # noqa: BLE001 -- re-raised below, on every rank
         if world == 1:
             raise
         err = e
     if world > 1:
-        failed = agree_on_failure(err is not None, group, device=None if local is None else local.device)
+        cdev = local.device if local is not None else dev
+        escalated = any(b != "fp32" and getattr(m, "precision", None) == "fp32" for m, b in zip(dens, before))
+        flags = agree_flags([1 if err is not None else 0, 1 if escalated else 0], group, device=cdev)
+        failed = [r for r, f in enumerate(flags) if f[0]]
         if err is not None:
             raise err
         if failed:
             raise RuntimeError(f"sample_parallel: rank(s) {failed} failed inside the sampling loop; rank {rank} stops before the gather")
+        if any(f[1] for f in flags) and not escalated and any(getattr(m, "precision", "fp32") != "fp32" for m in dens):
+            import warnings
+            from . import _lib
+            for m in dens:
+                if getattr(m, "precision", "fp32") != "fp32":
+                    m.escalated_from = getattr(m, "escalated_from", None) or m.precision
+                    m.set_precision("fp32")
+            warnings.warn(f"sample_parallel: rank(s) {[r for r, f in enumerate(flags) if f[1]]} escalated their shard to precision=\"fp32\"; "
+                          f"rank {rank} repeats its shard in fp32 so that the sharded batch equals the unsharded one", _lib.A2PPrecisionWarning,
+                          stacklevel=2)
+            try:
+                _rng_restore(dev, rng)
+                local = run_shard()
+            except Exception as e:   # noqa: BLE001
+                err = e
+            again = agree_on_failure(err is not None, group, device=cdev)
+            if err is not None:
+                raise err
+            if again:
+                raise RuntimeError(f"sample_parallel: rank(s) {again} failed while repeating their shard in fp32")
+        elif any(f[1] for f in flags):
+            # this rank escalated itself (its loop already repeated the call): it still joins the second agreement of the others
+            again = agree_on_failure(False, group, device=cdev)
+            if again:
+                raise RuntimeError(f"sample_parallel: rank(s) {again} failed while repeating their shard in fp32")
     return gather_samples(local, total, group)

@@ -458,15 +458,34 @@ def cpu_and_parity(case, dev, want_parity=True, chain_steps=1000, chain_batch=2)
     fnb = lambda xx, ts: den.forward_cfg(xx, ts, ceb, scb)
     nzb = [torch.randn(xb.shape, generator=g) for _ in range(3)]
     n_b = 2
+    tb_list = [999, 998, 997]
+    want_b = []                                            # the oracle's outputs at the BENCHMARKED batch: parity.b<B> below
     with torch.no_grad():
-        cur = smp.p_sample(fnb, xb, torch.full((Bc,), 999), nzb[0])["sample"]     # warm-up at the real batch
+        out = smp.p_sample(fnb, xb, torch.full((Bc,), 999), nzb[0])     # warm-up at the real batch
+        want_b.append(out)
+        warm = out["sample"]
+        cur = warm
         t0 = time.perf_counter()
         for k in range(n_b):
-            cur = smp.p_sample(fnb, cur, torch.full((Bc,), 998 - k), nzb[1 + k])["sample"]
+            out = smp.p_sample(fnb, cur, torch.full((Bc,), 998 - k), nzb[1 + k])
+            want_b.append(out)
+            cur = out["sample"]
         bdt = time.perf_counter() - t0
+        # SURVEY section 8d asks for the box's cores: the same two steps again with every host CPU as a torch thread (the 32-thread figure
+        # stays the headline of this record: past ~32 threads these matmul sizes stop scaling, and both are printed so nobody has to trust that)
+        all_cores = None
+        if ncpu > threads:
+            torch.set_num_threads(ncpu)
+            cur = smp.p_sample(fnb, xb, torch.full((Bc,), 999), nzb[0])["sample"]     # re-warm the larger pool
+            t0 = time.perf_counter()
+            for k in range(n_b):
+                cur = smp.p_sample(fnb, cur, torch.full((Bc,), 998 - k), nzb[1 + k])["sample"]
+            adt = time.perf_counter() - t0
+            all_cores = {"value": round(n_b / adt, 5), "cores": ncpu, "seconds": round(adt, 2)}
+            torch.set_num_threads(threads)
     cpu = {"value": round(n_b / bdt, 5),
            "unit": f"denoise steps/sec at batch {Bc} (the whole batch timed: {n_b} steps)",
-           "cores": threads, "host_cpus": ncpu, "kind": "port",
+           "cores": threads, "host_cpus": ncpu, "all_host_cpus_as_threads": all_cores, "kind": "port",
            "sample": f"oracle (torch CPU fp32 restatement of the reference algorithm, conditioning path recomputed every forward like "
                      f"the reference's decoder-only path), {Bc} samples x {n_b} DDPM steps (t = 998, 997) after one warm-up step, "
                      f"T={T}, S={S0 + 2}: {bdt:.2f} s",
@@ -519,9 +538,37 @@ def cpu_and_parity(case, dev, want_parity=True, chain_steps=1000, chain_batch=2)
             cfg.model.release()
         return rec
 
+    def gpu_batch(precision):
+        """The benchmarked batch itself against the oracle: the SAME three p_sample steps (t = 999, 998, 997; same x_T, conditioning and
+        noise for all B samples) the cpu_baseline run above pushed through the oracle, chained on the GPU's own outputs."""
+        if precision == case.precision:
+            cfg, diff = case.cfg, case.diffusion
+        else:
+            m, diff = create_model_and_diffusion(default_args(case.fmt, timestep_respacing=""), "test", precision=precision, max_batch=Bc)
+            load_model(m, case.sd)
+            cfg = ClassifierFreeSampleModel(m.to(dev).eval())
+        idx = diff._step_index_tensor(dev, Bc)
+        rec = {}
+        with torch.no_grad():
+            cur = case.x.contiguous()
+            for k, t in enumerate(tb_list):
+                out = diff.p_sample(cfg, cur, idx[t], clip_denoised=False, model_kwargs={"y": case.y}, noise=nzb[k].to(dev))
+                cur = out["sample"]
+                for key in ("sample", "pred_xstart"):
+                    rec[f"t{t}_{key}"] = {kk: float(f"{v:.3e}") for kk, v in rel_errors(out[key], want_b[k][key]).items()}
+            per_sample = [rel_errors(out["sample"][b], want_b[-1]["sample"][b])["rel_l2"] for b in range(Bc)]
+        rec["last_step_worst_single_sample_rel_l2"] = float(f"{max(per_sample):.3e}")
+        if cfg is not case.cfg:
+            cfg.model.release()
+        return rec
+
     parity = {"reference": "oracle/a2p_oracle.py (CPU fp32), pinned to reference-generated goldens by tests/test_oracle_golden.py",
               "shape": f"{case.fmt} B=1 T={T} S={S0 + 2}, p_sample at t={t_list}",
               "short": {"fp32": gpu_short("fp32"), "bf16": gpu_short("bf16"), "fp16": gpu_short("fp16")}}
+    parity[f"b{Bc}"] = {"what": f"the benchmarked batch ({case.fmt} B={Bc} x2 CFG, T={T}, S={S0 + 2}) through the oracle AND the product: "
+                                f"chained p_sample at t={tb_list}, identical x_T / conditioning / noise (the oracle run is the cpu_baseline's)",
+                        "chain_family": chain_family(case),
+                        case.precision: gpu_batch(case.precision), "fp32": gpu_batch("fp32")}
     if chain_steps:
         finals = {}
         Bc = chain_batch
@@ -554,6 +601,8 @@ def cpu_and_parity(case, dev, want_parity=True, chain_steps=1000, chain_batch=2)
     worst = {}
     for prec in ("fp32", "fp16", "bf16"):
         vals = [v["rel_l2"] for v in parity["short"][prec].values()]
+        if prec in parity[f"b{Bc}"]:
+            vals += [v["rel_l2"] for v in parity[f"b{Bc}"][prec].values() if isinstance(v, dict)]
         if "chain" in parity and prec in parity["chain"]:
             vals.append(parity["chain"][prec]["rel_l2"])
         worst[prec] = max(vals)
@@ -832,6 +881,20 @@ def main():
     ap.add_argument("--write-parity", default=None, help="also write the parity record to this JSON file (profiles/r02_parity.json)")
     a = ap.parse_args()
 
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` started directly (the form the driver uses at N=1): launch the N ranks ourselves, one process per
+        # GPU, exactly as `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py <args>`
+        # would; rank 0 of that job prints the one JSON line on this process's stdout
+        import socket
+        import subprocess
+        s = socket.socket()
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+        s.close()
+        env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={a.gpus}", "--master-addr", "127.0.0.1",
+               "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        sys.exit(subprocess.call(cmd, env=env))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))

@@ -606,3 +606,65 @@ def test_loops_repeat_the_first_step_or_the_call_when_the_model_escalates():
     inside, c3 = _EscalatingModel([None, None]), []
     got = run(inside, c3)
     assert len(c3) == 5 and inside.checks == 2 and not torch.equal(got, want)         # stays 16-bit: one pass
+
+
+# ----------------------------------------------------------------------------- round 6: precision is a property of the BATCH
+class _ShardModel:
+    """Stands in for a 16-bit FiLMTransformer behind sample_parallel: escalates itself when its shard holds a 'hot' sample."""
+    def __init__(self):
+        self.global_batch_hint, self.precision, self.escalated_from, self.runs = 0, "fp16", None, []
+
+    def set_precision(self, p):
+        self.precision = p
+
+
+def _precision_loop(model, shape, noise=None, model_kwargs=None, **kw):
+    hot = bool((model_kwargs["y"]["scale"] > 1.5).any()) if shape[0] else False
+    if model.precision != "fp32" and hot:        # what check_finite() + _run_call do: escalate, repeat the call in fp32
+        model.escalated_from, model.precision = model.precision, "fp32"
+    model.runs.append(model.precision)
+    return noise + (0.0 if model.precision == "fp32" else 1e-3)      # the two modes give different numbers
+
+
+def _precision_worker(rank, world, port, out_dir):
+    import datetime
+    import warnings
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=60))
+    total = 5
+    shape = (total, 4, 1, 6)
+    noise = per_sample_noise(shape, list(range(total)))
+    y = {"cond_embed": torch.zeros(total, 3, 2), "scale": torch.tensor([1.0, 1.0, 1.0, 1.0, 2.0])}   # only the LAST rank's shard is hot
+    m = _ShardModel()
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        res = sample_parallel(_precision_loop, m, shape, {"y": y}, noise=noise)
+    torch.save((res, m.runs, m.precision, m.escalated_from, [str(x.message) for x in w]), os.path.join(out_dir, f"q{rank}.pt"))
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_one_escalating_shard_moves_every_rank_to_fp32(tmp_path, world):
+    """each rank used to decide on escalation alone, from the logit maximum of its own shard -- some shards fp32,
+    some fp16, where the 1-GPU run escalates the whole batch.  The verdict now travels with the failure flag: if any rank escalated,
+    every other rank switches its replica to fp32 and repeats its shard, so the sharded result equals the single-process result."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    mp.spawn(_precision_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    total = 5
+    shape = (total, 4, 1, 6)
+    noise = per_sample_noise(shape, list(range(total)))
+    y = {"cond_embed": torch.zeros(total, 3, 2), "scale": torch.tensor([1.0, 1.0, 1.0, 1.0, 2.0])}
+    want = sample_parallel(_precision_loop, _ShardModel(), shape, {"y": y}, noise=noise)      # one process: the whole batch in fp32
+    assert torch.equal(want, noise)
+    for r in range(world):
+        res, runs, prec, esc_from, warns = torch.load(tmp_path / f"q{r}.pt", weights_only=False)
+        assert torch.equal(res, want), f"rank {r}: sharded result differs from the unsharded one"
+        assert prec == "fp32" and esc_from == "fp16"
+        if r == world - 1:
+            assert runs == ["fp32"] and not warns                     # the hot shard escalated inside its own loop
+        else:
+            assert runs == ["fp16", "fp32"] and any("repeats its shard in fp32" in x for x in warns)
