@@ -1,0 +1,560 @@
+// Third attention kernel of the 16-bit modes (round 6): ONE wave per SIMD, 80 queries per wave, and a tile body written at ISA level.
+//
+// What rounds 2-5 measured about attn_kernel / attn2_kernel (docs/lab_notebook_r1_r4.md 4.2, docs/lab_notebook_r5.md 4): per 64-key
+// tile a 32-query wave issues 32 MFMAs against ~220 VALU instructions (6.8 per MFMA), the loop is instruction-ISSUE bound, and every
+// term of the ablation adds.  Round 6 measured the issue model itself (scratch/ubench/mfma_fill.hip, profiles/r06_mfma_fill.txt): in
+// one wave's in-order stream a v_mfma_f32_16x16x32 (18 cycles back to back) hides TWO single-issue instructions; every further one
+// costs 4 cycles, a v_exp_f32 counts as two.  So the levers are (1) fewer vector instructions per score and (2) exactly the right
+// instructions between the MFMAs -- which a compiler-scheduled kernel cannot be talked into (see `step`).
+//
+//   1. VALU instructions per score.  attn_kernel pays, per score: scale-and-subtract fma, exp2, row-sum add, max, convert, AND one
+//      multiply of the O accumulator (head_dim 64 = 64 O rows per query against 64 keys per tile: the unconditional `o *= alpha` is as
+//      many instructions as the exponentials).  Here
+//        * Q is multiplied by log2(e)/sqrt(dh) ONCE when its fragments are loaded;
+//        * the running reference m_ref of the online softmax enters the score tile through the MFMA's C operand (S = K Q^T - m_ref:
+//          the accumulator is initialised with -m_ref instead of 0), so P = exp2(S) needs no subtract;
+//        * m_ref is LAZY (guide T13): it only moves when some score exceeds it by more than THR = 8 (P <= 256: exact in the fp32 sums,
+//          the same relative rounding in the 16-bit P operand); the test is one wave vote per tile step and the rare fix-up (rescale O
+//          and l, recompute or shift the pending score tile) is its own block OUTSIDE the fast loop.  Softmax is invariant to the
+//          reference value: the result differs from the exact-max form by rounding only.
+//      Fast path per score: exp2, add, half a max3, half a convert = 3 instructions (4 issue slots) instead of ~6.8.
+//   2. The stream.  For the five query tiles q of a wave, "group q" is 16 MFMAs -- O^T[q] += V^T(t) P[q]^T (8), then
+//      S[q] = K(t+1) Q[q]^T - m_ref[q] (8, overwriting the consumed scores in place) -- with the softmax of query tile q+1 and the maxima
+//      of the S[q-1] written one group earlier issued between them, packet by packet.
+//
+// Geometry: workgroup = 4 waves x 5 query tiles of 16 = 320 queries; T = 600 -> 2 workgroups per (sequence, head) pair; the headline
+// launch (16 sequences x 8 heads) is 256 workgroups = exactly one per CU, every SIMD carries 5 query tiles (attn_kernel: 6 on the
+// busy half).  K / V^T tiles of 64 keys arrive by LDS-DMA into an 8-slot ring, inline asm + counted vmcnt.  Fragment layouts,
+// swizzles, the key <-> fragment map, slot-indexed K/V, time-token tail, XCD-aware grid, non-temporal policy, logit maximum and the
+// LDS-transposed store are attn_kernel's.
+//
+// REGISTER OWNERSHIP.  The score tile (80 registers), the five row-sum accumulators and the five running maxima live in
+// v[A3_OWN : 255] and are addressed LITERALLY by the asm statements; hipcc is held below A3_OWN (amdgpu_num_vgpr) and never sees
+// them.  History of why (each seen in the ISA of a build of this file): builtins + sched_barrier(0) after every packet came out
+// with all 80 exponentials of a step in front of its first MFMA (instruction selection linearises pure values before the scheduler
+// ever sees the barriers); asm volatile statements keep their order, but with the tile as a C++ value hipcc parked the loop-carried
+// tile in the accumulator file around the loop header (80 v_accvgpr_write + 80 v_accvgpr_read per step) whenever ANY other code in
+// the kernel -- a second step variant, the fix-up block, the partial last tile -- touched it, and copied fresh MFMA results two
+// instructions behind their (to it, opaque) producer, i.e. before they had landed.  Owned registers end all of that.
+#pragma once
+#include "kernels_attn.h"
+
+template <int B, int E, class F>
+__device__ __forceinline__ void attn3_static_for(F&& f) {   // f(integral_constant<int, B>) ... f(integral_constant<int, E - 1>)
+  if constexpr (B < E) {
+    f(std::integral_constant<int, B>{});
+    attn3_static_for<B + 1, E>(f);
+  }
+}
+
+template <int DH>
+struct Attn3Geo {
+  using L = AttnLds<h16_t, DH>;
+  static constexpr int NW = 4, NS = 8;                  // waves per workgroup, ring slots
+  static constexpr int NPK = DH / 8, NPV = DH / 8;      // 1 KiB DMA pieces per K tile / V^T tile
+  static constexpr int PW = (NPK + NPV) / NW;           // pieces per wave per tile (4 at DH = 64, 2 at DH = 32)
+  static constexpr int SLOT = L::KSZ + L::VSZ;          // elements per ring slot (K tile, then V^T tile)
+  static_assert((NPK + NPV) % NW == 0, "pieces must divide over the waves");
+};
+
+#define A3_QT 5
+// Owned registers.  Vector file, v[A3_OWN : 255] (hipcc allocates v0 .. v[A3_OWN - 1]):
+#define A3_OWN 128
+#define A3_PF(b, c) (128 + 4 * (2 * (b) + (c)))   // P fragment tuples (MFMA B operand), double-buffered over query tiles: b = q & 1, c = key chunk
+#define A3_CI(q) (144 + 4 * (q))                  // -m_ref of query tile q, four copies: the C operand of its first QK^T MFMA
+#define A3_L(q) (164 + (q))                       // row-sum accumulator of query tile q (per lane: the lane's keys)
+#define A3_M(q) (169 + (q))                       // running maximum of query tile q's scores RELATIVE to its reference (per lane)
+#define A3_SB 176                                 // score (kt, q, r): v[A3_SB + 4 * (kt * A3_QT + q) + r]; tuples are MFMA C/D operands
+#define A3_S(kt, q, r) (A3_SB + 4 * ((kt) * A3_QT + (q)) + (r))
+// Accumulator file, a[0 : 183] (hipcc is given no reason to touch the accumulator file at all: every "a" value is literal):
+#define A3_AO(q, dv, DVT_) (4 * ((q) * (DVT_) + (dv)))          // O^T accumulators a[0 : 79]
+#define A3_AQ(q, kc, KC_) (80 + 4 * ((q) * (KC_) + (kc)))       // Q fragments a[80 : 119]
+#define A3_AK(kc, kt) (120 + 4 * ((kc) * 4 + (kt)))             // K fragments of the next tile a[120 : 151]
+#define A3_AV(c, dv, DVT_) (152 + 4 * ((c) * (DVT_) + (dv)))    // V^T fragments of the current tile a[152 : 183]
+#ifndef A3X
+#define A3X 0   // scratch timing experiments (results wrong): 1 no exp2, 2 no maxima, 4 no softmax packets at all, 8 no MFMAs, 16 no fragment reads
+#endif
+#ifndef A2P_ATTN3_THR
+#define A2P_ATTN3_THR 8.0f     // log2 units a score may exceed the lazy reference by before the reference moves
+#endif
+#ifdef A2P_HALF
+#define A3_MFMA "v_mfma_f32_16x16x32_f16"
+#define A3_CVT "v_cvt_pk_f16_f32"
+#else
+#define A3_MFMA "v_mfma_f32_16x16x32_bf16"
+#define A3_CVT "v_cvt_pk_bf16_f32"
+#endif
+// wait states behind an asm MFMA before anything but an accumulating MFMA may touch its result (nobody pads inside or behind asm:
+// cdna_hip_programming.md 5.7; 8-pass MFMA -> VALU)
+#define A3_MFMA_LANDED() asm volatile("s_nop 15\n\ts_nop 7" ::: "memory")
+
+// ABL (scratch/attn3_bench.hip only): 64 no tile DMA after the prologue, 128 no barriers
+template <int DH, int ABL = 0>
+__global__ __launch_bounds__(256, 1) __attribute__((amdgpu_num_vgpr(A3_OWN))) void attn3_kernel(AttnP p) {
+  using P = Prec<h16_t>;
+  using G = Attn3Geo<DH>;
+  using L = typename G::L;
+  constexpr int QT = A3_QT, KV = 64, NW = G::NW, NS = G::NS, PW = G::PW, BQ = NW * QT * 16;
+  constexpr int KC = DH / 32, DVT = DH / 16;
+  typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+  __shared__ __attribute__((aligned(16))) h16_t smem[NS * G::SLOT];
+  static_assert(BQ * (DH + 8) <= NS * G::SLOT, "output staging does not fit the tile ring");
+  asm volatile("" ::: "v255", "a183");   // (the kernel descriptor must cover the owned registers of both files)
+
+  const int lane = threadIdx.x & 63, wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int l15 = lane & 15, g = lane >> 4;
+  int qb, head, seq;
+  {
+    const int b = blockIdx.x;
+    if (p.xcd_remap) {
+      const int xcd = b & 7, j = b >> 3, pair = (j / p.nq) * 8 + xcd;
+      qb = j % p.nq;
+      head = pair % p.nheads;
+      seq = pair / p.nheads;
+    } else {
+      qb = b % p.nq;
+      head = (b / p.nq) % p.nheads;
+      seq = b / (p.nq * p.nheads);
+    }
+  }
+  const int slot = attn_slot(p, seq);
+  const int q0 = qb * BQ + wid * (QT * 16);
+  const bool kv_nt = p.kv_stream && slot != 0;
+  const int S_total = p.S_main + p.S_tail;
+  const int ntiles = (S_total + KV - 1) / KV;
+  const int nfull = S_total / KV;                 // full tiles; a partial last tile (index nfull) is drained behind the loop
+  const int rem = S_total - nfull * KV;           // its keys
+  const bool wave_active = __builtin_amdgcn_readfirstlane(q0) < p.Tq;
+
+  const h16_t* Qb = reinterpret_cast<const h16_t*>(p.Q) + (int64_t)seq * p.q_seq_stride + head * DH;
+  const h16_t* Kb = reinterpret_cast<const h16_t*>(p.K) + (int64_t)slot * p.k_slot_stride + head * DH;
+  const h16_t* Vb = reinterpret_cast<const h16_t*>(p.VT) + (int64_t)slot * p.vt_slot_stride + (int64_t)head * DH * p.ldvt;
+
+  // ---- tile DMA (attn2_kernel's: inline asm so that hipcc neither waits for it nor orders LDS reads behind it) ----
+  // piece pi of a tile = K piece pi (pi < NPK) or V^T piece pi - NPK; wave w owns pieces w, w + NW, ...: its first NPK / NW are K pieces
+  constexpr int CPR = DH / 8, KRPI = 64 / CPR, KPW = G::NPK / NW;
+  int64_t src_off[PW];
+  int dst_off[PW];
+#pragma unroll
+  for (int j = 0; j < PW; ++j) {
+    const int pi = wid + j * NW;
+    if (j < KPW) {
+      const int kr = pi * KRPI + lane / CPR;
+      src_off[j] = (int64_t)kr * p.ldk + (((lane % CPR) ^ L::kswz(kr)) << 3);
+      dst_off[j] = pi * KRPI * DH;
+    } else {
+      const int vp = pi - G::NPK, vr = vp * 8 + (lane >> 3);
+      src_off[j] = (int64_t)vr * p.ldvt + (((lane & 7) ^ L::vswz(vr)) << 3);
+      dst_off[j] = L::KSZ + vp * 8 * KV;
+    }
+  }
+  auto issue_tile = [&](int tile, int rs) __attribute__((always_inline)) {
+    h16_t* sl = smem + rs * G::SLOT;
+    const h16_t* Kt = Kb + (int64_t)tile * KV * p.ldk;
+    const h16_t* Vt = Vb + tile * KV;
+    if (kv_nt) {   // block-uniform: ONE branch per tile
+#pragma unroll
+      for (int j = 0; j < PW; ++j) {
+        const uint32_t m0v = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) h16_t*)(sl + dst_off[j]);
+        asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off nt" ::"s"(m0v), "v"((j < KPW ? Kt : Vt) + src_off[j]) : "memory");
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < PW; ++j) {
+        const uint32_t m0v = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) h16_t*)(sl + dst_off[j]);
+        asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(m0v), "v"((j < KPW ? Kt : Vt) + src_off[j]) : "memory");
+      }
+    }
+  };
+  // the last tile(s) in LDS, by the whole workgroup (block-uniform call sites): the time-token rows are written into it (attn_kernel),
+  // and the rows / columns of keys past the end are made harmless -- K rows become copies of the tile's key 0 (their scores are
+  // real, finite duplicates: they cannot raise a running maximum; the scores themselves are masked to -inf before the exponentials),
+  // V^T columns become 0 (they are never-written memory: 0 x (inf | nan) = nan, kernels_attn.h load_vfr)
+  auto finish_last_tile = [&](int tile, int rs) __attribute__((always_inline)) {
+    h16_t* Ks = smem + rs * G::SLOT;
+    h16_t* Vs = Ks + L::KSZ;
+    const int kv0 = tile * KV;
+    if (p.S_tail > 0 && kv0 + KV > p.S_main) {
+      const int sample = seq % p.tail_mod;
+      for (int e = threadIdx.x; e < p.S_tail * DH; e += 64 * NW) {
+        const int j = e / DH, c = e % DH;
+        const int kl = p.S_main + j - kv0;
+        if (kl >= 0 && kl < KV) {
+          const int64_t off = (int64_t)sample * p.tail_sample_stride + (int64_t)j * p.tail_row_stride + head * DH + c;
+          Ks[L::kidx(kl, c)] = (h16_t)p.ktail[off];
+          Vs[L::vidx(c, kl)] = (h16_t)p.vtail[off];
+        }
+      }
+    }
+    const int nvalid = S_total - kv0;
+    if (nvalid < KV) {
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();   // (key 0 may itself be a time token written above)
+      for (int e = threadIdx.x; e < (KV - nvalid) * DH; e += 64 * NW) {
+        const int kl = nvalid + e / DH, c = e % DH;
+        Ks[L::kidx(kl, c)] = Ks[L::kidx(0, c)];
+        Vs[L::vidx(c, kl)] = (h16_t)0.f;
+      }
+    }
+  };
+  // does anything have to be written into `tile` once it has landed?  (time tokens: the last tile, or the last two when S_main % 64 == 63)
+  auto needs_finish = [&](int tile) __attribute__((always_inline)) {
+    return tile < ntiles && ((p.S_tail > 0 && tile * KV + KV > p.S_main) || (tile + 1 == ntiles && rem > 0));
+  };
+
+  // ---- state ----
+  float mref[QT];            // (the only per-query state hipcc sees)
+#pragma unroll
+  for (int q = 0; q < QT; ++q) mref[q] = 0.f;
+  attn3_static_for<0, QT>([&](auto q_c) __attribute__((always_inline)) {
+    constexpr int q = decltype(q_c)::value;
+    // l = 0, running maximum = -inf, reference 0
+    asm volatile("v_mov_b32 v[%c0], 0\n\tv_mov_b32 v[%c1], 0xff800000" ::"n"(A3_L(q)), "n"(A3_M(q)));
+    asm volatile("v_mov_b32 v[%c0], 0\n\tv_mov_b32 v[%c1], 0\n\tv_mov_b32 v[%c2], 0\n\tv_mov_b32 v[%c3], 0" ::"n"(A3_CI(q)), "n"(A3_CI(q) + 1), "n"(A3_CI(q) + 2), "n"(A3_CI(q) + 3));
+    attn3_static_for<0, 4 * DVT>([&](auto e_c) __attribute__((always_inline)) {
+      constexpr int e = decltype(e_c)::value;
+      asm volatile("v_accvgpr_write_b32 a[%c0], 0" ::"n"(A3_AO(q, 0, DVT) + e));
+    });
+  });
+
+  // LDS byte addresses of this lane's K / V^T fragments inside ring slot 0.  The swizzle of a fragment depends on the lane only, the
+  // k-chunk (kc / c) flips one bit of the swizzled chunk index (hence one base per chunk), kt / dv are plain row offsets (immediates)
+  const unsigned smem_base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) h16_t*)smem;
+  unsigned kbase[KC], vbase[2];
+#pragma unroll
+  for (int kc = 0; kc < KC; ++kc) kbase[kc] = smem_base + 2u * (unsigned)L::kidx(L::krow(0, l15), kc * 32 + g * 8);
+#pragma unroll
+  for (int c = 0; c < 2; ++c) vbase[c] = smem_base + 2u * (unsigned)(L::KSZ + L::vidx(l15, c * 32 + g * 8));
+
+  // K / V^T fragments of the tile in ring slot rs -> their accumulator registers (ds_read_b128 straight into the accumulator file:
+  // MFMA A operands may live there)
+  auto read_kf = [&](unsigned rs) __attribute__((always_inline)) {
+    attn3_static_for<0, KC>([&](auto k_c) __attribute__((always_inline)) {
+      constexpr int kc = decltype(k_c)::value;
+      (void)&kbase;
+      const unsigned a = kbase[kc] + rs * (unsigned)(G::SLOT * 2);
+      attn3_static_for<0, 4>([&](auto t_c) __attribute__((always_inline)) {
+        constexpr int kt = decltype(t_c)::value, R = A3_AK(kc, kt);
+        (void)&a;
+        if constexpr (!(A3X & 16)) asm volatile("ds_read_b128 a[%c0:%c1], %2 offset:%3" ::"n"(R), "n"(R + 3), "v"(a), "n"((32 * (kt >> 1) + 4 * (kt & 1)) * L::LSK * 2));
+      });
+    });
+  };
+  auto read_vf = [&](unsigned rs) __attribute__((always_inline)) {
+    attn3_static_for<0, 2>([&](auto c_c) __attribute__((always_inline)) {
+      constexpr int c = decltype(c_c)::value;
+      (void)&vbase;
+      const unsigned a = vbase[c] + rs * (unsigned)(G::SLOT * 2);
+      attn3_static_for<0, DVT>([&](auto d_c) __attribute__((always_inline)) {
+        constexpr int dv = decltype(d_c)::value, R = A3_AV(c, dv, DVT);
+        (void)&a;
+        if constexpr (!(A3X & 16)) asm volatile("ds_read_b128 a[%c0:%c1], %2 offset:%3" ::"n"(R), "n"(R + 3), "v"(a), "n"(dv * 16 * L::LSV * 2));
+      });
+    });
+  };
+  auto wait_lds = [&]() __attribute__((always_inline)) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); };
+
+  // ---- cold code on the owned registers (prologue, reference moves, the partial last tile): plain sequences, nothing interleaved ----
+  // S = K(tile in slot rs) Q^T - m_ref for all query tiles
+  auto qk_owned = [&](unsigned rs) __attribute__((always_inline)) {
+    read_kf(rs);
+    wait_lds();
+    attn3_static_for<0, KC>([&](auto k_c) __attribute__((always_inline)) {
+      attn3_static_for<0, 4>([&](auto t_c) __attribute__((always_inline)) {
+        attn3_static_for<0, QT>([&](auto q_c) __attribute__((always_inline)) {
+          constexpr int kc = decltype(k_c)::value, kt = decltype(t_c)::value, q = decltype(q_c)::value, R = A3_S(kt, q, 0);
+          if constexpr (kc == 0) asm volatile(A3_MFMA " v[%c0:%c1], a[%c2:%c3], a[%c4:%c5], v[%c6:%c7]" ::"n"(R), "n"(R + 3), "n"(A3_AK(kc, kt)), "n"(A3_AK(kc, kt) + 3), "n"(A3_AQ(q, kc, KC)), "n"(A3_AQ(q, kc, KC) + 3), "n"(A3_CI(q)), "n"(A3_CI(q) + 3));
+          else asm volatile(A3_MFMA " v[%c0:%c1], a[%c2:%c3], a[%c4:%c5], v[%c0:%c1]" ::"n"(R), "n"(R + 3), "n"(A3_AK(kc, kt)), "n"(A3_AK(kc, kt) + 3), "n"(A3_AQ(q, kc, KC)), "n"(A3_AQ(q, kc, KC) + 3));
+        });
+      });
+    });
+    A3_MFMA_LANDED();
+  };
+  // scores of keys past the end of `tile` -> -inf (per-lane predicate: the lane's keys of S^T tile kt are krow(kt, 4 g + r))
+  auto mask_owned = [&](int tile) __attribute__((always_inline)) {
+    const int kv0 = tile * KV;
+    attn3_static_for<0, 4>([&](auto t_c) __attribute__((always_inline)) {
+      attn3_static_for<0, 4>([&](auto r_c) __attribute__((always_inline)) {
+        constexpr int kt = decltype(t_c)::value, r = decltype(r_c)::value;
+        if (kv0 + L::krow(kt, g * 4 + r) >= S_total) {
+          attn3_static_for<0, QT>([&](auto q_c) __attribute__((always_inline)) {
+            constexpr int q = decltype(q_c)::value;
+            asm volatile("v_mov_b32 v[%c0], 0xff800000" ::"n"(A3_S(kt, q, r)));
+          });
+        }
+      });
+    });
+  };
+  auto max_owned = [&]() __attribute__((always_inline)) {   // fold the tile into the running maxima
+    attn3_static_for<0, QT>([&](auto q_c) __attribute__((always_inline)) {
+      attn3_static_for<0, 8>([&](auto j_c) __attribute__((always_inline)) {
+        constexpr int q = decltype(q_c)::value, j = decltype(j_c)::value, R = A3_S(j >> 1, q, (j & 1) * 2);
+        asm volatile("v_max3_f32 v[%c0], v[%c0], v[%c1], v[%c2]" ::"n"(A3_M(q)), "n"(R), "n"(R + 1));
+      });
+    });
+  };
+  // does any running maximum of the wave exceed its reference by more than THR?
+  auto must_move = [&]() __attribute__((always_inline)) {
+    float a, b;
+    asm volatile("v_max3_f32 %0, v[%c1], v[%c2], v[%c3]" : "=v"(a) : "n"(A3_M(0)), "n"(A3_M(1)), "n"(A3_M(2)));
+    asm volatile("v_max3_f32 %0, %1, v[%c2], v[%c3]" : "=v"(b) : "v"(a), "n"(A3_M(3)), "n"(A3_M(4)));
+    return __any(b > A2P_ATTN3_THR);
+  };
+  // The references move to the exact running row maxima: O and l rescaled, the running maxima re-based; the pending score tile is
+  // shifted in place (SHIFT) or left to the caller to recompute from the K tile that is still in the ring.  Rare after the first tile.
+  auto move_refs = [&](auto shift_c) __attribute__((always_inline)) {
+    constexpr bool SHIFT = decltype(shift_c)::value;
+    attn3_static_for<0, QT>([&](auto q_c) __attribute__((always_inline)) {
+      constexpr int q = decltype(q_c)::value;
+      (void)&mref;
+      float m;
+      asm volatile("v_mov_b32 %0, v[%c1]" : "=v"(m) : "n"(A3_M(q)));
+      const float d = attn_rowgroup_max(m);    // over the 4 lanes that share the query column
+      const float f = __builtin_amdgcn_exp2f(-d);
+      mref[q] += d;
+      const float nm = -mref[q];
+      asm volatile("v_sub_f32 v[%c0], v[%c0], %2\n\tv_mul_f32 v[%c1], v[%c1], %3" ::"n"(A3_M(q)), "n"(A3_L(q)), "v"(d), "v"(f));
+      asm volatile("v_mov_b32 v[%c0], %4\n\tv_mov_b32 v[%c1], %4\n\tv_mov_b32 v[%c2], %4\n\tv_mov_b32 v[%c3], %4" ::"n"(A3_CI(q)), "n"(A3_CI(q) + 1), "n"(A3_CI(q) + 2), "n"(A3_CI(q) + 3), "v"(nm));
+      attn3_static_for<0, 4 * DVT>([&](auto e_c) __attribute__((always_inline)) {   // O *= f (through a vector register: the accumulator file has no arithmetic)
+        constexpr int e = decltype(e_c)::value;
+        (void)&f;
+        float x;
+        asm volatile("v_accvgpr_read_b32 %0, a[%c1]" : "=v"(x) : "n"(A3_AO(q, 0, DVT) + e));
+        x *= f;
+        asm volatile("v_accvgpr_write_b32 a[%c0], %1" ::"n"(A3_AO(q, 0, DVT) + e), "v"(x));
+      });
+      if constexpr (SHIFT) {
+        attn3_static_for<0, 16>([&](auto n_c) __attribute__((always_inline)) {
+          constexpr int n = decltype(n_c)::value;
+          (void)&d;
+          asm volatile("v_sub_f32 v[%c0], v[%c0], %1" ::"n"(A3_S(n >> 2, q, n & 3)), "v"(d));
+        });
+      }
+    });
+    asm volatile("s_nop 7" ::: "memory");   // (v_accvgpr_write / VALU writes -> MFMA operands: wait states nobody else inserts)
+  };
+
+  // ---- prologue ----
+  issue_tile(0, 0);
+  {
+    h16x8 qf[QT][KC];          // Q fragments (B operand of S^T = K Q^T): lane (query l15, k-group g), pre-multiplied by log2(e) / sqrt(dh)
+#pragma unroll
+    for (int q = 0; q < QT; ++q) {
+      int qi = q0 + q * 16 + l15;
+      if (qi >= p.Tq) qi = p.Tq - 1;
+#pragma unroll
+      for (int kc = 0; kc < KC; ++kc) qf[q][kc] = P::load(Qb + (int64_t)qi * p.ldq + kc * 32 + g * 8);
+    }
+    attn3_static_for<0, QT>([&](auto q_c) __attribute__((always_inline)) {
+      attn3_static_for<0, KC>([&](auto k_c) __attribute__((always_inline)) {
+        constexpr int q = decltype(q_c)::value, kc = decltype(k_c)::value;
+        (void)&qf;
+        asm volatile("" : "+v"(qf[q][kc]));   // hipcc's own vmcnt(0) for the Q loads lands here, not inside the loop (attn2_kernel)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) qf[q][kc][e] = (h16_t)((float)qf[q][kc][e] * p.scale_log2e);
+        const u32x4 w = __builtin_bit_cast(u32x4, qf[q][kc]);
+        asm volatile("v_accvgpr_write_b32 a[%c0], %4\n\tv_accvgpr_write_b32 a[%c1], %5\n\tv_accvgpr_write_b32 a[%c2], %6\n\tv_accvgpr_write_b32 a[%c3], %7"
+                     ::"n"(A3_AQ(q, kc, KC)), "n"(A3_AQ(q, kc, KC) + 1), "n"(A3_AQ(q, kc, KC) + 2), "n"(A3_AQ(q, kc, KC) + 3), "v"(w[0]), "v"(w[1]), "v"(w[2]), "v"(w[3]));
+      });
+    });
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+  for (int t = 1; t < NS - 1; ++t)
+    if (t < ntiles) issue_tile(t, t);
+  __builtin_amdgcn_s_barrier();
+  if (needs_finish(0)) {
+    finish_last_tile(0, 0);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+  }
+
+  // ---- one tile step ----------------------------------------------------------------------------------------------------------------
+  // Query-tile-major software pipeline, written out in ISSUE order (an in-order wave overlaps vector and matrix work only if they
+  // alternate in its instruction stream).  Every instruction is `asm volatile`: volatile statements keep their SOURCE ORDER.  hipcc
+  // still allocates the registers of the values it can see ("a" = accumulator file: O, Q and the K / V^T fragments, which ds_read_b128
+  // loads straight into it; "v": P fragments, -m_ref) and pads nothing: every reader of an MFMA result sits at least one MFMA group
+  // (>= 8 MFMAs) behind its producer, or behind A3_MFMA_LANDED.
+  // QK = false: the drain behind the loop (softmax + O^T += V^T P^T of the last tile only).
+  auto step = [&](int t, int tn, auto qk_c) __attribute__((always_inline)) {
+    constexpr bool QK = decltype(qk_c)::value;
+    read_vf((unsigned)(t & (NS - 1)));
+    if constexpr (QK) read_kf((unsigned)(tn & (NS - 1)));
+    // softmax packet n of query tile q, in issue order: exp2 of score n, the row-sum add of score n - 2, the convert of score pair
+    // (n - 5) / 2 into the P fragment registers of the query tile.  Every index is a compile-time constant (attn3_static_for).
+    auto soft = [&](auto n_c, auto q_c) __attribute__((always_inline)) {
+      constexpr int n = decltype(n_c)::value, q = decltype(q_c)::value;
+      if constexpr (n < 16 && !(A3X & 5)) asm volatile("v_exp_f32 v[%c0], v[%c0]" ::"n"(A3_S(n >> 2, q, n & 3)));
+      if constexpr (n >= 2 && n < 18 && !(A3X & 4)) asm volatile("v_add_f32 v[%c0], v[%c0], v[%c1]" ::"n"(A3_L(q)), "n"(A3_S((n - 2) >> 2, q, (n - 2) & 3)));
+      if constexpr (n >= 5 && ((n - 5) & 1) == 0 && (n - 5) / 2 < 8 && !(A3X & 4)) {
+        constexpr int j = (n - 5) / 2, c = j >> 2, w = j & 3, kt = 2 * c + (w >> 1), r0 = (w & 1) * 2;
+        asm volatile(A3_CVT " v[%c0], v[%c1], v[%c2]" ::"n"(A3_PF(q & 1, c) + w), "n"(A3_S(kt, q, r0)), "n"(A3_S(kt, q, r0 + 1)));
+      }
+    };
+    constexpr int NSOFT = 21;   // n = 0 .. 20 covers 16 exps, 16 adds, 8 converts
+    // query tile 0 has no MFMA group in front of it in this step
+    attn3_static_for<0, NSOFT>([&](auto n_c) __attribute__((always_inline)) { soft(n_c, std::integral_constant<int, 0>{}); });
+    wait_lds();
+    constexpr int NM = QK ? 2 * DVT + 4 * KC : 2 * DVT;   // MFMAs per group
+    attn3_static_for<0, QT>([&](auto q_c) __attribute__((always_inline)) {
+      constexpr int q = decltype(q_c)::value;
+      constexpr int qp = q > 0 ? q - 1 : 0;
+      attn3_static_for<0, NM>([&](auto i_c) __attribute__((always_inline)) {
+        constexpr int i = decltype(i_c)::value;
+        if constexpr (i < 2 * DVT) {
+          constexpr int c = i / DVT, dv = i % DVT, RO = A3_AO(q, dv, DVT);
+          if constexpr (!(A3X & 8)) asm volatile(A3_MFMA " a[%c0:%c1], a[%c2:%c3], v[%c4:%c5], a[%c0:%c1]" ::"n"(RO), "n"(RO + 3), "n"(A3_AV(c, dv, DVT)), "n"(A3_AV(c, dv, DVT) + 3), "n"(A3_PF(q & 1, c)), "n"(A3_PF(q & 1, c) + 3));
+        } else {
+          constexpr int kc = (i - 2 * DVT) / 4, kt = (i - 2 * DVT) % 4, R = A3_S(kt, q, 0);
+          if constexpr (A3X & 8) {}
+          else if constexpr (kc == 0) asm volatile(A3_MFMA " v[%c0:%c1], a[%c2:%c3], a[%c4:%c5], v[%c6:%c7]" ::"n"(R), "n"(R + 3), "n"(A3_AK(kc, kt)), "n"(A3_AK(kc, kt) + 3), "n"(A3_AQ(q, kc, KC)), "n"(A3_AQ(q, kc, KC) + 3), "n"(A3_CI(q)), "n"(A3_CI(q) + 3));
+          else asm volatile(A3_MFMA " v[%c0:%c1], a[%c2:%c3], a[%c4:%c5], v[%c0:%c1]" ::"n"(R), "n"(R + 3), "n"(A3_AK(kc, kt)), "n"(A3_AK(kc, kt) + 3), "n"(A3_AQ(q, kc, KC)), "n"(A3_AQ(q, kc, KC) + 3));
+        }
+        // fillers: the softmax of query tile q + 1 spread over the group's NM gaps, the maxima of S[q - 1] in every other gap
+        if constexpr (q + 1 < QT) {
+          constexpr int n0 = (i * NSOFT) / NM, n1 = ((i + 1) * NSOFT) / NM;
+          attn3_static_for<n0, n1>([&](auto n_c) __attribute__((always_inline)) { soft(n_c, std::integral_constant<int, q + 1>{}); });
+        }
+        if constexpr (QK && q > 0 && !(A3X & 2)) {
+          constexpr int j0 = (i * 8) / NM, j1 = ((i + 1) * 8) / NM;
+          attn3_static_for<j0, j1>([&](auto j_c) __attribute__((always_inline)) {
+            constexpr int j = decltype(j_c)::value, R = A3_S(j >> 1, qp, (j & 1) * 2);
+            asm volatile("v_max3_f32 v[%c0], v[%c0], v[%c1], v[%c2]" ::"n"(A3_M(qp)), "n"(R), "n"(R + 1));
+          });
+        }
+      });
+    });
+    A3_MFMA_LANDED();
+    if constexpr (QK && !(A3X & 2)) {   // maxima of the last query tile's new scores
+      attn3_static_for<0, 8>([&](auto j_c) __attribute__((always_inline)) {
+        constexpr int j = decltype(j_c)::value, R = A3_S(j >> 1, QT - 1, (j & 1) * 2);
+        asm volatile("v_max3_f32 v[%c0], v[%c0], v[%c1], v[%c2]" ::"n"(A3_M(QT - 1)), "n"(R), "n"(R + 1));
+      });
+    }
+  };
+
+  // ring bookkeeping at the top of step t: tile t+1 landed for everyone (its K is read in this step), the slot of tile t-1 -- last read
+  // in step t-1 -- refilled with tile t+NS-1
+  auto sync_top = [&](int t) __attribute__((always_inline)) {
+    if constexpr ((ABL & 64) == 0) {
+      const int younger = ntiles - 2 - t;   // wave-uniform: tiles requested after t+1 (at most NS - 3 = 5 of them are in flight)
+      if (younger >= 5) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PW * 5) : "memory");        // steady state
+      else if (younger >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PW * 2) : "memory");   // (the last steps wait a little early: two rungs instead of five branches)
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    static_assert(NS == 8, "the wait ladder is written for 5 younger tiles");
+    if constexpr (!(ABL & 128)) __builtin_amdgcn_s_barrier();
+    if constexpr ((ABL & 64) == 0) {
+      if (t + NS - 1 < ntiles) issue_tile(t + NS - 1, (t + NS - 1) & (NS - 1));
+    }
+    if (needs_finish(t + 1)) {
+      finish_last_tile(t + 1, (t + 1) & (NS - 1));
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+    }
+  };
+  // Everything the fast loop reads is "touched" in front of it: a compiler-visible load still in flight at loop entry (a spill reload
+  // of the cold code) turns into `s_waitcnt vmcnt(N)` ladders ending in vmcnt(0) INSIDE the loop -- executed every step, and the
+  // hardware counter they wait on is the one the tile DMA lives on: the ring was drained once per step (seen in the ISA).
+  auto touch_live_ins = [&]() __attribute__((always_inline)) {
+#pragma unroll
+    for (int kc = 0; kc < KC; ++kc) asm volatile("" : "+v"(kbase[kc]));
+#pragma unroll
+    for (int c = 0; c < 2; ++c) asm volatile("" : "+v"(vbase[c]));
+#pragma unroll
+    for (int j = 0; j < PW; ++j) asm volatile("" : "+v"(src_off[j]));
+  };
+
+  const std::true_type Tt{};
+  const std::false_type Ff{};
+  if (wave_active) {
+    // S(0) against reference 0, its exact row maxima become the references
+    qk_owned(0u);
+    if (ntiles == 1 && rem > 0) mask_owned(0);
+    max_owned();
+    sync_top(0);
+    move_refs(Tt);
+    int t = 0;
+    if (nfull > 0) {
+      for (;;) {
+        touch_live_ins();
+        bool done = false;
+#pragma clang loop unroll(disable)
+        for (;;) {
+          // the next tile: t + 1 (behind the last full tile: the partial tile, whose dead keys are copies of its key 0, or -- none
+          // left -- tile t again: real, finite scores that nobody reads, so that the loop body has ONE form)
+          step(t, t + 1 < ntiles ? t + 1 : t, Tt);
+          ++t;
+          if (t >= nfull) { done = true; break; }
+          sync_top(t);
+          if (must_move()) break;
+        }
+        if (done) break;
+        move_refs(Ff);                  // some score left the window of its reference: move it, recompute S(t) from the ring, re-enter
+        qk_owned((unsigned)(t & (NS - 1)));
+      }
+      if (rem > 0) {                    // the partial last tile: its scores are in place (unmasked), sync_top(nfull - 1) made it visible
+        mask_owned(t);
+        if (must_move()) move_refs(Tt);
+      }
+    }
+    if (rem > 0) step(t, t, Ff);        // drain: softmax + O^T += V^T P^T of the partial tile
+  } else {
+    const int nsync = nfull > 0 ? nfull : 1;
+    for (int t = 0; t < nsync; ++t) sync_top(t);
+  }
+
+  float lq[QT], mq[QT];
+  attn3_static_for<0, QT>([&](auto q_c) __attribute__((always_inline)) {
+    constexpr int q = decltype(q_c)::value;
+    (void)&lq; (void)&mq;
+    asm volatile("v_mov_b32 %0, v[%c2]\n\tv_mov_b32 %1, v[%c3]" : "=v"(lq[q]), "=v"(mq[q]) : "n"(A3_L(q)), "n"(A3_M(q)));
+  });
+  if (p.stat_max && wave_active) {   // largest row maximum (natural units) of this wave's queries: m_ref + the relative running maximum
+    float m = mref[0] + mq[0];
+#pragma unroll
+    for (int q = 1; q < QT; ++q) m = fmaxf(m, mref[q] + mq[q]);
+#pragma unroll
+    for (int sh = 32; sh > 0; sh >>= 1) m = fmaxf(m, __shfl_xor(m, sh, 64));   // (the maxima are per lane: all 64 lanes)
+    const int mi = attn_ordered_int(m * 0.6931471805599453f);
+    if (lane == 0 && mi > __atomic_load_n(p.stat_max, __ATOMIC_RELAXED)) atomicMax(p.stat_max, mi);
+  }
+
+  // ---- normalise, transpose through the (idle) ring, store whole rows ----
+  constexpr int SP = DH + 8, PPR = DH / 8, NPC = QT * 16 * PPR / 64;
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();   // every wave is done reading the last tile
+  h16_t* stw = smem + wid * (QT * 16) * SP;
+  f32x4 oq[QT][DVT];
+  attn3_static_for<0, QT>([&](auto q_c) __attribute__((always_inline)) {
+    attn3_static_for<0, DVT>([&](auto d_c) __attribute__((always_inline)) {
+      constexpr int q = decltype(q_c)::value, dv = decltype(d_c)::value, R = A3_AO(q, dv, DVT);
+      (void)&oq;
+      float x0, x1, x2, x3;
+      asm volatile("v_accvgpr_read_b32 %0, a[%c4]\n\tv_accvgpr_read_b32 %1, a[%c5]\n\tv_accvgpr_read_b32 %2, a[%c6]\n\tv_accvgpr_read_b32 %3, a[%c7]"
+                   : "=v"(x0), "=v"(x1), "=v"(x2), "=v"(x3) : "n"(R), "n"(R + 1), "n"(R + 2), "n"(R + 3));
+      oq[q][dv] = f32x4{x0, x1, x2, x3};
+    });
+  });
+#pragma unroll
+  for (int q = 0; q < QT; ++q) {
+    float l = lq[q];
+    l += __shfl_xor(l, 16, 64);
+    l += __shfl_xor(l, 32, 64);
+    const float inv = 1.0f / l;
+#pragma unroll
+    for (int dv = 0; dv < DVT; ++dv) {
+      const f32x4 v = oq[q][dv];
+      *reinterpret_cast<h16x4*>(stw + (q * 16 + l15) * SP + dv * 16 + g * 4) =
+          h16x4{(h16_t)(v[0] * inv), (h16_t)(v[1] * inv), (h16_t)(v[2] * inv), (h16_t)(v[3] * inv)};
+    }
+  }
+  h16_t* Ob = reinterpret_cast<h16_t*>(p.O) + (int64_t)seq * p.o_seq_stride + head * DH;
+#pragma unroll
+  for (int i = 0; i < NPC; ++i) {
+    const int pc = lane + 64 * i, row = pc / PPR, part = pc % PPR;
+    const h16x8 v = *reinterpret_cast<const h16x8*>(stw + row * SP + part * 8);
+    const int qi = q0 + row;
+    if (qi < p.Tq) *reinterpret_cast<h16x8*>(Ob + (int64_t)qi * p.ldo + part * 8) = v;
+  }
+}

@@ -565,7 +565,7 @@ def cpu_and_parity(case, dev, want_parity=True, chain_steps=1000, chain_batch=2)
     parity = {"reference": "oracle/a2p_oracle.py (CPU fp32), pinned to reference-generated goldens by tests/test_oracle_golden.py",
               "shape": f"{case.fmt} B=1 T={T} S={S0 + 2}, p_sample at t={t_list}",
               "short": {"fp32": gpu_short("fp32"), "bf16": gpu_short("bf16"), "fp16": gpu_short("fp16")}}
-    parity[f"b{Bc}"] = {"what": f"the benchmarked batch ({case.fmt} B={Bc} x2 CFG, T={T}, S={S0 + 2}) through the oracle AND the product: "
+    parity[f"b{case.B}"] = {"what": f"the benchmarked batch ({case.fmt} B={Bc} x2 CFG, T={T}, S={S0 + 2}) through the oracle AND the product: "
                                 f"chained p_sample at t={tb_list}, identical x_T / conditioning / noise (the oracle run is the cpu_baseline's)",
                         "chain_family": chain_family(case),
                         case.precision: gpu_batch(case.precision), "fp32": gpu_batch("fp32")}
@@ -601,8 +601,8 @@ def cpu_and_parity(case, dev, want_parity=True, chain_steps=1000, chain_batch=2)
     worst = {}
     for prec in ("fp32", "fp16", "bf16"):
         vals = [v["rel_l2"] for v in parity["short"][prec].values()]
-        if prec in parity[f"b{Bc}"]:
-            vals += [v["rel_l2"] for v in parity[f"b{Bc}"][prec].values() if isinstance(v, dict)]
+        if prec in parity[f"b{case.B}"]:
+            vals += [v["rel_l2"] for v in parity[f"b{case.B}"][prec].values() if isinstance(v, dict)]
         if "chain" in parity and prec in parity["chain"]:
             vals.append(parity["chain"][prec]["rel_l2"])
         worst[prec] = max(vals)
