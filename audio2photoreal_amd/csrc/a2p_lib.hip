@@ -26,6 +26,7 @@
 #include "../../include/a2p_hip.h"
 #include "kernels_attn.h"
 #include "kernels_attn2.h"
+#include "kernels_attn3.h"
 #include "kernels_chain.h"
 #include "kernels_chain4.h"
 #include "kernels_gemm.h"
@@ -163,6 +164,9 @@ struct A2POpts {
   int force_ksplit = 0;     // A2P_ATTN_KSPLIT=1: every 16-bit attention launch takes the key-split kernel (tests)
   int chain_v = 0;          // A2P_CHAIN_V=4: tall chain kernels (kernels_chain4.h) wherever their contract holds; A2P_CHAIN_V=1: never; 0: the
                             // faster of the two families ON THIS BOX, measured during the first forwards of a size (chain_pick_family)
+  int attn3 = 1;            // A2P_ATTN3: 1 (default) = the one-wave-per-SIMD kernel with the ISA-level tile body (kernels_attn3.h) where it wins
+                            // (head_dim 64, >= 160 queries, and >= 1024 keys or at most one workgroup per CU: launch_attn); 2 = wherever it is legal
+                            // (tests); 0 = never (A/B)
   int attn2 = 0;            // A2P_ATTN2=1: the query-split 16-bit attention launches take attn2_kernel (kernels_attn2.h: one 8-wave workgroup per CU,
                             // 48 + 32 queries per SIMD, unit-level software pipeline); 0: attn_kernel
   int no_fused_kf = 0;      // A2P_NO_FUSED_KF=1: body model: MID2 | keyframe attention | POST as three launches instead of one (A/B, tests)
@@ -183,7 +187,7 @@ static void load_opts(A2POpts& o) {
   o.side_early_join = flag("A2P_SIDE_EARLY_JOIN"); o.no_shared_half = flag("A2P_NO_SHARED_HALF");
   o.graph = flag("A2P_GRAPH");
   o.no_ksplit = flag("A2P_NO_KSPLIT"); o.force_ksplit = flag("A2P_ATTN_KSPLIT"); o.ksplit_nw = num("A2P_KSPLIT_NW", 0); o.ksplit_qt = num("A2P_KSPLIT_QT", 0);
-  o.no_fused_kf = flag("A2P_NO_FUSED_KF"); o.attn2 = num("A2P_ATTN2", 0); o.chain_v = num("A2P_CHAIN_V", 0);
+  o.no_fused_kf = flag("A2P_NO_FUSED_KF"); o.attn2 = num("A2P_ATTN2", 0); o.attn3 = num("A2P_ATTN3", 1); o.chain_v = num("A2P_CHAIN_V", 0);
   o.no_small = flag("A2P_NO_SMALL"); o.chain_rows = num("A2P_CHAIN_ROWS", 1100);
 }
 
@@ -216,6 +220,7 @@ struct a2p_ctx {
   Buf tail_w, tail_b;                  // fused output tail of the body model (kernels_tail.h): packed MFMA weight operands, [8][256] biases
   int64_t tail_woff[8] = {};
   bool tail_fused = false;
+  int64_t attn3_launches = 0;          // launches of attn3_kernel (a2p_debug_read "attn3_launches")
   int64_t ch4_launches = 0;            // launches of the tall chain kernels (a2p_debug_read "chain4_launches")
   std::vector<Buf> ch_stream4w;        // POST streams with 256-column hidden chunks [layer]
   std::vector<Buf> ch_stream4;         // kernels_chain4.h: half-stage streams [layer*5 + kind] (CH_MID, CH_POST of the face model; empty Buf otherwise)
@@ -451,6 +456,26 @@ static int launch_attn(a2p_ctx* c, const AttnP& p0, int nseq, int kind, hipStrea
     else A2P_LAUNCH(kt2, (attn2_kernel<32, 3, 2>), grid2, 512, s, p);
     HIPCHK(hipGetLastError());
     return 0;
+  }
+  // Round 6: attn3_kernel (kernels_attn3.h) -- one wave per SIMD, 80 queries per wave, ISA-level tile body with a lazy softmax
+  // reference.  Measured stand-alone against attn_kernel (scratch/attn3_bench.hip, profiles/r06_attn3_bench.txt): x1.35 on the B=8
+  // cross attention (2000 keys, 256 workgroups = one per CU), x1.12 on its self attention, x1.07 on the B=32 cross attention, but
+  // x0.85 on short key ranges once the launch is several rounds of workgroups (its per-workgroup prologue is longer), and slower on
+  // the body model's head_dim 32 -- hence the rule.
+  if (c->bf16 && c->opt.attn3 && !c->opt.attn2 && (c->DH == 64 || c->DH == 32) && p.ldvt % 8 == 0) {
+    const int nq3 = (p.Tq + 319) / 320;
+    const int64_t wgs = (int64_t)nq3 * c->H * nseq;
+    const bool wins = c->DH == 64 && p.Tq >= 160 && (p.S_main + p.S_tail >= 1024 || wgs <= 256);
+    if (c->opt.attn3 >= 2 || wins) {
+      p.nq = nq3;
+      dim3 grid3((unsigned)wgs);
+      KernelTimer kt3(c, kind);
+      if (c->DH == 64) A2P_LAUNCH(kt3, (attn3_kernel<64>), grid3, 256, s, p);
+      else A2P_LAUNCH(kt3, (attn3_kernel<32>), grid3, 256, s, p);
+      HIPCHK(hipGetLastError());
+      ++c->attn3_launches;
+      return 0;
+    }
   }
   dim3 grid(p.nq * c->H * nseq);
   KernelTimer kt(c, kind);

@@ -1413,6 +1413,11 @@ extern "C" int a2p_debug_read(a2p_ctx* c, const char* name, void* host, int64_t 
     *reinterpret_cast<int32_t*>(host) = c->ch_fam_mid * 10 + c->ch_fam_post;   // 11 | 44 | 41 | 14
     return 0;
   }
+  if (n == "attn3_launches") {   // int64: launches of attn3_kernel (kernels_attn3.h) on this context so far (tests, bench)
+    ARG(bytes >= 8, "attn3_launches is one int64");
+    *reinterpret_cast<int64_t*>(host) = c->attn3_launches;
+    return 0;
+  }
   if (n == "chain4_launches") {   // int64: launches of the tall chain kernels (kernels_chain4.h) on this context so far (tests, bench)
     ARG(bytes >= 8, "chain4_launches is one int64");
     *reinterpret_cast<int64_t*>(host) = c->ch4_launches;

@@ -66,11 +66,12 @@ struct Attn3Geo {
 #define A3_M(q) (169 + (q))                       // running maximum of query tile q's scores RELATIVE to its reference (per lane)
 #define A3_SB 176                                 // score (kt, q, r): v[A3_SB + 4 * (kt * A3_QT + q) + r]; tuples are MFMA C/D operands
 #define A3_S(kt, q, r) (A3_SB + 4 * ((kt) * A3_QT + (q)) + (r))
-// Accumulator file, a[0 : 183] (hipcc is given no reason to touch the accumulator file at all: every "a" value is literal):
+// Accumulator file, a[0 : 247] (hipcc is given no reason to touch the accumulator file at all: every "a" value is literal):
 #define A3_AO(q, dv, DVT_) (4 * ((q) * (DVT_) + (dv)))          // O^T accumulators a[0 : 79]
 #define A3_AQ(q, kc, KC_) (80 + 4 * ((q) * (KC_) + (kc)))       // Q fragments a[80 : 119]
-#define A3_AK(kc, kt) (120 + 4 * ((kc) * 4 + (kt)))             // K fragments of the next tile a[120 : 151]
-#define A3_AV(c, dv, DVT_) (152 + 4 * ((c) * (DVT_) + (dv)))    // V^T fragments of the current tile a[152 : 183]
+// two fragment sets (a[120 : 183], a[184 : 247]): step t consumes set t & 1 while the fragments of step t + 1 land in the other one
+#define A3_AK(set, kc, kt) (120 + 64 * (set) + 4 * ((kc) * 4 + (kt)))           // K fragments (of the tile whose scores the step produces)
+#define A3_AV(set, c, dv, DVT_) (152 + 64 * (set) + 4 * ((c) * (DVT_) + (dv)))  // V^T fragments (of the tile the step consumes)
 #ifndef A3X
 #define A3X 0   // scratch timing experiments (results wrong): 1 no exp2, 2 no maxima, 4 no softmax packets at all, 8 no MFMAs, 16 no fragment reads
 #endif
@@ -99,7 +100,7 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_num_vgpr(A3_OWN))) vo
   typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
   __shared__ __attribute__((aligned(16))) h16_t smem[NS * G::SLOT];
   static_assert(BQ * (DH + 8) <= NS * G::SLOT, "output staging does not fit the tile ring");
-  asm volatile("" ::: "v255", "a183");   // (the kernel descriptor must cover the owned registers of both files)
+  asm volatile("" ::: "v255", "a247");   // (the kernel descriptor must cover the owned registers of both files)
 
   const int lane = threadIdx.x & 63, wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int l15 = lane & 15, g = lane >> 4;
@@ -202,6 +203,19 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_num_vgpr(A3_OWN))) vo
     return tile < ntiles && ((p.S_tail > 0 && tile * KV + KV > p.S_main) || (tile + 1 == ntiles && rem > 0));
   };
 
+#ifdef A3_STAMPS   // scratch: where does a step's time go?  s_memtime deltas summed over the steps of workgroup 0 / wave 0 (p.kv_slot = output)
+  long long stamp_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  long long stamp_last = 0;
+  const long long stamp_t0 = __builtin_readcyclecounter();
+#define A3_STAMP(k) do { const long long now_ = __builtin_readcyclecounter(); stamp_acc[k] += now_ - stamp_last; stamp_last = now_; } while (0)
+#else
+#define A3_STAMP(k) do { } while (0)
+#endif
+  // first tile that has something written into it after it landed (time tokens, padding of the partial tile)
+  int tfin = ntiles;
+  if (rem > 0) tfin = ntiles - 1;
+  if (p.S_tail > 0) tfin = min(tfin, p.S_main / KV);
+
   // ---- state ----
   float mref[QT];            // (the only per-query state hipcc sees)
 #pragma unroll
@@ -228,25 +242,25 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_num_vgpr(A3_OWN))) vo
 
   // K / V^T fragments of the tile in ring slot rs -> their accumulator registers (ds_read_b128 straight into the accumulator file:
   // MFMA A operands may live there)
-  auto read_kf = [&](unsigned rs) __attribute__((always_inline)) {
+  auto read_kf = [&](unsigned rs, auto set_c) __attribute__((always_inline)) {
     attn3_static_for<0, KC>([&](auto k_c) __attribute__((always_inline)) {
       constexpr int kc = decltype(k_c)::value;
       (void)&kbase;
       const unsigned a = kbase[kc] + rs * (unsigned)(G::SLOT * 2);
       attn3_static_for<0, 4>([&](auto t_c) __attribute__((always_inline)) {
-        constexpr int kt = decltype(t_c)::value, R = A3_AK(kc, kt);
+        constexpr int kt = decltype(t_c)::value, R = A3_AK(decltype(set_c)::value, kc, kt);
         (void)&a;
         if constexpr (!(A3X & 16)) asm volatile("ds_read_b128 a[%c0:%c1], %2 offset:%3" ::"n"(R), "n"(R + 3), "v"(a), "n"((32 * (kt >> 1) + 4 * (kt & 1)) * L::LSK * 2));
       });
     });
   };
-  auto read_vf = [&](unsigned rs) __attribute__((always_inline)) {
+  auto read_vf = [&](unsigned rs, auto set_c) __attribute__((always_inline)) {
     attn3_static_for<0, 2>([&](auto c_c) __attribute__((always_inline)) {
       constexpr int c = decltype(c_c)::value;
       (void)&vbase;
       const unsigned a = vbase[c] + rs * (unsigned)(G::SLOT * 2);
       attn3_static_for<0, DVT>([&](auto d_c) __attribute__((always_inline)) {
-        constexpr int dv = decltype(d_c)::value, R = A3_AV(c, dv, DVT);
+        constexpr int dv = decltype(d_c)::value, R = A3_AV(decltype(set_c)::value, c, dv, DVT);
         (void)&a;
         if constexpr (!(A3X & 16)) asm volatile("ds_read_b128 a[%c0:%c1], %2 offset:%3" ::"n"(R), "n"(R + 3), "v"(a), "n"(dv * 16 * L::LSV * 2));
       });
@@ -256,15 +270,15 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_num_vgpr(A3_OWN))) vo
 
   // ---- cold code on the owned registers (prologue, reference moves, the partial last tile): plain sequences, nothing interleaved ----
   // S = K(tile in slot rs) Q^T - m_ref for all query tiles
-  auto qk_owned = [&](unsigned rs) __attribute__((always_inline)) {
-    read_kf(rs);
+  auto qk_owned = [&](unsigned rs) __attribute__((always_inline)) {   // (uses fragment set 0: every call is followed by a `prime`)
+    read_kf(rs, std::integral_constant<int, 0>{});
     wait_lds();
     attn3_static_for<0, KC>([&](auto k_c) __attribute__((always_inline)) {
       attn3_static_for<0, 4>([&](auto t_c) __attribute__((always_inline)) {
         attn3_static_for<0, QT>([&](auto q_c) __attribute__((always_inline)) {
           constexpr int kc = decltype(k_c)::value, kt = decltype(t_c)::value, q = decltype(q_c)::value, R = A3_S(kt, q, 0);
-          if constexpr (kc == 0) asm volatile(A3_MFMA " v[%c0:%c1], a[%c2:%c3], a[%c4:%c5], v[%c6:%c7]" ::"n"(R), "n"(R + 3), "n"(A3_AK(kc, kt)), "n"(A3_AK(kc, kt) + 3), "n"(A3_AQ(q, kc, KC)), "n"(A3_AQ(q, kc, KC) + 3), "n"(A3_CI(q)), "n"(A3_CI(q) + 3));
-          else asm volatile(A3_MFMA " v[%c0:%c1], a[%c2:%c3], a[%c4:%c5], v[%c0:%c1]" ::"n"(R), "n"(R + 3), "n"(A3_AK(kc, kt)), "n"(A3_AK(kc, kt) + 3), "n"(A3_AQ(q, kc, KC)), "n"(A3_AQ(q, kc, KC) + 3));
+          if constexpr (kc == 0) asm volatile(A3_MFMA " v[%c0:%c1], a[%c2:%c3], a[%c4:%c5], v[%c6:%c7]" ::"n"(R), "n"(R + 3), "n"(A3_AK(0, kc, kt)), "n"(A3_AK(0, kc, kt) + 3), "n"(A3_AQ(q, kc, KC)), "n"(A3_AQ(q, kc, KC) + 3), "n"(A3_CI(q)), "n"(A3_CI(q) + 3));
+          else asm volatile(A3_MFMA " v[%c0:%c1], a[%c2:%c3], a[%c4:%c5], v[%c0:%c1]" ::"n"(R), "n"(R + 3), "n"(A3_AK(0, kc, kt)), "n"(A3_AK(0, kc, kt) + 3), "n"(A3_AQ(q, kc, KC)), "n"(A3_AQ(q, kc, KC) + 3));
         });
       });
     });
@@ -376,10 +390,37 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_num_vgpr(A3_OWN))) vo
   // loads straight into it; "v": P fragments, -m_ref) and pads nothing: every reader of an MFMA result sits at least one MFMA group
   // (>= 8 MFMAs) behind its producer, or behind A3_MFMA_LANDED.
   // QK = false: the drain behind the loop (softmax + O^T += V^T P^T of the last tile only).
-  auto step = [&](int t, int tn, auto qk_c) __attribute__((always_inline)) {
+  // step t consumes fragment set PAR = t & 1 (V^T(t), K(next tile): requested one step earlier, or by `prime`) and requests the
+  // fragments of step t + 1 into the other set at its very top: the 16 ds_read_b128 of a step then have a whole step to land (issued
+  // and waited for inside one step they cost 680 exposed cycles per step: 64 KiB per CU and step against the softmax of ONE query tile)
+  auto step = [&](int t, auto qk_c, auto par_c) __attribute__((always_inline)) {
     constexpr bool QK = decltype(qk_c)::value;
-    read_vf((unsigned)(t & (NS - 1)));
-    if constexpr (QK) read_kf((unsigned)(tn & (NS - 1)));
+    constexpr int PAR = decltype(par_c)::value;
+    A3_STAMP(6);  // (loop control + must_move since the last stamp)
+    wait_lds();   // the fragments of THIS step (requested a step ago: long landed)
+    // addresses of the next step's fragments; the 2 DVT + 4 KC reads themselves are issued ONE PER MFMA GAP of query tile 0's group
+    // below (sixteen ds_read_b128 back to back from four lockstep waves block each wave's issue for ~40 cycles apiece)
+    [[maybe_unused]] unsigned fa_v[2], fa_k[KC];
+    if constexpr (QK) {
+      const unsigned vs = (unsigned)(min(t + 1, ntiles - 1) & (NS - 1)) * (unsigned)(G::SLOT * 2);
+      const unsigned ks = (unsigned)(min(t + 2, ntiles - 1) & (NS - 1)) * (unsigned)(G::SLOT * 2);
+#pragma unroll
+      for (int c = 0; c < 2; ++c) fa_v[c] = vbase[c] + vs;
+#pragma unroll
+      for (int kc = 0; kc < KC; ++kc) fa_k[kc] = kbase[kc] + ks;
+    }
+    auto frag_read = [&](auto i_c) __attribute__((always_inline)) {   // read number i of the next step's fragments
+      constexpr int i = decltype(i_c)::value;
+      (void)&fa_v; (void)&fa_k;
+      if constexpr (A3X & 16) return;
+      if constexpr (i < 2 * DVT) {
+        constexpr int c = i / DVT, dv = i % DVT, R = A3_AV(PAR ^ 1, c, dv, DVT);
+        asm volatile("ds_read_b128 a[%c0:%c1], %2 offset:%3" ::"n"(R), "n"(R + 3), "v"(fa_v[c]), "n"(dv * 16 * L::LSV * 2));
+      } else {
+        constexpr int kc = (i - 2 * DVT) / 4, kt = (i - 2 * DVT) % 4, R = A3_AK(PAR ^ 1, kc, kt);
+        asm volatile("ds_read_b128 a[%c0:%c1], %2 offset:%3" ::"n"(R), "n"(R + 3), "v"(fa_k[kc]), "n"((32 * (kt >> 1) + 4 * (kt & 1)) * L::LSK * 2));
+      }
+    };
     // softmax packet n of query tile q, in issue order: exp2 of score n, the row-sum add of score n - 2, the convert of score pair
     // (n - 5) / 2 into the P fragment registers of the query tile.  Every index is a compile-time constant (attn3_static_for).
     auto soft = [&](auto n_c, auto q_c) __attribute__((always_inline)) {
@@ -394,7 +435,7 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_num_vgpr(A3_OWN))) vo
     constexpr int NSOFT = 21;   // n = 0 .. 20 covers 16 exps, 16 adds, 8 converts
     // query tile 0 has no MFMA group in front of it in this step
     attn3_static_for<0, NSOFT>([&](auto n_c) __attribute__((always_inline)) { soft(n_c, std::integral_constant<int, 0>{}); });
-    wait_lds();
+    A3_STAMP(0);  // softmax of query tile 0 (nothing to overlap with)
     constexpr int NM = QK ? 2 * DVT + 4 * KC : 2 * DVT;   // MFMAs per group
     attn3_static_for<0, QT>([&](auto q_c) __attribute__((always_inline)) {
       constexpr int q = decltype(q_c)::value;
@@ -403,14 +444,16 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_num_vgpr(A3_OWN))) vo
         constexpr int i = decltype(i_c)::value;
         if constexpr (i < 2 * DVT) {
           constexpr int c = i / DVT, dv = i % DVT, RO = A3_AO(q, dv, DVT);
-          if constexpr (!(A3X & 8)) asm volatile(A3_MFMA " a[%c0:%c1], a[%c2:%c3], v[%c4:%c5], a[%c0:%c1]" ::"n"(RO), "n"(RO + 3), "n"(A3_AV(c, dv, DVT)), "n"(A3_AV(c, dv, DVT) + 3), "n"(A3_PF(q & 1, c)), "n"(A3_PF(q & 1, c) + 3));
+          if constexpr (!(A3X & 8)) asm volatile(A3_MFMA " a[%c0:%c1], a[%c2:%c3], v[%c4:%c5], a[%c0:%c1]" ::"n"(RO), "n"(RO + 3), "n"(A3_AV(PAR, c, dv, DVT)), "n"(A3_AV(PAR, c, dv, DVT) + 3), "n"(A3_PF(q & 1, c)), "n"(A3_PF(q & 1, c) + 3));
         } else {
           constexpr int kc = (i - 2 * DVT) / 4, kt = (i - 2 * DVT) % 4, R = A3_S(kt, q, 0);
           if constexpr (A3X & 8) {}
-          else if constexpr (kc == 0) asm volatile(A3_MFMA " v[%c0:%c1], a[%c2:%c3], a[%c4:%c5], v[%c6:%c7]" ::"n"(R), "n"(R + 3), "n"(A3_AK(kc, kt)), "n"(A3_AK(kc, kt) + 3), "n"(A3_AQ(q, kc, KC)), "n"(A3_AQ(q, kc, KC) + 3), "n"(A3_CI(q)), "n"(A3_CI(q) + 3));
-          else asm volatile(A3_MFMA " v[%c0:%c1], a[%c2:%c3], a[%c4:%c5], v[%c0:%c1]" ::"n"(R), "n"(R + 3), "n"(A3_AK(kc, kt)), "n"(A3_AK(kc, kt) + 3), "n"(A3_AQ(q, kc, KC)), "n"(A3_AQ(q, kc, KC) + 3));
+          else if constexpr (kc == 0) asm volatile(A3_MFMA " v[%c0:%c1], a[%c2:%c3], a[%c4:%c5], v[%c6:%c7]" ::"n"(R), "n"(R + 3), "n"(A3_AK(PAR, kc, kt)), "n"(A3_AK(PAR, kc, kt) + 3), "n"(A3_AQ(q, kc, KC)), "n"(A3_AQ(q, kc, KC) + 3), "n"(A3_CI(q)), "n"(A3_CI(q) + 3));
+          else asm volatile(A3_MFMA " v[%c0:%c1], a[%c2:%c3], a[%c4:%c5], v[%c0:%c1]" ::"n"(R), "n"(R + 3), "n"(A3_AK(PAR, kc, kt)), "n"(A3_AK(PAR, kc, kt) + 3), "n"(A3_AQ(q, kc, KC)), "n"(A3_AQ(q, kc, KC) + 3));
         }
-        // fillers: the softmax of query tile q + 1 spread over the group's NM gaps, the maxima of S[q - 1] in every other gap
+        // fillers: the softmax of query tile q + 1 spread over the group's NM gaps, the maxima of S[q - 1] in every other gap, and in
+        // query tile 0's group one fragment read of the next step per gap
+        if constexpr (QK && q == 0) frag_read(i_c);
         if constexpr (q + 1 < QT) {
           constexpr int n0 = (i * NSOFT) / NM, n1 = ((i + 1) * NSOFT) / NM;
           attn3_static_for<n0, n1>([&](auto n_c) __attribute__((always_inline)) { soft(n_c, std::integral_constant<int, q + 1>{}); });
@@ -424,6 +467,7 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_num_vgpr(A3_OWN))) vo
         }
       });
     });
+    A3_STAMP(1);  // the five MFMA groups
     A3_MFMA_LANDED();
     if constexpr (QK && !(A3X & 2)) {   // maxima of the last query tile's new scores
       attn3_static_for<0, 8>([&](auto j_c) __attribute__((always_inline)) {
@@ -437,20 +481,37 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_num_vgpr(A3_OWN))) vo
   // in step t-1 -- refilled with tile t+NS-1
   auto sync_top = [&](int t) __attribute__((always_inline)) {
     if constexpr ((ABL & 64) == 0) {
-      const int younger = ntiles - 2 - t;   // wave-uniform: tiles requested after t+1 (at most NS - 3 = 5 of them are in flight)
-      if (younger >= 5) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PW * 5) : "memory");        // steady state
-      else if (younger >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PW * 2) : "memory");   // (the last steps wait a little early: two rungs instead of five branches)
+      const int younger = ntiles - 3 - t;   // wave-uniform: tiles requested after t+2 (at most NS - 4 = 4 of them are in flight)
+      if (younger >= 4) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PW * 4) : "memory");        // steady state
+      else if (younger >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PW * 2) : "memory");   // (the last steps wait a little early: two rungs instead of four branches)
       else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
-    static_assert(NS == 8, "the wait ladder is written for 5 younger tiles");
+    static_assert(NS == 8, "the wait ladder is written for 4 younger tiles");
+    A3_STAMP(2);  // landed-wait states + tail maxima + the tile DMA wait
     if constexpr (!(ABL & 128)) __builtin_amdgcn_s_barrier();
+    A3_STAMP(3);  // barrier
     if constexpr ((ABL & 64) == 0) {
       if (t + NS - 1 < ntiles) issue_tile(t + NS - 1, (t + NS - 1) & (NS - 1));
     }
-    if (needs_finish(t + 1)) {
-      finish_last_tile(t + 1, (t + 1) & (NS - 1));
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      __builtin_amdgcn_s_barrier();
+    A3_STAMP(4);  // tile DMA issue
+    if (t + 2 >= tfin) {   // (rare: the last one or two steps)
+      for (int tile = (t == 0 ? 1 : t + 2); tile <= t + 2; ++tile)
+        if (needs_finish(tile)) {
+          finish_last_tile(tile, tile & (NS - 1));
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+          __builtin_amdgcn_s_barrier();
+        }
+    }
+  };
+  // request the fragments step t consumes (loop entry / re-entry; inside the loop every step requests its successor's)
+  auto prime = [&](int t) __attribute__((always_inline)) {
+    const int tk = min(t + 1, ntiles - 1);
+    if (t & 1) {
+      read_vf((unsigned)(t & (NS - 1)), std::integral_constant<int, 1>{});
+      read_kf((unsigned)(tk & (NS - 1)), std::integral_constant<int, 1>{});
+    } else {
+      read_vf((unsigned)(t & (NS - 1)), std::integral_constant<int, 0>{});
+      read_kf((unsigned)(tk & (NS - 1)), std::integral_constant<int, 0>{});
     }
   };
   // Everything the fast loop reads is "touched" in front of it: a compiler-visible load still in flight at loop entry (a spill reload
@@ -467,6 +528,8 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_num_vgpr(A3_OWN))) vo
 
   const std::true_type Tt{};
   const std::false_type Ff{};
+  const std::integral_constant<int, 0> P0{};
+  const std::integral_constant<int, 1> P1{};
   if (wave_active) {
     // S(0) against reference 0, its exact row maxima become the references
     qk_owned(0u);
@@ -476,34 +539,65 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_num_vgpr(A3_OWN))) vo
     move_refs(Tt);
     int t = 0;
     if (nfull > 0) {
+      // ONE step body per parity, the rare reference move OUTSIDE the fast loop (see the header).  Behind the last full tile the
+      // "next" tile is the partial tile (its dead keys are copies of its key 0: real scores that cannot raise a maximum) or, none
+      // left, the last tile again: the step has one form.
+#ifdef A3_STAMPS
+      for (int k = 0; k < 8; ++k) stamp_acc[k] = 0;
+      stamp_last = __builtin_readcyclecounter();
+      stamp_acc[5] = stamp_last - stamp_t0;     // prologue
+#endif
       for (;;) {
         touch_live_ins();
-        bool done = false;
-#pragma clang loop unroll(disable)
-        for (;;) {
-          // the next tile: t + 1 (behind the last full tile: the partial tile, whose dead keys are copies of its key 0, or -- none
-          // left -- tile t again: real, finite scores that nobody reads, so that the loop body has ONE form)
-          step(t, t + 1 < ntiles ? t + 1 : t, Tt);
+        prime(t);
+        bool done = false, moved = false;
+        if (t & 1) {   // align the unrolled loop to an even step
+          step(t, Tt, P1);
           ++t;
-          if (t >= nfull) { done = true; break; }
-          sync_top(t);
-          if (must_move()) break;
+          if (t >= nfull) done = true;
+          else {
+            sync_top(t);
+            moved = must_move();
+          }
+        }
+        if (!done && !moved) {
+#pragma clang loop unroll(disable)
+          for (;;) {
+            step(t, Tt, P0);
+            ++t;
+            if (t >= nfull) { done = true; break; }
+            sync_top(t);
+            if (must_move()) break;
+            step(t, Tt, P1);
+            ++t;
+            if (t >= nfull) { done = true; break; }
+            sync_top(t);
+            if (must_move()) break;
+          }
         }
         if (done) break;
         move_refs(Ff);                  // some score left the window of its reference: move it, recompute S(t) from the ring, re-enter
         qk_owned((unsigned)(t & (NS - 1)));
       }
-      if (rem > 0) {                    // the partial last tile: its scores are in place (unmasked), sync_top(nfull - 1) made it visible
+      if (rem > 0) {                    // the partial last tile: its scores are in place (unmasked), its V^T fragments requested
         mask_owned(t);
         if (must_move()) move_refs(Tt);
       }
+    } else {
+      prime(0);
     }
-    if (rem > 0) step(t, t, Ff);        // drain: softmax + O^T += V^T P^T of the partial tile
+    if (rem > 0) {                      // drain: softmax + O^T += V^T P^T of the partial tile
+      if (t & 1) step(t, Ff, P1);
+      else step(t, Ff, P0);
+    }
   } else {
     const int nsync = nfull > 0 ? nfull : 1;
     for (int t = 0; t < nsync; ++t) sync_top(t);
   }
 
+#ifdef A3_STAMPS
+  const long long stamp_loop_end = __builtin_readcyclecounter();
+#endif
   float lq[QT], mq[QT];
   attn3_static_for<0, QT>([&](auto q_c) __attribute__((always_inline)) {
     constexpr int q = decltype(q_c)::value;
@@ -557,4 +651,11 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_num_vgpr(A3_OWN))) vo
     const int qi = q0 + row;
     if (qi < p.Tq) *reinterpret_cast<h16x8*>(Ob + (int64_t)qi * p.ldo + part * 8) = v;
   }
+#ifdef A3_STAMPS
+  if (blockIdx.x == 0 && threadIdx.x == 0 && p.kv_slot) {
+    stamp_acc[7] = __builtin_readcyclecounter() - stamp_loop_end;   // epilogue
+    long long* dbg = (long long*)p.kv_slot;
+    for (int k = 0; k < 8; ++k) dbg[k] = stamp_acc[k];
+  }
+#endif
 }

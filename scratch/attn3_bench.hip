@@ -126,6 +126,33 @@ int main(int argc, char** argv) {
       }
     return 0;
   }
+#ifdef A3_STAMPS
+  if (argc > 1 && !strcmp(argv[1], "st")) {
+    const int DH = 64, nseq = 16, T = 600, S_main = 1984, H = 8, d = H * DH, Sld = 2048;   // 31 full tiles, no partial tile
+    h16_t *q, *k, *vt, *o; long long* dbg;
+    CK(hipMalloc(&q, (size_t)nseq * T * d * 2)); CK(hipMalloc(&k, (size_t)(nseq + 1) * Sld * d * 2)); CK(hipMalloc(&vt, (size_t)(nseq + 1) * d * Sld * 2));
+    CK(hipMalloc(&o, (size_t)nseq * T * d * 2)); CK(hipMalloc(&dbg, 64)); CK(hipMemset(dbg, 0, 64));
+    std::vector<uint16_t> h((size_t)(nseq + 1) * Sld * d);
+    for (auto& v : h) v = rnd_h(1.5f);
+    CK(hipMemcpy(k, h.data(), h.size() * 2, hipMemcpyHostToDevice)); CK(hipMemcpy(vt, h.data(), h.size() * 2, hipMemcpyHostToDevice));
+    CK(hipMemcpy(q, h.data(), (size_t)nseq * T * d * 2, hipMemcpyHostToDevice));
+    AttnP a; memset(&a, 0, sizeof(a));
+    a.Q = q; a.q_seq_stride = (int64_t)T * d; a.ldq = d; a.K = k; a.k_slot_stride = (int64_t)Sld * d; a.ldk = d;
+    a.VT = vt; a.vt_slot_stride = (int64_t)d * Sld; a.ldvt = Sld; a.O = o; a.o_seq_stride = (int64_t)T * d; a.ldo = d;
+    a.tail_mod = nseq; a.Tq = T; a.S_main = S_main; a.S_tail = 0; a.scale_log2e = 1.4426950408889634f / 8.0f;
+    a.slot_rule = 3; a.slot_b = nseq / 2; a.kv_stream = 1; a.kv_slot = (const int*)dbg;
+    a.nheads = H; a.nseq = nseq; a.xcd_remap = 1; a.nq = (T + 319) / 320;
+    const float t0 = time_it([&] { attn3_kernel<64><<<dim3(a.nq * H * nseq), 256>>>(a); });
+    long long hd[8]; CK(hipMemcpy(hd, dbg, 64, hipMemcpyDeviceToHost));
+    const char* nm[8] = {"softmax of query tile 0", "five MFMA groups", "landed nops + tail maxima + DMA wait", "barrier", "tile DMA issue", "PROLOGUE (once, not per step: x31)", "loop control + must_move + fragment wait", "EPILOGUE (once: x31)"};
+    printf("stamped kernel %.1f us; per step (31 steps), workgroup 0 wave 0, cycles:\n", t0);
+    long long tot = 0;
+    for (int i = 0; i < 8; ++i) tot += hd[i];
+    for (int i = 0; i < 8; ++i) if (hd[i]) printf("  %-46s %8.1f  (%4.1f %%)\n", nm[i], hd[i] / 31.0, 100.0 * hd[i] / tot);
+    printf("  total %.1f cycles per step\n", tot / 31.0);
+    return 0;
+  }
+#endif
   if (argc > 1) { shape<64>(16, 600, 1998, 2, 1, 1); return 0; }
   shape<64>(16, 600, 1998, 2, 1, 1);
   shape<64>(16, 600, 600, 0, 0, 0);

@@ -167,3 +167,95 @@ def test_fp16_overflow_escalates_to_fp32_instead_of_raising(dev):
     record("fp16_overflow_escalation/ddim5", rel_l2=e)
     assert e < 1e-3, e
     model.release()
+
+
+# ----------------------------------------------------------------------------- attn3_kernel: the ISA-level attention tile body
+def _attention_fp64(q, k, v, heads):
+    """softmax(q k^T / sqrt(dh)) v per head in float64 (nn.MultiheadAttention's core, transformer_modules.py:239-246, no projections)."""
+    N, Tq, d = q.shape
+    dh = d // heads
+    qh, kh, vh = (x.double().view(N, -1, heads, dh).transpose(1, 2) for x in (q, k, v))
+    w = torch.softmax(qh @ kh.transpose(-1, -2) / dh ** 0.5, dim=-1)
+    return (w @ vh).transpose(1, 2).reshape(N, Tq, d)
+
+
+@pytest.mark.parametrize("precision", ["fp16", "bf16"])
+@pytest.mark.parametrize("fmt", ["face", "pose"])
+def test_attn3_kernel_vs_fp64_and_vs_attn_kernel(dev, fmt, precision, monkeypatch):
+    """csrc/kernels_attn3.h through a2p_attention (A2P_ATTN3=2: wherever legal; 0: attn_kernel): one wave per SIMD, 80 queries per
+    wave, asm tile body on owned registers, Q pre-scaled, the softmax reference carried LAZILY through the MFMA C operand.  Not
+    bit-identical to attn_kernel (different reference values, one more rounding of Q): both are compared with a float64 attention,
+    and with each other.  Shapes: one partial tile, full tiles only (S = 128: no drain), many tiles + partial, ragged query blocks
+    (321 = one workgroup + 1 query), 600 x 2000 (the benchmarked cross shape); `spike` multiplies one key row by 6 -- scores jump
+    by far more than the lazy window (8 in log2 units) in the MIDDLE of the key range, so the fix-up path (move_refs + the recomputed
+    score tile) runs -- and `neg` shifts all scores far below zero (a reference that must go DOWN from its initial 0)."""
+    spec = face_spec() if fmt == "face" else pose_spec()
+    model, _ = create_model_and_diffusion(default_args(fmt), "test", precision=precision, max_batch=2)
+    load_model(model, synthetic_state_dict(spec, SEED))
+    model = model.to(dev).eval()
+    model._ensure_ctx(dev, 2)
+    lib = model._lib()
+    d, H = spec.latent_dim, spec.num_heads
+    g = torch.Generator().manual_seed(11)
+    tol = 1.0e-3 if precision == "fp16" else 6.0e-3
+
+    def run(mode, qd, kd, vd, N, Tq, S):
+        monkeypatch.setenv("A2P_ATTN3", mode)
+        _lib.check(lib.a2p_reload_env(model._ctx), "a2p_reload_env")
+        before = _debug_i64(model, b"attn3_launches")
+        out = torch.empty(N, Tq, d, device=dev)
+        _lib.check(lib.a2p_attention(model._ctx, _lib.ptr(qd), _lib.ptr(kd), _lib.ptr(vd), _lib.ptr(out), N, Tq, S, _lib.current_stream()), "a2p_attention")
+        return out.cpu(), _debug_i64(model, b"attn3_launches") - before
+    worst = 0.0
+    for (N, Tq, S, kind) in [(2, 100, 77, "plain"), (3, 33, 20, "plain"), (2, 321, 128, "plain"), (1, 600, 800, "spike"), (2, 150, 150, "neg"),
+                             (1, 600, 2000, "spike"), (2, 640, 254, "plain"), (1, 80, 1000, "spike")]:
+        q, k, v = (torch.randn(N, L, d, generator=g) for L in (Tq, S, S))
+        if kind == "spike":
+            k[0, S // 3] *= 6.0
+            k[0, (2 * S) // 3] *= -5.0
+        if kind == "neg":
+            q[:] = q.abs() * 1.5
+            k[:] = -k.abs() * 1.5
+        want = _attention_fp64(q, k, v, H)
+        qd, kd, vd = q.to(dev), k.to(dev), v.to(dev)
+        old, n_old = run("0", qd, kd, vd, N, Tq, S)
+        new, n_new = run("2", qd, kd, vd, N, Tq, S)
+        again, _ = run("2", qd, kd, vd, N, Tq, S)
+        e_new, e_old, e_pair = rel_l2(new, want), rel_l2(old, want), rel_l2(new, old)
+        worst = max(worst, e_new)
+        record(f"attn3/{fmt}/{precision}/N{N}_T{Tq}_S{S}_{kind}", vs_fp64=e_new, attn_kernel_vs_fp64=e_old, vs_attn_kernel=e_pair)
+        assert (n_old, n_new) == (0, 1), (n_old, n_new)
+        assert torch.isfinite(new).all() and torch.equal(new, again), "attn3 must be deterministic"
+        assert e_new < tol and e_new < 1.5 * e_old + 1e-4, (N, Tq, S, kind, e_new, e_old)
+    monkeypatch.delenv("A2P_ATTN3", raising=False)
+    _lib.check(lib.a2p_reload_env(model._ctx), "a2p_reload_env")
+    model.release()
+
+
+@pytest.mark.parametrize("precision", ["fp16", "bf16"])
+def test_guided_forward_with_attn3_matches_attn_kernel_path(dev, precision, monkeypatch):
+    """A whole guided forward of the face model (B = 2, T = 600: cached K/V slots, the shared unconditional slot, the two time tokens
+    patched into the LAST, PARTIAL key tile) with attn3_kernel on (the default rule picks it for self and cross attention: 16 launches
+    asserted) and off: the two paths must agree to the 16-bit operand rounding (they are not bit-identical, see above)."""
+    spec = face_spec()
+    B, T = 2, 600
+    inp = synthetic_inputs(spec, B, T, SEED)
+    model, _ = create_model_and_diffusion(default_args("face"), "test", precision=precision, max_batch=B)
+    load_model(model, synthetic_state_dict(spec, SEED))
+    cfg = ClassifierFreeSampleModel(model.to(dev).eval())
+    y = {"cond_embed": inp["cond_embed"].to(dev), "scale": torch.full((B,), 10.0, device=dev)}
+    t = torch.tensor([901, 33], device=dev)
+    outs, launches = {}, {}
+    for mode in ("0", "1"):
+        monkeypatch.setenv("A2P_ATTN3", mode)
+        cfg(inp["x_T"].to(dev), t, y)
+        before = _debug_i64(model, b"attn3_launches")
+        outs[mode] = cfg(inp["x_T"].to(dev), t, y).cpu()
+        launches[mode] = _debug_i64(model, b"attn3_launches") - before
+    monkeypatch.delenv("A2P_ATTN3", raising=False)
+    model.check_finite()
+    model.release()
+    e = rel_l2(outs["1"], outs["0"])
+    record(f"attn3/guided_forward/{precision}", vs_attn_kernel_path=e, launches=launches["1"])
+    assert launches == {"0": 0, "1": 16}, launches      # 8 layers x (self + cross); layer 0's shared-half trick keeps one launch per attention
+    assert e < (6e-4 if precision == "fp16" else 5e-3), e
