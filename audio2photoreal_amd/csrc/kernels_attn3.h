@@ -59,8 +59,10 @@ struct Attn3Geo {
 
 #define A3_QT 5
 // Owned registers.  Vector file, v[A3_OWN : 255] (hipcc allocates v0 .. v[A3_OWN - 1]):
-#define A3_OWN 128
-#define A3_PF(b, c) (128 + 4 * (2 * (b) + (c)))   // P fragment tuples (MFMA B operand), double-buffered over query tiles: b = q & 1, c = key chunk
+#define A3_OWN 120
+#define A3_PF(b, c) (120 + 4 * (2 * (b) + (c)))   // P fragment tuples (MFMA B operand), three buffers: b = q % 3, c = key chunk (query tile 0 of the NEXT tile
+                                                  // is converted while query tile 4's fragments, buffer 1, are still being read)
+#define A3_LSAVE 174                              // l of query tile 0 before the early softmax of the next tile (restored when that tile is recomputed)
 #define A3_CI(q) (144 + 4 * (q))                  // -m_ref of query tile q, four copies: the C operand of its first QK^T MFMA
 #define A3_L(q) (164 + (q))                       // row-sum accumulator of query tile q (per lane: the lane's keys)
 #define A3_M(q) (169 + (q))                       // running maximum of query tile q's scores RELATIVE to its reference (per lane)
@@ -149,23 +151,31 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_num_vgpr(A3_OWN))) vo
       dst_off[j] = L::KSZ + vp * 8 * KV;
     }
   }
-  auto issue_tile = [&](int tile, int rs) __attribute__((always_inline)) {
+  // tiles are requested strictly in order: the (wave-uniform) source bases advance by one tile per request, the per-lane part is a
+  // 32-bit byte offset (global_load_lds with an SGPR base: two scalar adds per tile instead of four 64-bit vector adds)
+  unsigned dma_off[PW];
+#pragma unroll
+  for (int j = 0; j < PW; ++j) dma_off[j] = (unsigned)(src_off[j] * 2);
+  const char* knext = reinterpret_cast<const char*>(Kb);
+  const char* vnext = reinterpret_cast<const char*>(Vb);
+  const int64_t kstep = (int64_t)KV * p.ldk * 2;
+  auto issue_tile = [&](int rs) __attribute__((always_inline)) {
     h16_t* sl = smem + rs * G::SLOT;
-    const h16_t* Kt = Kb + (int64_t)tile * KV * p.ldk;
-    const h16_t* Vt = Vb + tile * KV;
     if (kv_nt) {   // block-uniform: ONE branch per tile
 #pragma unroll
       for (int j = 0; j < PW; ++j) {
         const uint32_t m0v = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) h16_t*)(sl + dst_off[j]);
-        asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off nt" ::"s"(m0v), "v"((j < KPW ? Kt : Vt) + src_off[j]) : "memory");
+        asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2 nt" ::"s"(m0v), "v"(dma_off[j]), "s"(j < KPW ? knext : vnext) : "memory");
       }
     } else {
 #pragma unroll
       for (int j = 0; j < PW; ++j) {
         const uint32_t m0v = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) h16_t*)(sl + dst_off[j]);
-        asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(m0v), "v"((j < KPW ? Kt : Vt) + src_off[j]) : "memory");
+        asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(m0v), "v"(dma_off[j]), "s"(j < KPW ? knext : vnext) : "memory");
       }
     }
+    knext += kstep;
+    vnext += KV * 2;
   };
   // the last tile(s) in LDS, by the whole workgroup (block-uniform call sites): the time-token rows are written into it (attn_kernel),
   // and the rows / columns of keys past the end are made harmless -- K rows become copies of the tile's key 0 (their scores are
@@ -316,8 +326,9 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_num_vgpr(A3_OWN))) vo
   };
   // The references move to the exact running row maxima: O and l rescaled, the running maxima re-based; the pending score tile is
   // shifted in place (SHIFT) or left to the caller to recompute from the K tile that is still in the ring.  Rare after the first tile.
-  auto move_refs = [&](auto shift_c) __attribute__((always_inline)) {
-    constexpr bool SHIFT = decltype(shift_c)::value;
+  auto move_refs = [&](auto shift_c, auto first_c) __attribute__((always_inline)) {
+    constexpr bool SHIFT = decltype(shift_c)::value, FIRST = decltype(first_c)::value;   // FIRST: O and l are still zero
+    A3_MFMA_LANDED();
     attn3_static_for<0, QT>([&](auto q_c) __attribute__((always_inline)) {
       constexpr int q = decltype(q_c)::value;
       (void)&mref;
@@ -329,7 +340,7 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_num_vgpr(A3_OWN))) vo
       const float nm = -mref[q];
       asm volatile("v_sub_f32 v[%c0], v[%c0], %2\n\tv_mul_f32 v[%c1], v[%c1], %3" ::"n"(A3_M(q)), "n"(A3_L(q)), "v"(d), "v"(f));
       asm volatile("v_mov_b32 v[%c0], %4\n\tv_mov_b32 v[%c1], %4\n\tv_mov_b32 v[%c2], %4\n\tv_mov_b32 v[%c3], %4" ::"n"(A3_CI(q)), "n"(A3_CI(q) + 1), "n"(A3_CI(q) + 2), "n"(A3_CI(q) + 3), "v"(nm));
-      attn3_static_for<0, 4 * DVT>([&](auto e_c) __attribute__((always_inline)) {   // O *= f (through a vector register: the accumulator file has no arithmetic)
+      attn3_static_for<0, FIRST ? 0 : 4 * DVT>([&](auto e_c) __attribute__((always_inline)) {   // O *= f (through a vector register: the accumulator file has no arithmetic)
         constexpr int e = decltype(e_c)::value;
         (void)&f;
         float x;
@@ -349,7 +360,7 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_num_vgpr(A3_OWN))) vo
   };
 
   // ---- prologue ----
-  issue_tile(0, 0);
+  issue_tile(0);
   {
     h16x8 qf[QT][KC];          // Q fragments (B operand of S^T = K Q^T): lane (query l15, k-group g), pre-multiplied by log2(e) / sqrt(dh)
 #pragma unroll
@@ -375,7 +386,7 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_num_vgpr(A3_OWN))) vo
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #pragma unroll
   for (int t = 1; t < NS - 1; ++t)
-    if (t < ntiles) issue_tile(t, t);
+    if (t < ntiles) issue_tile(t);
   __builtin_amdgcn_s_barrier();
   if (needs_finish(0)) {
     finish_last_tile(0, 0);
@@ -390,16 +401,36 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_num_vgpr(A3_OWN))) vo
   // loads straight into it; "v": P fragments, -m_ref) and pads nothing: every reader of an MFMA result sits at least one MFMA group
   // (>= 8 MFMAs) behind its producer, or behind A3_MFMA_LANDED.
   // QK = false: the drain behind the loop (softmax + O^T += V^T P^T of the last tile only).
+  // softmax packet n of query tile q, in issue order: exp2 of score n, the row-sum add of score n - 2, the convert of score pair
+  // (n - 5) / 2 into the P fragment registers of the query tile.  Every index is a compile-time constant (attn3_static_for).
+  auto soft = [&](auto n_c, auto q_c) __attribute__((always_inline)) {
+    constexpr int n = decltype(n_c)::value, q = decltype(q_c)::value;
+    if constexpr (n < 16 && !(A3X & 5)) asm volatile("v_exp_f32 v[%c0], v[%c0]" ::"n"(A3_S(n >> 2, q, n & 3)));
+    if constexpr (n >= 2 && n < 18 && !(A3X & 4)) asm volatile("v_add_f32 v[%c0], v[%c0], v[%c1]" ::"n"(A3_L(q)), "n"(A3_S((n - 2) >> 2, q, (n - 2) & 3)));
+    if constexpr (n >= 5 && ((n - 5) & 1) == 0 && (n - 5) / 2 < 8 && !(A3X & 4)) {
+      constexpr int j = (n - 5) / 2, c = j >> 2, w = j & 3, kt = 2 * c + (w >> 1), r0 = (w & 1) * 2;
+      asm volatile(A3_CVT " v[%c0], v[%c1], v[%c2]" ::"n"(A3_PF(q % 3, c) + w), "n"(A3_S(kt, q, r0)), "n"(A3_S(kt, q, r0 + 1)));
+    }
+  };
+  constexpr int NSOFT = 21;   // n = 0 .. 20 covers 16 exps, 16 adds, 8 converts
+  // the softmax of query tile 0, on its own (loop entry / re-entry and the drain; inside the loop it runs EARLY, see `step`)
+  auto soft0_now = [&]() __attribute__((always_inline)) {
+    attn3_static_for<0, NSOFT>([&](auto n_c) __attribute__((always_inline)) { soft(n_c, std::integral_constant<int, 0>{}); });
+  };
   // step t consumes fragment set PAR = t & 1 (V^T(t), K(next tile): requested one step earlier, or by `prime`) and requests the
-  // fragments of step t + 1 into the other set at its very top: the 16 ds_read_b128 of a step then have a whole step to land (issued
-  // and waited for inside one step they cost 680 exposed cycles per step: 64 KiB per CU and step against the softmax of ONE query tile)
+  // fragments of step t + 1 into the other set, one ds_read_b128 per MFMA gap of query tile 0's group (sixteen of them back to back
+  // from four lockstep waves block each wave's issue for ~40 cycles apiece).
+  // QK = true (the loop): the softmax of query tile 0 of tile t is ALREADY DONE (by the previous step, or soft0_now), and the one of
+  // tile t + 1 is issued between the MFMAs of this step's LAST group, whose MFMA order is QK^T first, PV second, so that the maxima of
+  // its new scores fit behind them: nothing of a step is left un-overlapped (measured before: softmax of query tile 0 347 of 3000
+  // cycles per step, wait states + tail maxima ~70).  The early softmax runs BEFORE the vote on tile t + 1: if that tile turns out to
+  // need a reference move it is recomputed from the ring anyway, and l of query tile 0 is restored from A3_LSAVE.
+  // QK = false: the drain of the partial last tile (softmax of query tile 0 first, PV MFMAs only).
   auto step = [&](int t, auto qk_c, auto par_c) __attribute__((always_inline)) {
     constexpr bool QK = decltype(qk_c)::value;
     constexpr int PAR = decltype(par_c)::value;
     A3_STAMP(6);  // (loop control + must_move since the last stamp)
     wait_lds();   // the fragments of THIS step (requested a step ago: long landed)
-    // addresses of the next step's fragments; the 2 DVT + 4 KC reads themselves are issued ONE PER MFMA GAP of query tile 0's group
-    // below (sixteen ds_read_b128 back to back from four lockstep waves block each wave's issue for ~40 cycles apiece)
     [[maybe_unused]] unsigned fa_v[2], fa_k[KC];
     if constexpr (QK) {
       const unsigned vs = (unsigned)(min(t + 1, ntiles - 1) & (NS - 1)) * (unsigned)(G::SLOT * 2);
@@ -408,6 +439,8 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_num_vgpr(A3_OWN))) vo
       for (int c = 0; c < 2; ++c) fa_v[c] = vbase[c] + vs;
 #pragma unroll
       for (int kc = 0; kc < KC; ++kc) fa_k[kc] = kbase[kc] + ks;
+    } else {
+      soft0_now();
     }
     auto frag_read = [&](auto i_c) __attribute__((always_inline)) {   // read number i of the next step's fragments
       constexpr int i = decltype(i_c)::value;
@@ -421,42 +454,36 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_num_vgpr(A3_OWN))) vo
         asm volatile("ds_read_b128 a[%c0:%c1], %2 offset:%3" ::"n"(R), "n"(R + 3), "v"(fa_k[kc]), "n"((32 * (kt >> 1) + 4 * (kt & 1)) * L::LSK * 2));
       }
     };
-    // softmax packet n of query tile q, in issue order: exp2 of score n, the row-sum add of score n - 2, the convert of score pair
-    // (n - 5) / 2 into the P fragment registers of the query tile.  Every index is a compile-time constant (attn3_static_for).
-    auto soft = [&](auto n_c, auto q_c) __attribute__((always_inline)) {
-      constexpr int n = decltype(n_c)::value, q = decltype(q_c)::value;
-      if constexpr (n < 16 && !(A3X & 5)) asm volatile("v_exp_f32 v[%c0], v[%c0]" ::"n"(A3_S(n >> 2, q, n & 3)));
-      if constexpr (n >= 2 && n < 18 && !(A3X & 4)) asm volatile("v_add_f32 v[%c0], v[%c0], v[%c1]" ::"n"(A3_L(q)), "n"(A3_S((n - 2) >> 2, q, (n - 2) & 3)));
-      if constexpr (n >= 5 && ((n - 5) & 1) == 0 && (n - 5) / 2 < 8 && !(A3X & 4)) {
-        constexpr int j = (n - 5) / 2, c = j >> 2, w = j & 3, kt = 2 * c + (w >> 1), r0 = (w & 1) * 2;
-        asm volatile(A3_CVT " v[%c0], v[%c1], v[%c2]" ::"n"(A3_PF(q & 1, c) + w), "n"(A3_S(kt, q, r0)), "n"(A3_S(kt, q, r0 + 1)));
-      }
-    };
-    constexpr int NSOFT = 21;   // n = 0 .. 20 covers 16 exps, 16 adds, 8 converts
-    // query tile 0 has no MFMA group in front of it in this step
-    attn3_static_for<0, NSOFT>([&](auto n_c) __attribute__((always_inline)) { soft(n_c, std::integral_constant<int, 0>{}); });
-    A3_STAMP(0);  // softmax of query tile 0 (nothing to overlap with)
-    constexpr int NM = QK ? 2 * DVT + 4 * KC : 2 * DVT;   // MFMAs per group
+    A3_STAMP(0);  // fragment wait + addresses
+    constexpr int NPV = 2 * DVT, NQK = QK ? 4 * KC : 0, NM = NPV + NQK;   // MFMAs per group
     attn3_static_for<0, QT>([&](auto q_c) __attribute__((always_inline)) {
       constexpr int q = decltype(q_c)::value;
       constexpr int qp = q > 0 ? q - 1 : 0;
+      constexpr bool LASTG = QK && q == QT - 1;   // the last group: QK^T MFMAs first
       attn3_static_for<0, NM>([&](auto i_c) __attribute__((always_inline)) {
         constexpr int i = decltype(i_c)::value;
-        if constexpr (i < 2 * DVT) {
-          constexpr int c = i / DVT, dv = i % DVT, RO = A3_AO(q, dv, DVT);
-          if constexpr (!(A3X & 8)) asm volatile(A3_MFMA " a[%c0:%c1], a[%c2:%c3], v[%c4:%c5], a[%c0:%c1]" ::"n"(RO), "n"(RO + 3), "n"(A3_AV(PAR, c, dv, DVT)), "n"(A3_AV(PAR, c, dv, DVT) + 3), "n"(A3_PF(q & 1, c)), "n"(A3_PF(q & 1, c) + 3));
+        constexpr bool is_pv = LASTG ? i >= NQK : i < NPV;
+        constexpr int ip = LASTG ? i - NQK : i, iq = LASTG ? i : i - NPV;
+        if constexpr (is_pv) {
+          constexpr int c = ip / DVT, dv = ip % DVT, RO = A3_AO(q, dv, DVT);
+          if constexpr (!(A3X & 8)) asm volatile(A3_MFMA " a[%c0:%c1], a[%c2:%c3], v[%c4:%c5], a[%c0:%c1]" ::"n"(RO), "n"(RO + 3), "n"(A3_AV(PAR, c, dv, DVT)), "n"(A3_AV(PAR, c, dv, DVT) + 3), "n"(A3_PF(q % 3, c)), "n"(A3_PF(q % 3, c) + 3));
         } else {
-          constexpr int kc = (i - 2 * DVT) / 4, kt = (i - 2 * DVT) % 4, R = A3_S(kt, q, 0);
+          constexpr int kc = iq / 4, kt = iq % 4, R = A3_S(kt, q, 0);
           if constexpr (A3X & 8) {}
           else if constexpr (kc == 0) asm volatile(A3_MFMA " v[%c0:%c1], a[%c2:%c3], a[%c4:%c5], v[%c6:%c7]" ::"n"(R), "n"(R + 3), "n"(A3_AK(PAR, kc, kt)), "n"(A3_AK(PAR, kc, kt) + 3), "n"(A3_AQ(q, kc, KC)), "n"(A3_AQ(q, kc, KC) + 3), "n"(A3_CI(q)), "n"(A3_CI(q) + 3));
           else asm volatile(A3_MFMA " v[%c0:%c1], a[%c2:%c3], a[%c4:%c5], v[%c0:%c1]" ::"n"(R), "n"(R + 3), "n"(A3_AK(PAR, kc, kt)), "n"(A3_AK(PAR, kc, kt) + 3), "n"(A3_AQ(q, kc, KC)), "n"(A3_AQ(q, kc, KC) + 3));
         }
-        // fillers: the softmax of query tile q + 1 spread over the group's NM gaps, the maxima of S[q - 1] in every other gap, and in
-        // query tile 0's group one fragment read of the next step per gap
+        // fillers: the softmax of query tile q + 1 (behind the last group: of query tile 0 of the NEXT tile) spread over the group's
+        // gaps, the maxima of the S[q - 1] written one group earlier in every other gap, in query tile 0's group one fragment read of
+        // the next step per gap, and behind the last group's QK^T MFMAs the maxima of its own new scores
         if constexpr (QK && q == 0) frag_read(i_c);
         if constexpr (q + 1 < QT) {
           constexpr int n0 = (i * NSOFT) / NM, n1 = ((i + 1) * NSOFT) / NM;
           attn3_static_for<n0, n1>([&](auto n_c) __attribute__((always_inline)) { soft(n_c, std::integral_constant<int, q + 1>{}); });
+        } else if constexpr (QK) {
+          if constexpr (i == 0) asm volatile("v_mov_b32 v[%c0], v[%c1]" ::"n"(A3_LSAVE), "n"(A3_L(0)));
+          constexpr int n0 = (i * NSOFT) / NM, n1 = ((i + 1) * NSOFT) / NM;
+          attn3_static_for<n0, n1>([&](auto n_c) __attribute__((always_inline)) { soft(n_c, std::integral_constant<int, 0>{}); });
         }
         if constexpr (QK && q > 0 && !(A3X & 2)) {
           constexpr int j0 = (i * 8) / NM, j1 = ((i + 1) * 8) / NM;
@@ -465,16 +492,13 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_num_vgpr(A3_OWN))) vo
             asm volatile("v_max3_f32 v[%c0], v[%c0], v[%c1], v[%c2]" ::"n"(A3_M(qp)), "n"(R), "n"(R + 1));
           });
         }
+        if constexpr (LASTG && !(A3X & 2) && i >= NM - 4) {   // its own maxima: score tile kt was completed by MFMA NQK - 4 + kt, >= 4 MFMAs ago
+          constexpr int kt = i - (NM - 4), R = A3_S(kt, q, 0);
+          asm volatile("v_max3_f32 v[%c0], v[%c0], v[%c1], v[%c2]\n\tv_max3_f32 v[%c0], v[%c0], v[%c3], v[%c4]" ::"n"(A3_M(q)), "n"(R), "n"(R + 1), "n"(R + 2), "n"(R + 3));
+        }
       });
     });
     A3_STAMP(1);  // the five MFMA groups
-    A3_MFMA_LANDED();
-    if constexpr (QK && !(A3X & 2)) {   // maxima of the last query tile's new scores
-      attn3_static_for<0, 8>([&](auto j_c) __attribute__((always_inline)) {
-        constexpr int j = decltype(j_c)::value, R = A3_S(j >> 1, QT - 1, (j & 1) * 2);
-        asm volatile("v_max3_f32 v[%c0], v[%c0], v[%c1], v[%c2]" ::"n"(A3_M(QT - 1)), "n"(R), "n"(R + 1));
-      });
-    }
   };
 
   // ring bookkeeping at the top of step t: tile t+1 landed for everyone (its K is read in this step), the slot of tile t-1 -- last read
@@ -491,7 +515,7 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_num_vgpr(A3_OWN))) vo
     if constexpr (!(ABL & 128)) __builtin_amdgcn_s_barrier();
     A3_STAMP(3);  // barrier
     if constexpr ((ABL & 64) == 0) {
-      if (t + NS - 1 < ntiles) issue_tile(t + NS - 1, (t + NS - 1) & (NS - 1));
+      if (t + NS - 1 < ntiles) issue_tile((t + NS - 1) & (NS - 1));
     }
     A3_STAMP(4);  // tile DMA issue
     if (t + 2 >= tfin) {   // (rare: the last one or two steps)
@@ -523,7 +547,7 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_num_vgpr(A3_OWN))) vo
 #pragma unroll
     for (int c = 0; c < 2; ++c) asm volatile("" : "+v"(vbase[c]));
 #pragma unroll
-    for (int j = 0; j < PW; ++j) asm volatile("" : "+v"(src_off[j]));
+    for (int j = 0; j < PW; ++j) asm volatile("" : "+v"(dma_off[j]));
   };
 
   const std::true_type Tt{};
@@ -536,12 +560,12 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_num_vgpr(A3_OWN))) vo
     if (ntiles == 1 && rem > 0) mask_owned(0);
     max_owned();
     sync_top(0);
-    move_refs(Tt);
+    move_refs(Tt, Tt);
     int t = 0;
     if (nfull > 0) {
       // ONE step body per parity, the rare reference move OUTSIDE the fast loop (see the header).  Behind the last full tile the
       // "next" tile is the partial tile (its dead keys are copies of its key 0: real scores that cannot raise a maximum) or, none
-      // left, the last tile again: the step has one form.
+      // left, the last tile again: the step has one form, and what it did too early for that tile is undone behind the loop.
 #ifdef A3_STAMPS
       for (int k = 0; k < 8; ++k) stamp_acc[k] = 0;
       stamp_last = __builtin_readcyclecounter();
@@ -550,38 +574,30 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_num_vgpr(A3_OWN))) vo
       for (;;) {
         touch_live_ins();
         prime(t);
-        bool done = false, moved = false;
-        if (t & 1) {   // align the unrolled loop to an even step
-          step(t, Tt, P1);
-          ++t;
-          if (t >= nfull) done = true;
-          else {
-            sync_top(t);
-            moved = must_move();
-          }
-        }
-        if (!done && !moved) {
+        soft0_now();
+        bool done = false;
 #pragma clang loop unroll(disable)
-          for (;;) {
-            step(t, Tt, P0);
-            ++t;
-            if (t >= nfull) { done = true; break; }
-            sync_top(t);
-            if (must_move()) break;
-            step(t, Tt, P1);
-            ++t;
-            if (t >= nfull) { done = true; break; }
-            sync_top(t);
-            if (must_move()) break;
-          }
+        for (;;) {
+          if (t & 1) step(t, Tt, P1);
+          else step(t, Tt, P0);
+          ++t;
+          if (t >= nfull) { done = true; break; }
+          sync_top(t);
+          if (must_move()) break;
         }
+        // the early softmax of query tile 0 ran on a tile that is recomputed (reference move), masked first (partial tile) or not
+        // there at all: its row sums are taken back, its scores are overwritten by whoever needs them
+        asm volatile("v_mov_b32 v[%c0], v[%c1]" ::"n"(A3_L(0)), "n"(A3_LSAVE));
         if (done) break;
-        move_refs(Ff);                  // some score left the window of its reference: move it, recompute S(t) from the ring, re-enter
+        move_refs(Ff, Ff);              // some score left the window of its reference: move it, recompute S(t) from the ring, re-enter
         qk_owned((unsigned)(t & (NS - 1)));
       }
-      if (rem > 0) {                    // the partial last tile: its scores are in place (unmasked), its V^T fragments requested
+      if (rem > 0) {                    // the partial last tile: recomputed (query tile 0 was exponentiated early, unmasked), masked
+        A3_MFMA_LANDED();
+        qk_owned((unsigned)(t & (NS - 1)));
         mask_owned(t);
-        if (must_move()) move_refs(Tt);
+        if (must_move()) move_refs(Tt, Ff);
+        prime(t);                       // (qk_owned used fragment set 0)
       }
     } else {
       prime(0);
@@ -590,6 +606,7 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_num_vgpr(A3_OWN))) vo
       if (t & 1) step(t, Ff, P1);
       else step(t, Ff, P0);
     }
+    A3_MFMA_LANDED();
   } else {
     const int nsync = nfull > 0 ? nfull : 1;
     for (int t = 0; t < nsync; ++t) sync_top(t);

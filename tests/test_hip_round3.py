@@ -129,6 +129,7 @@ def test_key_split_attention_matches_softmax_and_the_query_split_kernel(dev, fmt
     attention at the precision's bar, and against attn_kernel to the rounding of the softmax sums.  Sizes: fewer tiles than waves
     (20 keys), ragged last tiles (77, 150), several tiles per wave (800), a spiked key (rescale across the merge)."""
     from audio2photoreal_amd import _lib
+    monkeypatch.setenv("A2P_ATTN3", "0")   # the query-split side of the comparison is attn_kernel (attn3_kernel has its own tests: test_hip_round6.py)
     spec, model = _model(fmt, precision, dev, 1)
     model._ensure_ctx(dev, 1)
     lib = model._lib()
