@@ -998,7 +998,12 @@ def main():
         # MI355X_MICROARCH.md + WRITE_SIZE; scratch/run_pmc.sh writes the file) -- null when not collected for this workload
         tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         if os.path.exists(tpath) and a.model == "face" and B == 8 and T == 600 and a.precision != "fp32":   # 16-bit modes: same bytes
-            traffic = json.load(open(tpath)).get(roofline["kernel"])
+            tj = json.load(open(tpath))
+            traffic = tj.get(roofline["kernel"])
+            # the entry of the kernel FAMILY that was timed (chain_family = 10 x MID + POST), not the mix of a calibration run
+            fam = (tj.get("chain_by_family") or {}).get(str(roofline.get("chain_family"))) if roofline["kernel"] == "chain" else None
+            if fam:
+                traffic = dict(fam, chain_family=roofline.get("chain_family"))
             if traffic:
                 roofline["traffic"], roofline["traffic_detail"] = traffic["total_bytes"], traffic
                 roofline["traffic_source"] = ("profiles/pmc_traffic.json: builder-run rocprofv3 --pmc passes of this workload (scratch/run_pmc.sh), "
