@@ -221,6 +221,14 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_num_vgpr(A3_OWN))) vo
 #else
 #define A3_STAMP(k) do { } while (0)
 #endif
+#ifdef A3_WGSTAMPS   // scratch: per-WORKGROUP timeline (wave 0): 100 MHz wall clock at kernel start / loop entry / loop end / kernel end + the loop's shader cycles
+  long long wg_t[6] = {(long long)wall_clock64(), 0, 0, 0, 0, 0};
+#define A3_WGSTAMP(k) do { wg_t[k] = (long long)wall_clock64(); } while (0)
+#define A3_WGCYC(k) do { wg_t[k] = __builtin_readcyclecounter(); } while (0)
+#else
+#define A3_WGSTAMP(k) do { } while (0)
+#define A3_WGCYC(k) do { } while (0)
+#endif
   // first tile that has something written into it after it landed (time tokens, padding of the partial tile)
   int tfin = ntiles;
   if (rem > 0) tfin = ntiles - 1;
@@ -571,6 +579,8 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_num_vgpr(A3_OWN))) vo
       stamp_last = __builtin_readcyclecounter();
       stamp_acc[5] = stamp_last - stamp_t0;     // prologue
 #endif
+      A3_WGSTAMP(1);
+      A3_WGCYC(4);
       for (;;) {
         touch_live_ins();
         prime(t);
@@ -615,6 +625,8 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_num_vgpr(A3_OWN))) vo
 #ifdef A3_STAMPS
   const long long stamp_loop_end = __builtin_readcyclecounter();
 #endif
+  A3_WGSTAMP(2);
+  A3_WGCYC(5);
   float lq[QT], mq[QT];
   attn3_static_for<0, QT>([&](auto q_c) __attribute__((always_inline)) {
     constexpr int q = decltype(q_c)::value;
@@ -668,6 +680,14 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_num_vgpr(A3_OWN))) vo
     const int qi = q0 + row;
     if (qi < p.Tq) *reinterpret_cast<h16x8*>(Ob + (int64_t)qi * p.ldo + part * 8) = v;
   }
+#ifdef A3_WGSTAMPS
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (the output stores have left)
+  A3_WGSTAMP(3);
+  if (threadIdx.x == 0 && p.kv_slot) {
+    long long* dbg = (long long*)p.kv_slot + (int64_t)blockIdx.x * 8;
+    for (int k = 0; k < 6; ++k) dbg[k] = wg_t[k];
+  }
+#endif
 #ifdef A3_STAMPS
   if (blockIdx.x == 0 && threadIdx.x == 0 && p.kv_slot) {
     stamp_acc[7] = __builtin_readcyclecounter() - stamp_loop_end;   // epilogue

@@ -414,7 +414,7 @@ def leg_record(case, steps, warmup, repeats, ksteps=3):
 # ----------------------------------------------------------------------------------------------------------------------
 # CPU baseline (oracle) + parity of both GPU modes against that same oracle run
 # ----------------------------------------------------------------------------------------------------------------------
-def cpu_and_parity(case, dev, want_parity=True, chain_steps=1000, chain_batch=2):
+def cpu_and_parity(case, dev, want_parity=True, chain_steps=1000, chain_batch=2, all_cores_live=False):
     """The oracle (CPU restatement of the reference algorithm, oracle/a2p_oracle.py) on ONE sample of the bench workload at
     the bench shape: 4 DDPM steps at the head of the 1000-step chain (t = 999..996) and 4 at its tail (t = 3..0, where the
     model's x0 carries the whole update).  The wall time of those 8 steps is the `cpu_baseline`; their outputs are the
@@ -471,21 +471,28 @@ def cpu_and_parity(case, dev, want_parity=True, chain_steps=1000, chain_batch=2)
             want_b.append(out)
             cur = out["sample"]
         bdt = time.perf_counter() - t0
-        # SURVEY section 8d asks for the box's cores: the same two steps again with every host CPU as a torch thread (the 32-thread figure
-        # stays the headline of this record: past ~32 threads these matmul sizes stop scaling, and both are printed so nobody has to trust that)
+        # SURVEY section 8d asks for the box's cores.  Every host CPU as a torch thread is measured ON REQUEST only (--cpu-all-cores): on
+        # the 256-CPU GPU boxes these matmul sizes thrash (round 6: ONE sample x ONE step took 231 s at 256 threads against 2.7 s for the
+        # whole batch at 32), i.e. the leg alone would add ~8 minutes to the default run.  The default line carries the measured record
+        # (profiles/r06_cpu_all_cores.json) with its source; the 32-thread figure stays the headline of this record.
         all_cores = None
-        if ncpu > threads:
-            # one sample, one step: with every host CPU as a torch thread these matmul sizes thrash (round 6, a 256-CPU box: the whole batch
-            # took 237 s per step at 256 threads against 2.7 s at 32) -- the figure is reported, not used, and must not cost minutes
+        if ncpu > threads and all_cores_live:
             torch.set_num_threads(ncpu)
             fn1 = lambda xx, ts: den.forward_cfg(xx, ts, ceb[:1], scb[:1])
             cur = smp.p_sample(fn1, xb[:1], torch.full((1,), 999), nzb[0][:1])["sample"]     # re-warm the larger pool
             t0 = time.perf_counter()
             smp.p_sample(fn1, cur, torch.full((1,), 998), nzb[1][:1])
             adt = time.perf_counter() - t0
-            all_cores = {"value": round(1.0 / adt / Bc, 5), "cores": ncpu, "seconds": round(adt, 2),
+            all_cores = {"value": round(1.0 / adt / Bc, 5), "cores": ncpu, "seconds": round(adt, 2), "measured": "this run",
                          "what": f"ONE sample x 1 step with {ncpu} torch threads, divided by the batch {Bc} (the {threads}-thread figure above times the whole batch)"}
             torch.set_num_threads(threads)
+        elif ncpu > threads:
+            try:
+                with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r06_cpu_all_cores.json")) as f:
+                    all_cores = json.load(f)
+                all_cores["measured"] = "profiles/r06_cpu_all_cores.json (a 256-CPU GPU box, round 6; NOT this run: --cpu-all-cores re-measures, ~8 min)"
+            except (OSError, ValueError):
+                all_cores = None
     cpu = {"value": round(n_b / bdt, 5),
            "unit": f"denoise steps/sec at batch {Bc} (the whole batch timed: {n_b} steps)",
            "cores": threads, "host_cpus": ncpu, "all_host_cpus_as_threads": all_cores, "kind": "port",
@@ -877,6 +884,9 @@ def main():
                     help="STRONG scaling (BASELINE configs[3]): a fixed number of samples split over --gpus ranks (contiguous blocks; a rank may "
                          "hold none) instead of --batch samples per GPU; the pose model then steps its ddim100 chain")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-all-cores", action="store_true",
+                    help="also time the oracle with EVERY host CPU as a torch thread (one sample x one step; ~8 minutes on a 256-CPU box, where it "
+                         "thrashes: the default line quotes profiles/r06_cpu_all_cores.json instead)")
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--no-parity", action="store_true", help="skip the parity legs (the oracle still times the cpu_baseline)")
     ap.add_argument("--no-legs", action="store_true", help="skip the face B=32 and body B=16 sub-records")
@@ -1013,7 +1023,7 @@ def main():
     legs = {}
     if rank == 0 and world == 1:   # reported at N=1 only (other ranks would idle in the final barrier)
         if not a.no_cpu_baseline and a.model == "face":
-            cpu, parity = cpu_and_parity(case, dev, want_parity=not a.no_parity, chain_steps=a.chain_steps)
+            cpu, parity = cpu_and_parity(case, dev, want_parity=not a.no_parity, chain_steps=a.chain_steps, all_cores_live=a.cpu_all_cores)
             if parity and a.write_parity:
                 with open(a.write_parity, "w") as f:
                     json.dump(parity, f, indent=1)

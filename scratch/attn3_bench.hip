@@ -97,7 +97,67 @@ void ablate() {
          abl_time<16>(a, H, nseq), abl_time<24>(a, H, nseq), abl_time<59>(a, H, nseq), abl_time<59 | 64>(a, H, nseq), abl_time<59 | 64 | 128>(a, H, nseq), abl_time<64>(a, H, nseq));
 }
 #endif
+#ifdef A3_WGSTAMPS
+// per-workgroup timeline of one launch (wave 0 of every workgroup): when it started, how long its prologue / loop / epilogue took
+template <int DH> void wg_timeline(const char* name, int nseq, int T, int S_main, int S_tail, int shared_slot0, int nt) {
+  const int H = 8, d = H * DH, S = S_main + S_tail, Sld = (S + 63) / 64 * 64, nslot = nseq + 1;
+  h16_t *q, *k, *vt, *o; float *kt, *vtl; long long* dbg;
+  CK(hipMalloc(&q, (size_t)nseq * T * d * 2)); CK(hipMalloc(&k, (size_t)nslot * Sld * d * 2)); CK(hipMalloc(&vt, (size_t)nslot * d * Sld * 2));
+  CK(hipMalloc(&o, (size_t)nseq * T * d * 2)); CK(hipMalloc(&kt, (size_t)nseq * 2 * d * 4)); CK(hipMalloc(&vtl, (size_t)nseq * 2 * d * 4));
+  std::vector<uint16_t> h((size_t)nslot * Sld * d);
+  for (auto& v : h) v = rnd_h(1.5f);
+  CK(hipMemcpy(k, h.data(), h.size() * 2, hipMemcpyHostToDevice)); CK(hipMemcpy(vt, h.data(), h.size() * 2, hipMemcpyHostToDevice));
+  CK(hipMemcpy(q, h.data(), (size_t)nseq * T * d * 2, hipMemcpyHostToDevice));
+  CK(hipMemset(kt, 0, (size_t)nseq * 2 * d * 4)); CK(hipMemset(vtl, 0, (size_t)nseq * 2 * d * 4));
+  AttnP a; memset(&a, 0, sizeof(a));
+  a.Q = q; a.q_seq_stride = (int64_t)T * d; a.ldq = d; a.K = k; a.k_slot_stride = (int64_t)Sld * d; a.ldk = d;
+  a.VT = vt; a.vt_slot_stride = (int64_t)d * Sld; a.ldvt = Sld; a.O = o; a.o_seq_stride = (int64_t)T * d; a.ldo = d;
+  a.ktail = S_tail ? kt : nullptr; a.vtail = S_tail ? vtl : nullptr; a.tail_sample_stride = 2 * d; a.tail_row_stride = d;
+  a.tail_mod = nseq; a.Tq = T; a.S_main = S_main; a.S_tail = S_tail; a.scale_log2e = 1.4426950408889634f / sqrtf((float)DH);
+  a.slot_rule = shared_slot0 ? 3 : 1; a.slot_b = nseq / 2; a.kv_stream = nt;
+  a.nheads = H; a.nseq = nseq; a.xcd_remap = 1; a.nq = (T + 319) / 320;
+  const int nwg = a.nq * H * nseq;
+  CK(hipMalloc(&dbg, (size_t)nwg * 64)); CK(hipMemset(dbg, 0, (size_t)nwg * 64));
+  a.kv_slot = (const int*)dbg;
+  const float us = time_it([&] { attn3_kernel<DH><<<dim3(nwg), 256>>>(a); });
+  std::vector<long long> hd((size_t)nwg * 8);
+  CK(hipMemcpy(hd.data(), dbg, hd.size() * 8, hipMemcpyDeviceToHost));
+  long long t0 = hd[0], t3 = hd[3];
+  for (int w = 0; w < nwg; ++w) { if (hd[w * 8] < t0) t0 = hd[w * 8]; if (hd[w * 8 + 3] > t3) t3 = hd[w * 8 + 3]; }
+  double s[5] = {0, 0, 0, 0, 0}, mx[5] = {0, 0, 0, 0, 0}, mn[5] = {1e30, 1e30, 1e30, 1e30, 1e30}, cyc = 0;
+  for (int w = 0; w < nwg; ++w) {
+    const long long* r = &hd[w * 8];
+    const double v[5] = {(r[0] - t0) * 0.01, (r[1] - r[0]) * 0.01, (r[2] - r[1]) * 0.01, (r[3] - r[2]) * 0.01, (r[3] - t0) * 0.01};
+    for (int i = 0; i < 5; ++i) { s[i] += v[i]; if (v[i] > mx[i]) mx[i] = v[i]; if (v[i] < mn[i]) mn[i] = v[i]; }
+    cyc += (double)(r[5] - r[4]);
+  }
+  const int nsteps = (S + 63) / 64;
+  printf("%s: %d wg, launch-to-launch %.1f us, first start -> last end %.1f us | per workgroup avg [min..max] us: start +%.2f [%.2f..%.2f]  prologue %.2f [%.2f..%.2f]  loop %.2f [%.2f..%.2f]  epilogue %.2f [%.2f..%.2f]  end +%.2f [%.2f..%.2f] | loop %.0f cycles = %.0f per tile step (%d), clock %.3f GHz\n",
+         name, nwg, us, (t3 - t0) * 0.01, s[0] / nwg, mn[0], mx[0], s[1] / nwg, mn[1], mx[1], s[2] / nwg, mn[2], mx[2], s[3] / nwg, mn[3], mx[3], s[4] / nwg, mn[4], mx[4],
+         cyc / nwg, cyc / nwg / nsteps, nsteps, cyc / nwg / (s[2] / nwg) * 1e-3);
+  // by slot class (shared slot 0 = L2-resident; own slot = streamed)
+  if (shared_slot0) {
+    double sl[2] = {0, 0}; int n[2] = {0, 0};
+    for (int w = 0; w < nwg; ++w) {
+      const int xcd = w & 7, j = w >> 3, pair = (j / a.nq) * 8 + xcd, seq = pair / H;
+      const int c = seq < a.slot_b ? 1 : 0;
+      sl[c] += (hd[w * 8 + 2] - hd[w * 8 + 1]) * 0.01; ++n[c];
+    }
+    printf("    loop us by K/V source: shared slot 0 (L2) %.2f (%d wg) | own slot (streamed) %.2f (%d wg)\n", sl[0] / (n[0] ? n[0] : 1), n[0], sl[1] / (n[1] ? n[1] : 1), n[1]);
+  }
+  CK(hipFree(q)); CK(hipFree(k)); CK(hipFree(vt)); CK(hipFree(o)); CK(hipFree(kt)); CK(hipFree(vtl)); CK(hipFree(dbg));
+}
+#endif
 int main(int argc, char** argv) {
+#ifdef A3_WGSTAMPS
+  if (argc > 1 && !strcmp(argv[1], "wg")) {
+    wg_timeline<64>("B=8 cross", 16, 600, 1998, 2, 1, 1);
+    wg_timeline<64>("B=8 self ", 16, 600, 600, 0, 0, 0);
+    wg_timeline<64>("B=32 cross", 64, 600, 1998, 2, 1, 1);
+    wg_timeline<64>("B=32 self ", 64, 600, 600, 0, 0, 0);
+    return 0;
+  }
+#endif
 #ifdef ATTN3_ABL
   if (argc > 1 && !strcmp(argv[1], "abl")) { ablate(); return 0; }
 #endif
