@@ -113,7 +113,12 @@ __device__ __forceinline__ void chain4_body(const ChainP& p, h16_t* const smem, 
   const int W4 = wid >> 1, J0 = wid & 1;
 #ifdef A2P_STAMPS   // diagnostic build (scratch/phase_probe4.py): 100 MHz phase stamps of workgroups 0 and 101 into p.fin_out
   auto stamp = [&](int i) __attribute__((always_inline)) {
-    if (tid == 0 && (blockIdx.x == 0 || blockIdx.x == 101)) reinterpret_cast<unsigned long long*>(p.fin_out)[(blockIdx.x ? 32 : 0) + i] = wall_clock64();
+    if (tid == 0 && (blockIdx.x == 0 || blockIdx.x == 101)) {
+      unsigned long long* o = reinterpret_cast<unsigned long long*>(p.fin_out) + (blockIdx.x ? 32 : 0);
+      o[i] = wall_clock64();
+      if (i == 0) o[30] = __builtin_readcyclecounter();   // shader cycles at the first / the latest stamp: the EFFECTIVE clock of the launch
+      o[31] = __builtin_readcyclecounter();
+    }
   };
 #else
   auto stamp = [&](int) __attribute__((always_inline)) {};
@@ -561,7 +566,7 @@ __device__ __forceinline__ void chain4_body(const ChainP& p, h16_t* const smem, 
       __builtin_amdgcn_sched_barrier(0);
       gemm(std::integral_constant<int, NH>{}, std::integral_constant<int, KC>{}, std::integral_constant<int, D>{}, acc, panelA, false);
       __builtin_amdgcn_sched_barrier(0);
-      if (13 + 3 * h < 32) stamp(13 + 3 * h);       // (stamped builds: linear1 of this hidden chunk done in wave 0)
+      if (13 + 3 * h < 28) stamp(13 + 3 * h);       // (stamped builds: linear1 of this hidden chunk done in wave 0)
       if (h > 0) chain_bar();   // every wave finished the linear2 partial of the previous chunk
 #pragma unroll
       for (int tt = 0; tt < NH; ++tt)
@@ -572,11 +577,11 @@ __device__ __forceinline__ void chain4_body(const ChainP& p, h16_t* const smem, 
               h16x4{(h16_t)act_gelu_fast(v[0]), (h16_t)act_gelu_fast(v[1]), (h16_t)act_gelu_fast(v[2]), (h16_t)act_gelu_fast(v[3])};
         }
       chain_bar();              // the hidden chunk is complete
-      if (14 + 3 * h < 32) stamp(14 + 3 * h);       // (GELU + both barriers)
+      if (14 + 3 * h < 29) stamp(14 + 3 * h);       // (GELU + both barriers)
       __builtin_amdgcn_sched_barrier(0);
       gemm(std::integral_constant<int, NT>{}, std::integral_constant<int, HLD / 32>{}, std::integral_constant<int, HLD>{}, R, panelH, false);
       __builtin_amdgcn_sched_barrier(0);
-      if (15 + 3 * h < 32) stamp(15 + 3 * h);       // (linear2 partial)
+      if (15 + 3 * h < 30) stamp(15 + 3 * h);       // (linear2 partial)
     }
     stamp(6);
     if constexpr (PARK) {

@@ -607,6 +607,14 @@ def cpu_and_parity(case, dev, want_parity=True, chain_steps=1000, chain_batch=2,
                            "bf16": {k: float(f"{v:.3e}") for k, v in rel_errors(finals["bf16"][0], finals["fp32"][0]).items()},
                            "fp16": {k: float(f"{v:.3e}") for k, v in rel_errors(finals["fp16"][0], finals["fp32"][0]).items()},
                            **{f"{k}_chain_s": round(v[1], 2) for k, v in finals.items()}}
+    # the same full chain against the ORACLE (20 CPU-minutes: offline, tests/tools/chain_vs_oracle.py; the record travels with the repo)
+    try:
+        with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r06_chain_vs_oracle.json")) as f:
+            co = json.load(f)
+        parity["chain_vs_oracle"] = {"what": co["what"], "source": "profiles/r06_chain_vs_oracle.json (builder-run: oracle in the build container, product on an MI355X; NOT measured in this run)",
+                                     **{prec: {"after_1000_steps": m["steps"]["step1000"], "after_500_steps": m["steps"]["step500"]} for prec, m in co["modes"].items()}}
+    except (OSError, KeyError, ValueError):
+        pass
     bar = 1e-3
     worst = {}
     for prec in ("fp32", "fp16", "bf16"):

@@ -97,6 +97,9 @@ void ablate() {
          abl_time<16>(a, H, nseq), abl_time<24>(a, H, nseq), abl_time<59>(a, H, nseq), abl_time<59 | 64>(a, H, nseq), abl_time<59 | 64 | 128>(a, H, nseq), abl_time<64>(a, H, nseq));
 }
 #endif
+#ifndef A3_ABL
+#define A3_ABL 0
+#endif
 #ifdef A3_WGSTAMPS
 // per-workgroup timeline of one launch (wave 0 of every workgroup): when it started, how long its prologue / loop / epilogue took
 template <int DH> void wg_timeline(const char* name, int nseq, int T, int S_main, int S_tail, int shared_slot0, int nt) {
@@ -119,7 +122,7 @@ template <int DH> void wg_timeline(const char* name, int nseq, int T, int S_main
   const int nwg = a.nq * H * nseq;
   CK(hipMalloc(&dbg, (size_t)nwg * 64)); CK(hipMemset(dbg, 0, (size_t)nwg * 64));
   a.kv_slot = (const int*)dbg;
-  const float us = time_it([&] { attn3_kernel<DH><<<dim3(nwg), 256>>>(a); });
+  const float us = time_it([&] { attn3_kernel<DH, A3_ABL><<<dim3(nwg), 256>>>(a); });
   std::vector<long long> hd((size_t)nwg * 8);
   CK(hipMemcpy(hd.data(), dbg, hd.size() * 8, hipMemcpyDeviceToHost));
   long long t0 = hd[0], t3 = hd[3];

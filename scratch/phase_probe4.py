@@ -21,7 +21,8 @@ for ver in ("1", "4"):
     torch.cuda.synchronize()
     a = np.zeros(64 * 32 + 128, np.uint64)
     _lib.check(case.model._lib().a2p_debug_read(case.model._ctx, b"clk", a.ctypes.data_as(C.c_void_p), a.nbytes), "clk")
-    st = a[64 * 32: 64 * 32 + 64].astype(np.float64) * 0.01     # us
+    raw = a[64 * 32: 64 * 32 + 64].astype(np.float64)
+    st = raw * 0.01     # us
     for blk in (0, 1):
         h = st[blk * 32: blk * 32 + 32]
         names = G4M if (ver == "4" and os.environ.get("A2P_STAMP_LAUNCH") in ("1", "2", "3")) else G4P
@@ -39,8 +40,10 @@ for ver in ("1", "4"):
                 ff, prev = [], 5
                 for c in range(6):
                     i = 13 + 3 * c
-                    if i + 2 < 32 and h[i + 2] > 0:
+                    if i + 2 < 30 and h[i + 2] > 0:
                         ff.append(f"[{h[i] - h[prev]:.2f} {h[i + 1] - h[i]:.2f} {h[i + 2] - h[i + 1]:.2f}]")
                         prev = i + 2
                 parts.append("ffn chunks (lin1 gelu+bar lin2): " + " ".join(ff))
+        if ver == "4" and raw[blk * 32 + 31] > raw[blk * 32 + 30] > 0 and tot > 0:
+            parts.append(f"| {raw[blk * 32 + 31] - raw[blk * 32 + 30]:.0f} shader cycles = {(raw[blk * 32 + 31] - raw[blk * 32 + 30]) / tot * 1e-3:.3f} GHz effective")
         print(f"B={B} gen {ver} block {'0' if blk == 0 else '101'}: total={tot:.2f} us | " + " ".join(parts), flush=True)
