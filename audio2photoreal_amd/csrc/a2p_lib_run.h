@@ -343,50 +343,51 @@ static int chain_pick_nw(a2p_ctx* c, int64_t rows, hipEvent_t* e0, hipEvent_t* e
 }
 
 // Chain kernel FAMILY of a forward, per chain: kernels_chain.h (1) or kernels_chain4.h (4) for the MID kernels and for the POST
-// kernels.  The two families produce the same bits (tests/test_hip_round5.py), so the choice is invisible in the results -- and
-// which one is faster depends on the BOX and on the chain: on most MI355X boxes leased this round the tall family leads everywhere
-// (B=8: 552 -> 594 steps/s; B=16 +13 %, B=32 +6 %); on a minority -- the boxes that also run the memory-heavy PRE kernel 30 % slow,
-// docs/lab_notebook_r1_r4.md section 6 "box-to-box spread" -- the tall POST kernel with its parked rows LOSES (B=32: 330 vs 278 us) while the tall MID
-// kernel still wins (88 vs 106 us) (profiles/r05_tall_chain_same_box_*.txt, r05_family_calibration.txt).  So it is measured in situ,
-// like round 3's workgroup shape: forward 0 of a size is warm-up, forwards 1..8 run the four (MID, POST) combinations twice with an
-// event pair around the decoder stack, forward 9 keeps the fastest.  A2P_CHAIN_V=1 | 4 forces one family for both.
-static const int kFamConfigs[4][2] = {{1, 1}, {4, 4}, {4, 1}, {1, 4}};
-static const int kTuneForwards4 = 9;
+// kernels.  The two families produce the same bits (tests/test_hip_round5.py), so the choice is invisible in the results.  What the
+// boxes of rounds 5 and 6 showed (profiles/r05_boxes.md, r05_tall_chain_same_box_*.txt, r05_family_calibration.txt): the tall MID kernel
+// wins on EVERY box (fast type 26.7 vs 30.9 us at B=8; slow type -- the boxes that also run the memory-heavy PRE kernel 30 % slow --
+// 27 vs 34, B=32 88 vs 106), so MID is tall by rule; the tall POST kernel wins on most boxes (B=8: 71 vs 83 us) and LOSES on the slow
+// type (B=32: 330 vs 278 us), so POST alone is measured in situ.  Round 5 timed all four (MID, POST) combinations twice each and took
+// the smallest MEAN: a 2 % difference decided by two samples, one of which carried a kernel's first launch -- round 6 saw it pick the
+// gen-1 MID kernels on a fast box (family 14: 664 instead of 676 steps/s).  Now: forwards 0 and 1 of a size warm both candidates up
+// (untimed), forwards 2..9 alternate them with an event pair around the decoder stack (four samples each), forward 10 compares the
+// MINIMA (interference from other streams only ever adds time) and keeps gen 1 only if it leads by more than 1.5 %.
+// A2P_CHAIN_V=1 | 4 forces one family for both chains.
+static const int kFamConfigs[2][2] = {{4, 4}, {4, 1}};
+static const int kTuneForwards4 = 10;
 static void chain_pick_family(a2p_ctx* c, int64_t rows, hipEvent_t* e0, hipEvent_t* e1) {
   *e0 = *e1 = nullptr;
   auto set = [&](int cfg) { c->ch_fam_mid = kFamConfigs[cfg][0]; c->ch_fam_post = kFamConfigs[cfg][1]; };
-  if (c->opt.chain_v == 1 || c->ch_stream4.empty() || c->d != 512 || c->ch_nw != 8) return set(0);
-  if (c->opt.chain_v == 4) return set(1);
+  if (c->opt.chain_v == 1 || c->ch_stream4.empty() || c->d != 512 || c->ch_nw != 8) { c->ch_fam_mid = c->ch_fam_post = 1; return; }
+  if (c->opt.chain_v == 4) return set(0);
+  if (c->ch_tune4.size() > 64 && !c->ch_tune4.count(rows)) {   // (variable-length clips: the table stays bounded; pending event pairs are released)
+    for (auto& kv : c->ch_tune4)
+      for (auto& sm : kv.second.samples) { (void)hipEventDestroy(std::get<1>(sm)); (void)hipEventDestroy(std::get<2>(sm)); }
+    c->ch_tune4.clear();
+  }
   auto& t = c->ch_tune4[rows];
   if (t.choice) return set(t.choice - 1);
   const int call = t.calls++;
   if (call < kTuneForwards4) {
-    const int cfg = call == 0 ? 1 : (call - 1) & 3;
-    if (call >= 1 && hipEventCreate(e0) == hipSuccess && hipEventCreate(e1) == hipSuccess) t.samples.emplace_back(cfg, *e0, *e1);
+    const int cfg = call & 1;
+    if (call >= 2 && hipEventCreate(e0) == hipSuccess && hipEventCreate(e1) == hipSuccess) t.samples.emplace_back(cfg, *e0, *e1);
     else *e0 = *e1 = nullptr;
     return set(cfg);
   }
-  double sum[4] = {0, 0, 0, 0};
-  int cnt[4] = {0, 0, 0, 0};
+  double best_ms[2] = {1e30, 1e30};
   for (auto& sm : t.samples) {
     float ms = 0.f;
-    if (hipEventSynchronize(std::get<2>(sm)) == hipSuccess && hipEventElapsedTime(&ms, std::get<1>(sm), std::get<2>(sm)) == hipSuccess) {
-      sum[std::get<0>(sm)] += ms;
-      ++cnt[std::get<0>(sm)];
-    }
+    if (hipEventSynchronize(std::get<2>(sm)) == hipSuccess && hipEventElapsedTime(&ms, std::get<1>(sm), std::get<2>(sm)) == hipSuccess)
+      best_ms[std::get<0>(sm)] = std::min(best_ms[std::get<0>(sm)], (double)ms);
     (void)hipEventDestroy(std::get<1>(sm));
     (void)hipEventDestroy(std::get<2>(sm));
   }
   t.samples.clear();
-  int best = 1;   // (no measurement: the tall family)
-  double bt = 1e30;
-  for (int i = 0; i < 4; ++i)
-    if (cnt[i] && sum[i] / cnt[i] < bt) { bt = sum[i] / cnt[i]; best = i; }
+  const int best = (best_ms[1] < 1e29 && best_ms[0] < 1e29 && best_ms[1] < 0.985 * best_ms[0]) ? 1 : 0;   // (no measurement: the tall family)
   t.choice = best + 1;
   if (c->opt.tune_verbose)
-    fprintf(stderr, "[a2p] chain kernel families (MID, POST) for %lld rows, ms per decoder stack: (1,1) %.3f  (4,4) %.3f  (4,1) %.3f  (1,4) %.3f -> (%d,%d)\n",
-            (long long)rows, cnt[0] ? sum[0] / cnt[0] : -1.0, cnt[1] ? sum[1] / cnt[1] : -1.0, cnt[2] ? sum[2] / cnt[2] : -1.0,
-            cnt[3] ? sum[3] / cnt[3] : -1.0, kFamConfigs[best][0], kFamConfigs[best][1]);
+    fprintf(stderr, "[a2p] chain kernel family of the POST chain for %lld rows (MID is tall by rule), fastest decoder stack of 4, ms: tall %.3f  gen 1 %.3f -> (%d,%d)\n",
+            (long long)rows, best_ms[0], best_ms[1], kFamConfigs[best][0], kFamConfigs[best][1]);
   set(best);
 }
 

@@ -58,14 +58,26 @@ struct Attn3Geo {
 };
 
 #define A3_QT 5
+#ifndef A3_MFMA_SUMS
+#define A3_MFMA_SUMS 1   // 1: the softmax row sums are two extra MFMAs per query tile and key tile (a fragment of ones x P^T) instead of 16 v_add_f32
+#endif
 // Owned registers.  Vector file, v[A3_OWN : 255] (hipcc allocates v0 .. v[A3_OWN - 1]):
-#define A3_OWN 120
-#define A3_PF(b, c) (120 + 4 * (2 * (b) + (c)))   // P fragment tuples (MFMA B operand), three buffers: b = q % 3, c = key chunk (query tile 0 of the NEXT tile
+#if A3_MFMA_SUMS
+#define A3_OWN 100
+#define A3_PF(b, c) (100 + 4 * (2 * (b) + (c)))   // P fragment tuples (MFMA B operand), three buffers: b = q % 3, c = key chunk (query tile 0 of the NEXT tile
                                                   // is converted while query tile 4's fragments, buffer 1, are still being read)
+#define A3_CI(q) (124 + 4 * (q))                  // -m_ref of query tile q, four copies: the C operand of its first QK^T MFMA
+#define A3_AL(q) (144 + 4 * (q))                  // row sums of query tile q as an MFMA accumulator tile: l[query l15] in every register of every lane group
+#define A3_ONES 164                               // a fragment of ones (A operand of the row-sum MFMAs)
+#define A3_M(q) (168 + (q))                       // running maximum of query tile q's scores RELATIVE to its reference (per lane)
+#else
+#define A3_OWN 120
+#define A3_PF(b, c) (120 + 4 * (2 * (b) + (c)))
 #define A3_LSAVE 174                              // l of query tile 0 before the early softmax of the next tile (restored when that tile is recomputed)
-#define A3_CI(q) (144 + 4 * (q))                  // -m_ref of query tile q, four copies: the C operand of its first QK^T MFMA
+#define A3_CI(q) (144 + 4 * (q))
 #define A3_L(q) (164 + (q))                       // row-sum accumulator of query tile q (per lane: the lane's keys)
-#define A3_M(q) (169 + (q))                       // running maximum of query tile q's scores RELATIVE to its reference (per lane)
+#define A3_M(q) (169 + (q))
+#endif
 #define A3_SB 176                                 // score (kt, q, r): v[A3_SB + 4 * (kt * A3_QT + q) + r]; tuples are MFMA C/D operands
 #define A3_S(kt, q, r) (A3_SB + 4 * ((kt) * A3_QT + (q)) + (r))
 // Accumulator file, a[0 : 247] (hipcc is given no reason to touch the accumulator file at all: every "a" value is literal):
@@ -241,7 +253,12 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_num_vgpr(A3_OWN))) vo
   attn3_static_for<0, QT>([&](auto q_c) __attribute__((always_inline)) {
     constexpr int q = decltype(q_c)::value;
     // l = 0, running maximum = -inf, reference 0
+#if A3_MFMA_SUMS
+    asm volatile("v_mov_b32 v[%c0], 0xff800000" ::"n"(A3_M(q)));
+    asm volatile("v_mov_b32 v[%c0], 0\n\tv_mov_b32 v[%c1], 0\n\tv_mov_b32 v[%c2], 0\n\tv_mov_b32 v[%c3], 0" ::"n"(A3_AL(q)), "n"(A3_AL(q) + 1), "n"(A3_AL(q) + 2), "n"(A3_AL(q) + 3));
+#else
     asm volatile("v_mov_b32 v[%c0], 0\n\tv_mov_b32 v[%c1], 0xff800000" ::"n"(A3_L(q)), "n"(A3_M(q)));
+#endif
     asm volatile("v_mov_b32 v[%c0], 0\n\tv_mov_b32 v[%c1], 0\n\tv_mov_b32 v[%c2], 0\n\tv_mov_b32 v[%c3], 0" ::"n"(A3_CI(q)), "n"(A3_CI(q) + 1), "n"(A3_CI(q) + 2), "n"(A3_CI(q) + 3));
     attn3_static_for<0, 4 * DVT>([&](auto e_c) __attribute__((always_inline)) {
       constexpr int e = decltype(e_c)::value;
@@ -249,6 +266,16 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_num_vgpr(A3_OWN))) vo
     });
   });
 
+#if A3_MFMA_SUMS
+  {
+#ifdef A2P_HALF
+    constexpr unsigned ONE2 = 0x3c003c00u;   // two IEEE-half ones
+#else
+    constexpr unsigned ONE2 = 0x3f803f80u;   // two bfloat16 ones
+#endif
+    asm volatile("v_mov_b32 v[%c0], %4\n\tv_mov_b32 v[%c1], %4\n\tv_mov_b32 v[%c2], %4\n\tv_mov_b32 v[%c3], %4" ::"n"(A3_ONES), "n"(A3_ONES + 1), "n"(A3_ONES + 2), "n"(A3_ONES + 3), "s"(ONE2));
+  }
+#endif
   // LDS byte addresses of this lane's K / V^T fragments inside ring slot 0.  The swizzle of a fragment depends on the lane only, the
   // k-chunk (kc / c) flips one bit of the swizzled chunk index (hence one base per chunk), kt / dv are plain row offsets (immediates)
   const unsigned smem_base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) h16_t*)smem;
@@ -346,7 +373,14 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_num_vgpr(A3_OWN))) vo
       const float f = __builtin_amdgcn_exp2f(-d);
       mref[q] += d;
       const float nm = -mref[q];
+#if A3_MFMA_SUMS
+      asm volatile("v_sub_f32 v[%c0], v[%c0], %1" ::"n"(A3_M(q)), "v"(d));
+      if constexpr (!FIRST)
+        asm volatile("v_mul_f32 v[%c0], v[%c0], %4\n\tv_mul_f32 v[%c1], v[%c1], %4\n\tv_mul_f32 v[%c2], v[%c2], %4\n\tv_mul_f32 v[%c3], v[%c3], %4"
+                     ::"n"(A3_AL(q)), "n"(A3_AL(q) + 1), "n"(A3_AL(q) + 2), "n"(A3_AL(q) + 3), "v"(f));
+#else
       asm volatile("v_sub_f32 v[%c0], v[%c0], %2\n\tv_mul_f32 v[%c1], v[%c1], %3" ::"n"(A3_M(q)), "n"(A3_L(q)), "v"(d), "v"(f));
+#endif
       asm volatile("v_mov_b32 v[%c0], %4\n\tv_mov_b32 v[%c1], %4\n\tv_mov_b32 v[%c2], %4\n\tv_mov_b32 v[%c3], %4" ::"n"(A3_CI(q)), "n"(A3_CI(q) + 1), "n"(A3_CI(q) + 2), "n"(A3_CI(q) + 3), "v"(nm));
       attn3_static_for<0, FIRST ? 0 : 4 * DVT>([&](auto e_c) __attribute__((always_inline)) {   // O *= f (through a vector register: the accumulator file has no arithmetic)
         constexpr int e = decltype(e_c)::value;
@@ -414,7 +448,9 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_num_vgpr(A3_OWN))) vo
   auto soft = [&](auto n_c, auto q_c) __attribute__((always_inline)) {
     constexpr int n = decltype(n_c)::value, q = decltype(q_c)::value;
     if constexpr (n < 16 && !(A3X & 5)) asm volatile("v_exp_f32 v[%c0], v[%c0]" ::"n"(A3_S(n >> 2, q, n & 3)));
+#if !A3_MFMA_SUMS
     if constexpr (n >= 2 && n < 18 && !(A3X & 4)) asm volatile("v_add_f32 v[%c0], v[%c0], v[%c1]" ::"n"(A3_L(q)), "n"(A3_S((n - 2) >> 2, q, (n - 2) & 3)));
+#endif
     if constexpr (n >= 5 && ((n - 5) & 1) == 0 && (n - 5) / 2 < 8 && !(A3X & 4)) {
       constexpr int j = (n - 5) / 2, c = j >> 2, w = j & 3, kt = 2 * c + (w >> 1), r0 = (w & 1) * 2;
       asm volatile(A3_CVT " v[%c0], v[%c1], v[%c2]" ::"n"(A3_PF(q % 3, c) + w), "n"(A3_S(kt, q, r0)), "n"(A3_S(kt, q, r0 + 1)));
@@ -463,7 +499,9 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_num_vgpr(A3_OWN))) vo
       }
     };
     A3_STAMP(0);  // fragment wait + addresses
-    constexpr int NPV = 2 * DVT, NQK = QK ? 4 * KC : 0, NM = NPV + NQK;   // MFMAs per group
+    constexpr int NSUM = A3_MFMA_SUMS ? 2 : 0;   // row-sum MFMAs per group: l[q] += ones x P[q]^T, one per 32-key chunk
+    constexpr int SPC = DVT + NSUM / 2;          // PV-part MFMAs per 32-key chunk
+    constexpr int NPV = 2 * SPC, NQK = QK ? 4 * KC : 0, NM = NPV + NQK;   // MFMAs per group
     attn3_static_for<0, QT>([&](auto q_c) __attribute__((always_inline)) {
       constexpr int q = decltype(q_c)::value;
       constexpr int qp = q > 0 ? q - 1 : 0;
@@ -472,8 +510,15 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_num_vgpr(A3_OWN))) vo
         constexpr int i = decltype(i_c)::value;
         constexpr bool is_pv = LASTG ? i >= NQK : i < NPV;
         constexpr int ip = LASTG ? i - NQK : i, iq = LASTG ? i : i - NPV;
-        if constexpr (is_pv) {
-          constexpr int c = ip / DVT, dv = ip % DVT, RO = A3_AO(q, dv, DVT);
+        // PV part, per 32-key chunk c: the DVT MFMAs of O^T[q] and (A3_MFMA_SUMS) the row-sum MFMA behind them -- the two accumulating MFMAs of
+        // an accumulator are DVT + 1 apart, never back to back
+        if constexpr (is_pv && ip % SPC == DVT) {
+#if A3_MFMA_SUMS
+          constexpr int c = ip / SPC, RL = A3_AL(q);
+          if constexpr (!(A3X & 8)) asm volatile(A3_MFMA " v[%c0:%c1], v[%c2:%c3], v[%c4:%c5], v[%c0:%c1]" ::"n"(RL), "n"(RL + 3), "n"(A3_ONES), "n"(A3_ONES + 3), "n"(A3_PF(q % 3, c)), "n"(A3_PF(q % 3, c) + 3));
+#endif
+        } else if constexpr (is_pv) {
+          constexpr int c = ip / SPC, dv = ip % SPC, RO = A3_AO(q, dv, DVT);
           if constexpr (!(A3X & 8)) asm volatile(A3_MFMA " a[%c0:%c1], a[%c2:%c3], v[%c4:%c5], a[%c0:%c1]" ::"n"(RO), "n"(RO + 3), "n"(A3_AV(PAR, c, dv, DVT)), "n"(A3_AV(PAR, c, dv, DVT) + 3), "n"(A3_PF(q % 3, c)), "n"(A3_PF(q % 3, c) + 3));
         } else {
           constexpr int kc = iq / 4, kt = iq % 4, R = A3_S(kt, q, 0);
@@ -484,12 +529,14 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_num_vgpr(A3_OWN))) vo
         // fillers: the softmax of query tile q + 1 (behind the last group: of query tile 0 of the NEXT tile) spread over the group's
         // gaps, the maxima of the S[q - 1] written one group earlier in every other gap, in query tile 0's group one fragment read of
         // the next step per gap, and behind the last group's QK^T MFMAs the maxima of its own new scores
-        if constexpr (QK && q == 0) frag_read(i_c);
+        if constexpr (QK && q == 0 && i < 2 * DVT + 4 * KC) frag_read(i_c);
         if constexpr (q + 1 < QT) {
           constexpr int n0 = (i * NSOFT) / NM, n1 = ((i + 1) * NSOFT) / NM;
           attn3_static_for<n0, n1>([&](auto n_c) __attribute__((always_inline)) { soft(n_c, std::integral_constant<int, q + 1>{}); });
         } else if constexpr (QK) {
+#if !A3_MFMA_SUMS
           if constexpr (i == 0) asm volatile("v_mov_b32 v[%c0], v[%c1]" ::"n"(A3_LSAVE), "n"(A3_L(0)));
+#endif
           constexpr int n0 = (i * NSOFT) / NM, n1 = ((i + 1) * NSOFT) / NM;
           attn3_static_for<n0, n1>([&](auto n_c) __attribute__((always_inline)) { soft(n_c, std::integral_constant<int, 0>{}); });
         }
@@ -597,7 +644,9 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_num_vgpr(A3_OWN))) vo
         }
         // the early softmax of query tile 0 ran on a tile that is recomputed (reference move), masked first (partial tile) or not
         // there at all: its row sums are taken back, its scores are overwritten by whoever needs them
+#if !A3_MFMA_SUMS   // (with the row sums on the matrix pipe the early softmax adds nothing to l: there is nothing to take back)
         asm volatile("v_mov_b32 v[%c0], v[%c1]" ::"n"(A3_L(0)), "n"(A3_LSAVE));
+#endif
         if (done) break;
         move_refs(Ff, Ff);              // some score left the window of its reference: move it, recompute S(t) from the ring, re-enter
         qk_owned((unsigned)(t & (NS - 1)));
@@ -631,7 +680,11 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_num_vgpr(A3_OWN))) vo
   attn3_static_for<0, QT>([&](auto q_c) __attribute__((always_inline)) {
     constexpr int q = decltype(q_c)::value;
     (void)&lq; (void)&mq;
+#if A3_MFMA_SUMS
+    asm volatile("v_mov_b32 %0, v[%c2]\n\tv_mov_b32 %1, v[%c3]" : "=v"(lq[q]), "=v"(mq[q]) : "n"(A3_AL(q)), "n"(A3_M(q)));
+#else
     asm volatile("v_mov_b32 %0, v[%c2]\n\tv_mov_b32 %1, v[%c3]" : "=v"(lq[q]), "=v"(mq[q]) : "n"(A3_L(q)), "n"(A3_M(q)));
+#endif
   });
   if (p.stat_max && wave_active) {   // largest row maximum (natural units) of this wave's queries: m_ref + the relative running maximum
     float m = mref[0] + mq[0];
@@ -662,8 +715,10 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_num_vgpr(A3_OWN))) vo
 #pragma unroll
   for (int q = 0; q < QT; ++q) {
     float l = lq[q];
+#if !A3_MFMA_SUMS   // (an MFMA row-sum tile already holds the full sum of the lane's query in every lane group)
     l += __shfl_xor(l, 16, 64);
     l += __shfl_xor(l, 32, 64);
+#endif
     const float inv = 1.0f / l;
 #pragma unroll
     for (int dv = 0; dv < DVT; ++dv) {

@@ -176,7 +176,7 @@ class Case:
         self.prepare_s = time.perf_counter() - t0
         with torch.no_grad():
             # warm-up forwards: the library measures which chain-kernel family (MID / POST: kernels_chain.h or the tall kernels) is faster on
-            # THIS box during the first 10 forwards of a given size (csrc/a2p_lib_run.h chain_pick_family; with A2P_CHAIN_TUNE=1 another 6
+            # THIS box during the first 11 forwards of a given size (csrc/a2p_lib_run.h chain_pick_family; with A2P_CHAIN_TUNE=1 another 6
             # for the workgroup shape, chain_pick_nw) -- all of them here, so that no timed step carries a calibration event wait whatever
             # --warmup the caller passes
             for _ in range(18):
