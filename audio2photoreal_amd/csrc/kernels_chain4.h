@@ -44,6 +44,9 @@
 #ifndef CHAIN4_PARK3
 #define CHAIN4_PARK3 0         // 48-row POST kernel with parked rows (frees 48 registers, e.g. for a 16-deep ring: CHAIN4_PF_POST3=16)
 #endif
+#ifndef CHAIN4_ABL
+#define CHAIN4_ABL 0           // scratch timing experiments (results wrong): 1 no weight loads after the ring is primed, 2 panel fragments read once per GEMM call, 4 the weight stream wraps inside its first 256 KiB (always L2-resident)
+#endif
 #define CHAIN4_HS_ELEMS 4096   // 128 output columns x 32 k: 8 KiB
 
 template <int MT>
@@ -128,8 +131,11 @@ __device__ __forceinline__ void chain4_body(const ChainP& p, h16_t* const smem, 
   // ---- weight stream: register ring of PF half stages --------------------------------------------------------------------
   uint32_t woff = (uint32_t)(wid * 64 + lane) * 16;   // byte offset of this lane's 16 bytes of the next half stage to load
   h16x8 wr[PF];
+  bool w_primed = false;
   auto w_issue = [&](int slot) __attribute__((always_inline)) {
-    wr[slot] = *reinterpret_cast<const h16x8*>(reinterpret_cast<const char*>(p.stream) + woff);   // uniform base + 32-bit offset
+    if ((CHAIN4_ABL & 1) && w_primed) { asm volatile("" : "+v"(wr[slot])); return; }
+    if (CHAIN4_ABL & 4) wr[slot] = *reinterpret_cast<const h16x8*>(reinterpret_cast<const char*>(p.stream) + (woff & 0x3ffffu));   // (every half stage from the first 256 KiB: L2 hits by construction)
+    else wr[slot] = *reinterpret_cast<const h16x8*>(reinterpret_cast<const char*>(p.stream) + woff);   // uniform base + 32-bit offset
     woff += CHAIN4_HS_ELEMS * 2;    // the host pads the stream behind the last half stage
   };
 
@@ -231,8 +237,10 @@ __device__ __forceinline__ void chain4_body(const ChainP& p, h16_t* const smem, 
       for (int c = 0; c < NKC; ++c) {
         if (c + 1 < NKC) {
 #pragma unroll
-          for (int mt = 0; mt < MT; ++mt)
-            a[(c + 1) & 1][mt] = *reinterpret_cast<const h16x8*>(rp + aswz[(c + 1) & 3] + ((c + 1) >> 2) * 256 + mt * rstep);
+          for (int mt = 0; mt < MT; ++mt) {
+            if (CHAIN4_ABL & 2) { a[(c + 1) & 1][mt] = a[c & 1][mt]; asm volatile("" : "+v"(a[(c + 1) & 1][mt])); }
+            else a[(c + 1) & 1][mt] = *reinterpret_cast<const h16x8*>(rp + aswz[(c + 1) & 3] + ((c + 1) >> 2) * 256 + mt * rstep);
+          }
         }
 #pragma unroll
         for (int t = 0; t < NTG; ++t) {
@@ -287,6 +295,7 @@ __device__ __forceinline__ void chain4_body(const ChainP& p, h16_t* const smem, 
   }
 #pragma unroll
   for (int i = 0; i < PF; ++i) w_issue(i);
+  w_primed = true;
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the DMA pieces have landed for this wave (once per kernel: the ring's first loads too)
   chain_bar();                                        // ... and for every other wave
   stamp(1);
