@@ -611,8 +611,11 @@ def cpu_and_parity(case, dev, want_parity=True, chain_steps=1000, chain_batch=2,
     try:
         with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r06_chain_vs_oracle.json")) as f:
             co = json.load(f)
-        parity["chain_vs_oracle"] = {"what": co["what"], "source": "profiles/r06_chain_vs_oracle.json (builder-run: oracle in the build container, product on an MI355X; NOT measured in this run)",
+        parity["chain_vs_oracle"] = {"what": co["what"], "source": "profiles/r06_chain_vs_oracle.json (builder-run: oracle in the build container, product on an MI355X; NOT measured in this run -- tests/test_hip_round6.py::test_full_sampling_chain_vs_oracle_states re-runs the product side against the committed oracle states in every GPU test run)",
                                      **{prec: {"after_1000_steps": m["steps"]["step1000"], "after_500_steps": m["steps"]["step500"]} for prec, m in co["modes"].items()}}
+        with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r06_chain_vs_oracle_body.json")) as f:
+            cb = json.load(f)
+        parity["chain_vs_oracle"]["body_ddim100"] = {"what": cb["what"], **{prec: m["steps"]["step100"] for prec, m in cb["modes"].items()}}
     except (OSError, KeyError, ValueError):
         pass
     bar = 1e-3

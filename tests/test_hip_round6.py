@@ -259,3 +259,32 @@ def test_guided_forward_with_attn3_matches_attn_kernel_path(dev, precision, monk
     record(f"attn3/guided_forward/{precision}", vs_attn_kernel_path=e, launches=launches["1"])
     assert launches == {"0": 0, "1": 16}, launches      # 8 layers x (self + cross); layer 0's shared-half trick keeps one launch per attention
     assert e < (6e-4 if precision == "fp16" else 5e-3), e
+
+
+# ----------------------------------------------------------------------------- the FULL chains of configs[1] and configs[2] against the oracle
+# gates: fp32 ~10x the measured error; 16-bit min(1e-3, 2 x measured) (profiles/r06_chain_vs_oracle*.json); bf16 is recorded, its gate is 2 x measured (it misses 1e-3)
+_CHAIN_GATES = {("face", "fp32"): 1e-4, ("face", "fp16"): 8.5e-4, ("face", "bf16"): 7e-3,
+                ("body", "fp32"): 1e-4, ("body", "fp16"): 7.5e-4, ("body", "bf16"): 6e-3}   # measured: face 7.3e-6 / 4.1e-4 / 3.4e-3, body 1.2e-6 / 3.6e-4 / 3.0e-3
+
+
+@pytest.mark.parametrize("workload,precision", sorted(_CHAIN_GATES))
+def test_full_sampling_chain_vs_oracle_states(dev, workload, precision):
+    """The WHOLE chain of the benchmarked workloads -- face: 1000 DDPM steps (gaussian_diffusion.py:434-477, :525-607), body: ddim100 with keyframe conditioning
+    (:667-779) -- at B=1, T=600, S=1998+2 through the product, against the chain states the ORACLE reached under identical x_T / conditioning / per-step noise
+    (tests/golden/golden_chain_<workload>_v1.npz, generated by tests/tools/chain_vs_oracle.py --side oracle: 21 CPU-minutes for the face chain).  Checked at
+    every saved step, gated on the last (the loop's return value: the north_star's 1e-3 applies to fp16)."""
+    import numpy as np
+    sys.path.insert(0, os.path.join(ROOT, "tests", "tools"))
+    import chain_vs_oracle as CVO
+    want = np.load(CVO.golden_path(workload))
+    states, seconds, ran_as = CVO.run_product(workload, precision, dev)
+    assert ran_as == precision
+    errs = {}
+    for n, got in sorted(states.items()):
+        w = torch.from_numpy(want[f"step{n}"])
+        assert torch.isfinite(got).all()
+        errs[n] = rel_l2(got, w)
+    last = max(errs)
+    record(f"chain_vs_oracle/{workload}/{precision}", steps=last, gpu_seconds=round(seconds, 2), **{f"rel_l2_step{n}": e for n, e in errs.items()})
+    assert last == CVO.WORKLOADS[workload]["steps"]
+    assert errs[last] <= _CHAIN_GATES[(workload, precision)], (workload, precision, errs)
