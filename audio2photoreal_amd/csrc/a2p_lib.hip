@@ -461,11 +461,14 @@ static int launch_attn(a2p_ctx* c, const AttnP& p0, int nseq, int kind, hipStrea
   // reference.  Measured stand-alone against attn_kernel (scratch/attn3_bench.hip, profiles/r06_attn3_bench.txt): x1.35 on the B=8
   // cross attention (2000 keys, 256 workgroups = one per CU), x1.12 on its self attention, x1.07 on the B=32 cross attention, but
   // x0.85 on short key ranges once the launch is several rounds of workgroups (its per-workgroup prologue is longer), and slower on
-  // the body model's head_dim 32 -- hence the rule.
+  // the body model's short key ranges -- hence the rule.
   if (c->bf16 && c->opt.attn3 && !c->opt.attn2 && (c->DH == 64 || c->DH == 32) && p.ldvt % 8 == 0) {
     const int nq3 = (p.Tq + 319) / 320;
     const int64_t wgs = (int64_t)nq3 * c->H * nseq;
-    const bool wins = c->DH == 64 && p.Tq >= 160 && (p.S_main + p.S_tail >= 1024 || wgs <= 256);
+    // v5 (row sums on the matrix pipe; profiles/r06_attn3_bench_v5.txt): also x1.19 on the body model's cross attention (head_dim 32, 2000 keys, 512 workgroups:
+    // 81 vs 97 us); its self attention (600 keys) and the B=32 face self attention stay x0.9
+    const int S3 = p.S_main + p.S_tail;
+    const bool wins = p.Tq >= 160 && ((c->DH == 64 && (S3 >= 1024 || wgs <= 256)) || (c->DH == 32 && S3 >= 1024));
     if (c->opt.attn3 >= 2 || wins) {
       p.nq = nq3;
       dim3 grid3((unsigned)wgs);

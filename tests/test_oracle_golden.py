@@ -121,3 +121,25 @@ def test_plms_first_steps_and_ddim_reverse_vs_reference(golden_plms):
     r = s.ddim_reverse_sample(fn, inp["x_T"], torch.tensor([5]))
     assert rel_l2(r["sample"], golden_plms["face/ddim_reverse_t5"]) < 5 * TOL
 
+
+
+def test_chain_fixture_is_what_the_committed_generator_produces():
+    """tests/golden/golden_chain_body_v1.npz (the oracle's ddim100 chain of the body workload, gated against by the GPU suite) must be reproducible from
+    tests/tools/chain_vs_oracle.py --side oracle: the first 10 steps re-run here (3 s) land on the stored state after step 10; the face fixture (21
+    CPU-minutes) is checked for its layout only."""
+    import os
+    import sys
+    import numpy as np
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "tools"))
+    import chain_vs_oracle as CVO
+
+    class A:
+        workload, T, threads, steps, out = "body", 600, 4, 10, os.path.join(os.environ.get("TMPDIR", "/tmp"), "chain_body_first10.npz")
+    CVO.side_oracle(A)
+    got, want = np.load(A.out), np.load(CVO.golden_path("body"))
+    assert sorted(k for k in want.files if k.startswith("step")) == ["step10", "step100", "step50", "step90"]
+    err = np.linalg.norm(got["step10"].astype(np.float64) - want["step10"]) / np.linalg.norm(want["step10"])
+    assert err < 1e-6, err
+    face = np.load(CVO.golden_path("face"))
+    assert sorted(k for k in face.files if k.startswith("step")) == ["step100", "step1000", "step500", "step900"]
+    assert face["step1000"].shape == (1, 256, 1, 600) and np.isfinite(face["step1000"]).all()
