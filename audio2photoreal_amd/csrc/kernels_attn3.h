@@ -58,26 +58,13 @@ struct Attn3Geo {
 };
 
 #define A3_QT 5
-#ifndef A3_MFMA_SUMS
-#define A3_MFMA_SUMS 1   // 1: the softmax row sums are two extra MFMAs per query tile and key tile (a fragment of ones x P^T) instead of 16 v_add_f32
-#endif
 // Owned registers.  Vector file, v[A3_OWN : 255] (hipcc allocates v0 .. v[A3_OWN - 1]):
-#if A3_MFMA_SUMS
 #define A3_OWN 100
 #define A3_PF(b, c) (100 + 4 * (2 * (b) + (c)))   // P fragment tuples (MFMA B operand), three buffers: b = q % 3, c = key chunk (query tile 0 of the NEXT tile
                                                   // is converted while query tile 4's fragments, buffer 1, are still being read)
 #define A3_CI(q) (124 + 4 * (q))                  // -m_ref of query tile q, four copies: the C operand of its first QK^T MFMA
 #define A3_AL(q) (144 + 4 * (q))                  // row sums of query tile q as an MFMA accumulator tile: l[query l15] in every register of every lane group
-#define A3_ONES 164                               // a fragment of ones (A operand of the row-sum MFMAs)
 #define A3_M(q) (168 + (q))                       // running maximum of query tile q's scores RELATIVE to its reference (per lane)
-#else
-#define A3_OWN 120
-#define A3_PF(b, c) (120 + 4 * (2 * (b) + (c)))
-#define A3_LSAVE 174                              // l of query tile 0 before the early softmax of the next tile (restored when that tile is recomputed)
-#define A3_CI(q) (144 + 4 * (q))
-#define A3_L(q) (164 + (q))                       // row-sum accumulator of query tile q (per lane: the lane's keys)
-#define A3_M(q) (169 + (q))
-#endif
 #define A3_SB 176                                 // score (kt, q, r): v[A3_SB + 4 * (kt * A3_QT + q) + r]; tuples are MFMA C/D operands
 #define A3_S(kt, q, r) (A3_SB + 4 * ((kt) * A3_QT + (q)) + (r))
 // Accumulator file, a[0 : 247] (hipcc is given no reason to touch the accumulator file at all: every "a" value is literal):
@@ -86,6 +73,7 @@ struct Attn3Geo {
 // two fragment sets (a[120 : 183], a[184 : 247]): step t consumes set t & 1 while the fragments of step t + 1 land in the other one
 #define A3_AK(set, kc, kt) (120 + 64 * (set) + 4 * ((kc) * 4 + (kt)))           // K fragments (of the tile whose scores the step produces)
 #define A3_AV(set, c, dv, DVT_) (152 + 64 * (set) + 4 * ((c) * (DVT_) + (dv)))  // V^T fragments (of the tile the step consumes)
+#define A3_ONES(c) (248 + 4 * (c))   // A operand of the row-sum MFMAs of 32-key chunk c: ones -- for the LAST tile: ones on its valid keys, zeros on the padding
 #ifndef A3X
 #define A3X 0   // scratch timing experiments (results wrong): 1 no exp2, 2 no maxima, 4 no softmax packets at all, 8 no MFMAs, 16 no fragment reads
 #endif
@@ -114,7 +102,7 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_num_vgpr(A3_OWN))) vo
   typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
   __shared__ __attribute__((aligned(16))) h16_t smem[NS * G::SLOT];
   static_assert(BQ * (DH + 8) <= NS * G::SLOT, "output staging does not fit the tile ring");
-  asm volatile("" ::: "v255", "a247");   // (the kernel descriptor must cover the owned registers of both files)
+  asm volatile("" ::: "v255", "a255");   // (the kernel descriptor must cover the owned registers of both files)
 
   const int lane = threadIdx.x & 63, wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int l15 = lane & 15, g = lane >> 4;
@@ -137,8 +125,7 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_num_vgpr(A3_OWN))) vo
   const bool kv_nt = p.kv_stream && slot != 0;
   const int S_total = p.S_main + p.S_tail;
   const int ntiles = (S_total + KV - 1) / KV;
-  const int nfull = S_total / KV;                 // full tiles; a partial last tile (index nfull) is drained behind the loop
-  const int rem = S_total - nfull * KV;           // its keys
+  const int rem = S_total % KV;                   // keys of a partial last tile (0: the last tile is full)
   const bool wave_active = __builtin_amdgcn_readfirstlane(q0) < p.Tq;
 
   const h16_t* Qb = reinterpret_cast<const h16_t*>(p.Q) + (int64_t)seq * p.q_seq_stride + head * DH;
@@ -253,12 +240,8 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_num_vgpr(A3_OWN))) vo
   attn3_static_for<0, QT>([&](auto q_c) __attribute__((always_inline)) {
     constexpr int q = decltype(q_c)::value;
     // l = 0, running maximum = -inf, reference 0
-#if A3_MFMA_SUMS
     asm volatile("v_mov_b32 v[%c0], 0xff800000" ::"n"(A3_M(q)));
     asm volatile("v_mov_b32 v[%c0], 0\n\tv_mov_b32 v[%c1], 0\n\tv_mov_b32 v[%c2], 0\n\tv_mov_b32 v[%c3], 0" ::"n"(A3_AL(q)), "n"(A3_AL(q) + 1), "n"(A3_AL(q) + 2), "n"(A3_AL(q) + 3));
-#else
-    asm volatile("v_mov_b32 v[%c0], 0\n\tv_mov_b32 v[%c1], 0xff800000" ::"n"(A3_L(q)), "n"(A3_M(q)));
-#endif
     asm volatile("v_mov_b32 v[%c0], 0\n\tv_mov_b32 v[%c1], 0\n\tv_mov_b32 v[%c2], 0\n\tv_mov_b32 v[%c3], 0" ::"n"(A3_CI(q)), "n"(A3_CI(q) + 1), "n"(A3_CI(q) + 2), "n"(A3_CI(q) + 3));
     attn3_static_for<0, 4 * DVT>([&](auto e_c) __attribute__((always_inline)) {
       constexpr int e = decltype(e_c)::value;
@@ -266,16 +249,14 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_num_vgpr(A3_OWN))) vo
     });
   });
 
-#if A3_MFMA_SUMS
-  {
 #ifdef A2P_HALF
-    constexpr unsigned ONE2 = 0x3c003c00u;   // two IEEE-half ones
+  constexpr unsigned ONE1 = 0x3c00u;   // an IEEE-half one
 #else
-    constexpr unsigned ONE2 = 0x3f803f80u;   // two bfloat16 ones
+  constexpr unsigned ONE1 = 0x3f80u;   // a bfloat16 one
 #endif
-    asm volatile("v_mov_b32 v[%c0], %4\n\tv_mov_b32 v[%c1], %4\n\tv_mov_b32 v[%c2], %4\n\tv_mov_b32 v[%c3], %4" ::"n"(A3_ONES), "n"(A3_ONES + 1), "n"(A3_ONES + 2), "n"(A3_ONES + 3), "s"(ONE2));
-  }
-#endif
+  attn3_static_for<0, 8>([&](auto e_c) __attribute__((always_inline)) {
+    asm volatile("v_accvgpr_write_b32 a[%c0], %1" ::"n"(A3_ONES(0) + decltype(e_c)::value), "v"(ONE1 | (ONE1 << 16)));
+  });
   // LDS byte addresses of this lane's K / V^T fragments inside ring slot 0.  The swizzle of a fragment depends on the lane only, the
   // k-chunk (kc / c) flips one bit of the swizzled chunk index (hence one base per chunk), kt / dv are plain row offsets (immediates)
   const unsigned smem_base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) h16_t*)smem;
@@ -329,20 +310,18 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_num_vgpr(A3_OWN))) vo
     });
     A3_MFMA_LANDED();
   };
-  // scores of keys past the end of `tile` -> -inf (per-lane predicate: the lane's keys of S^T tile kt are krow(kt, 4 g + r))
-  auto mask_owned = [&](int tile) __attribute__((always_inline)) {
-    const int kv0 = tile * KV;
-    attn3_static_for<0, 4>([&](auto t_c) __attribute__((always_inline)) {
-      attn3_static_for<0, 4>([&](auto r_c) __attribute__((always_inline)) {
-        constexpr int kt = decltype(t_c)::value, r = decltype(r_c)::value;
-        if (kv0 + L::krow(kt, g * 4 + r) >= S_total) {
-          attn3_static_for<0, QT>([&](auto q_c) __attribute__((always_inline)) {
-            constexpr int q = decltype(q_c)::value;
-            asm volatile("v_mov_b32 v[%c0], 0xff800000" ::"n"(A3_S(kt, q, r)));
-          });
-        }
-      });
+  // keys past the end of the LAST tile need no score mask: their K rows are copies of the tile's key 0 (finish_last_tile: finite duplicate scores that cannot
+  // raise a maximum), their V^T columns are zero (no contribution to O), and the ones fragment of that tile's row-sum MFMAs is zero on them (no
+  // contribution to l) -- so the partial tile is an ordinary step and nothing is recomputed for it
+  auto mask_last_ones = [&]() __attribute__((always_inline)) {
+    const int kv0 = (ntiles - 1) * KV;
+    A3_MFMA_LANDED();   // (the previous step's row-sum MFMAs have long read the fragment; cheap insurance in a cold path)
+    attn3_static_for<0, 8>([&](auto e_c) __attribute__((always_inline)) {
+      constexpr int e = decltype(e_c)::value, c = e >> 2, w = e & 3, kt = 2 * c + (w >> 1), r0 = (w & 1) * 2;   // P fragment register w of chunk c = scores (kt, r0), (kt, r0 + 1)
+      const unsigned m = (kv0 + L::krow(kt, g * 4 + r0) < S_total ? ONE1 : 0u) | (kv0 + L::krow(kt, g * 4 + r0 + 1) < S_total ? ONE1 << 16 : 0u);
+      asm volatile("v_accvgpr_write_b32 a[%c0], %1" ::"n"(A3_ONES(0) + e), "v"(m));
     });
+    asm volatile("s_nop 7" ::: "memory");   // (v_accvgpr_write -> MFMA operand)
   };
   auto max_owned = [&]() __attribute__((always_inline)) {   // fold the tile into the running maxima
     attn3_static_for<0, QT>([&](auto q_c) __attribute__((always_inline)) {
@@ -373,14 +352,10 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_num_vgpr(A3_OWN))) vo
       const float f = __builtin_amdgcn_exp2f(-d);
       mref[q] += d;
       const float nm = -mref[q];
-#if A3_MFMA_SUMS
       asm volatile("v_sub_f32 v[%c0], v[%c0], %1" ::"n"(A3_M(q)), "v"(d));
       if constexpr (!FIRST)
         asm volatile("v_mul_f32 v[%c0], v[%c0], %4\n\tv_mul_f32 v[%c1], v[%c1], %4\n\tv_mul_f32 v[%c2], v[%c2], %4\n\tv_mul_f32 v[%c3], v[%c3], %4"
                      ::"n"(A3_AL(q)), "n"(A3_AL(q) + 1), "n"(A3_AL(q) + 2), "n"(A3_AL(q) + 3), "v"(f));
-#else
-      asm volatile("v_sub_f32 v[%c0], v[%c0], %2\n\tv_mul_f32 v[%c1], v[%c1], %3" ::"n"(A3_M(q)), "n"(A3_L(q)), "v"(d), "v"(f));
-#endif
       asm volatile("v_mov_b32 v[%c0], %4\n\tv_mov_b32 v[%c1], %4\n\tv_mov_b32 v[%c2], %4\n\tv_mov_b32 v[%c3], %4" ::"n"(A3_CI(q)), "n"(A3_CI(q) + 1), "n"(A3_CI(q) + 2), "n"(A3_CI(q) + 3), "v"(nm));
       attn3_static_for<0, FIRST ? 0 : 4 * DVT>([&](auto e_c) __attribute__((always_inline)) {   // O *= f (through a vector register: the accumulator file has no arithmetic)
         constexpr int e = decltype(e_c)::value;
@@ -448,9 +423,6 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_num_vgpr(A3_OWN))) vo
   auto soft = [&](auto n_c, auto q_c) __attribute__((always_inline)) {
     constexpr int n = decltype(n_c)::value, q = decltype(q_c)::value;
     if constexpr (n < 16 && !(A3X & 5)) asm volatile("v_exp_f32 v[%c0], v[%c0]" ::"n"(A3_S(n >> 2, q, n & 3)));
-#if !A3_MFMA_SUMS
-    if constexpr (n >= 2 && n < 18 && !(A3X & 4)) asm volatile("v_add_f32 v[%c0], v[%c0], v[%c1]" ::"n"(A3_L(q)), "n"(A3_S((n - 2) >> 2, q, (n - 2) & 3)));
-#endif
     if constexpr (n >= 5 && ((n - 5) & 1) == 0 && (n - 5) / 2 < 8 && !(A3X & 4)) {
       constexpr int j = (n - 5) / 2, c = j >> 2, w = j & 3, kt = 2 * c + (w >> 1), r0 = (w & 1) * 2;
       asm volatile(A3_CVT " v[%c0], v[%c1], v[%c2]" ::"n"(A3_PF(q % 3, c) + w), "n"(A3_S(kt, q, r0)), "n"(A3_S(kt, q, r0 + 1)));
@@ -468,8 +440,8 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_num_vgpr(A3_OWN))) vo
   // tile t + 1 is issued between the MFMAs of this step's LAST group, whose MFMA order is QK^T first, PV second, so that the maxima of
   // its new scores fit behind them: nothing of a step is left un-overlapped (measured before: softmax of query tile 0 347 of 3000
   // cycles per step, wait states + tail maxima ~70).  The early softmax runs BEFORE the vote on tile t + 1: if that tile turns out to
-  // need a reference move it is recomputed from the ring anyway, and l of query tile 0 is restored from A3_LSAVE.
-  // QK = false: the drain of the partial last tile (softmax of query tile 0 first, PV MFMAs only).
+  // need a reference move it is recomputed from the ring anyway (the row sums live on the matrix pipe: the early softmax adds nothing to l).
+  // QK = false: the drain of the LAST tile (PV + row-sum MFMAs with the softmax of query tiles 1 .. 4 between them; query tile 0 is the caller's).
   auto step = [&](int t, auto qk_c, auto par_c) __attribute__((always_inline)) {
     constexpr bool QK = decltype(qk_c)::value;
     constexpr int PAR = decltype(par_c)::value;
@@ -483,8 +455,6 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_num_vgpr(A3_OWN))) vo
       for (int c = 0; c < 2; ++c) fa_v[c] = vbase[c] + vs;
 #pragma unroll
       for (int kc = 0; kc < KC; ++kc) fa_k[kc] = kbase[kc] + ks;
-    } else {
-      soft0_now();
     }
     auto frag_read = [&](auto i_c) __attribute__((always_inline)) {   // read number i of the next step's fragments
       constexpr int i = decltype(i_c)::value;
@@ -499,7 +469,7 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_num_vgpr(A3_OWN))) vo
       }
     };
     A3_STAMP(0);  // fragment wait + addresses
-    constexpr int NSUM = A3_MFMA_SUMS ? 2 : 0;   // row-sum MFMAs per group: l[q] += ones x P[q]^T, one per 32-key chunk
+    constexpr int NSUM = 2;   // row-sum MFMAs per group: l[q] += ones x P[q]^T, one per 32-key chunk
     constexpr int SPC = DVT + NSUM / 2;          // PV-part MFMAs per 32-key chunk
     constexpr int NPV = 2 * SPC, NQK = QK ? 4 * KC : 0, NM = NPV + NQK;   // MFMAs per group
     attn3_static_for<0, QT>([&](auto q_c) __attribute__((always_inline)) {
@@ -510,13 +480,11 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_num_vgpr(A3_OWN))) vo
         constexpr int i = decltype(i_c)::value;
         constexpr bool is_pv = LASTG ? i >= NQK : i < NPV;
         constexpr int ip = LASTG ? i - NQK : i, iq = LASTG ? i : i - NPV;
-        // PV part, per 32-key chunk c: the DVT MFMAs of O^T[q] and (A3_MFMA_SUMS) the row-sum MFMA behind them -- the two accumulating MFMAs of
+        // PV part, per 32-key chunk c: the DVT MFMAs of O^T[q] and the row-sum MFMA behind them -- the two accumulating MFMAs of
         // an accumulator are DVT + 1 apart, never back to back
         if constexpr (is_pv && ip % SPC == DVT) {
-#if A3_MFMA_SUMS
           constexpr int c = ip / SPC, RL = A3_AL(q);
-          if constexpr (!(A3X & 8)) asm volatile(A3_MFMA " v[%c0:%c1], v[%c2:%c3], v[%c4:%c5], v[%c0:%c1]" ::"n"(RL), "n"(RL + 3), "n"(A3_ONES), "n"(A3_ONES + 3), "n"(A3_PF(q % 3, c)), "n"(A3_PF(q % 3, c) + 3));
-#endif
+          if constexpr (!(A3X & 8)) asm volatile(A3_MFMA " v[%c0:%c1], a[%c2:%c3], v[%c4:%c5], v[%c0:%c1]" ::"n"(RL), "n"(RL + 3), "n"(A3_ONES(c)), "n"(A3_ONES(c) + 3), "n"(A3_PF(q % 3, c)), "n"(A3_PF(q % 3, c) + 3));
         } else if constexpr (is_pv) {
           constexpr int c = ip / SPC, dv = ip % SPC, RO = A3_AO(q, dv, DVT);
           if constexpr (!(A3X & 8)) asm volatile(A3_MFMA " a[%c0:%c1], a[%c2:%c3], v[%c4:%c5], a[%c0:%c1]" ::"n"(RO), "n"(RO + 3), "n"(A3_AV(PAR, c, dv, DVT)), "n"(A3_AV(PAR, c, dv, DVT) + 3), "n"(A3_PF(q % 3, c)), "n"(A3_PF(q % 3, c) + 3));
@@ -534,9 +502,6 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_num_vgpr(A3_OWN))) vo
           constexpr int n0 = (i * NSOFT) / NM, n1 = ((i + 1) * NSOFT) / NM;
           attn3_static_for<n0, n1>([&](auto n_c) __attribute__((always_inline)) { soft(n_c, std::integral_constant<int, q + 1>{}); });
         } else if constexpr (QK) {
-#if !A3_MFMA_SUMS
-          if constexpr (i == 0) asm volatile("v_mov_b32 v[%c0], v[%c1]" ::"n"(A3_LSAVE), "n"(A3_L(0)));
-#endif
           constexpr int n0 = (i * NSOFT) / NM, n1 = ((i + 1) * NSOFT) / NM;
           attn3_static_for<n0, n1>([&](auto n_c) __attribute__((always_inline)) { soft(n_c, std::integral_constant<int, 0>{}); });
         }
@@ -612,15 +577,13 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_num_vgpr(A3_OWN))) vo
   if (wave_active) {
     // S(0) against reference 0, its exact row maxima become the references
     qk_owned(0u);
-    if (ntiles == 1 && rem > 0) mask_owned(0);
     max_owned();
     sync_top(0);
     move_refs(Tt, Tt);
     int t = 0;
-    if (nfull > 0) {
-      // ONE step body per parity, the rare reference move OUTSIDE the fast loop (see the header).  Behind the last full tile the
-      // "next" tile is the partial tile (its dead keys are copies of its key 0: real scores that cannot raise a maximum) or, none
-      // left, the last tile again: the step has one form, and what it did too early for that tile is undone behind the loop.
+    const int nqk = ntiles - 1;   // steps that also produce their successor's scores: tiles 0 .. ntiles - 2; the last tile is consumed by the drain
+    if (nqk > 0) {
+      // ONE step body per parity, the rare reference move OUTSIDE the fast loop (see the header)
 #ifdef A3_STAMPS
       for (int k = 0; k < 8; ++k) stamp_acc[k] = 0;
       stamp_last = __builtin_readcyclecounter();
@@ -638,36 +601,32 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_num_vgpr(A3_OWN))) vo
           if (t & 1) step(t, Tt, P1);
           else step(t, Tt, P0);
           ++t;
-          if (t >= nfull) { done = true; break; }
+          if (t >= nqk) { done = true; break; }
           sync_top(t);
           if (must_move()) break;
         }
-        // the early softmax of query tile 0 ran on a tile that is recomputed (reference move), masked first (partial tile) or not
-        // there at all: its row sums are taken back, its scores are overwritten by whoever needs them
-#if !A3_MFMA_SUMS   // (with the row sums on the matrix pipe the early softmax adds nothing to l: there is nothing to take back)
-        asm volatile("v_mov_b32 v[%c0], v[%c1]" ::"n"(A3_L(0)), "n"(A3_LSAVE));
-#endif
         if (done) break;
         move_refs(Ff, Ff);              // some score left the window of its reference: move it, recompute S(t) from the ring, re-enter
         qk_owned((unsigned)(t & (NS - 1)));
       }
-      if (rem > 0) {                    // the partial last tile: recomputed (query tile 0 was exponentiated early, unmasked), masked
-        A3_MFMA_LANDED();
+      // t == ntiles - 1: its scores are there, query tile 0 already exponentiated (by the last step); nothing left to wait for or to request
+      if (must_move()) {
+        move_refs(Ff, Ff);
         qk_owned((unsigned)(t & (NS - 1)));
-        mask_owned(t);
-        if (must_move()) move_refs(Tt, Ff);
         prime(t);                       // (qk_owned used fragment set 0)
+        soft0_now();
       }
     } else {
       prime(0);
+      soft0_now();
     }
-    if (rem > 0) {                      // drain: softmax + O^T += V^T P^T of the partial tile
-      if (t & 1) step(t, Ff, P1);
-      else step(t, Ff, P0);
-    }
+    if (rem > 0) mask_last_ones();
+    // drain: softmax of query tiles 1 .. 4 + O^T += V^T P^T + row sums of the last tile
+    if (t & 1) step(t, Ff, P1);
+    else step(t, Ff, P0);
     A3_MFMA_LANDED();
   } else {
-    const int nsync = nfull > 0 ? nfull : 1;
+    const int nsync = ntiles > 1 ? ntiles - 1 : 1;
     for (int t = 0; t < nsync; ++t) sync_top(t);
   }
 
@@ -680,11 +639,7 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_num_vgpr(A3_OWN))) vo
   attn3_static_for<0, QT>([&](auto q_c) __attribute__((always_inline)) {
     constexpr int q = decltype(q_c)::value;
     (void)&lq; (void)&mq;
-#if A3_MFMA_SUMS
     asm volatile("v_mov_b32 %0, v[%c2]\n\tv_mov_b32 %1, v[%c3]" : "=v"(lq[q]), "=v"(mq[q]) : "n"(A3_AL(q)), "n"(A3_M(q)));
-#else
-    asm volatile("v_mov_b32 %0, v[%c2]\n\tv_mov_b32 %1, v[%c3]" : "=v"(lq[q]), "=v"(mq[q]) : "n"(A3_L(q)), "n"(A3_M(q)));
-#endif
   });
   if (p.stat_max && wave_active) {   // largest row maximum (natural units) of this wave's queries: m_ref + the relative running maximum
     float m = mref[0] + mq[0];
@@ -715,10 +670,6 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_num_vgpr(A3_OWN))) vo
 #pragma unroll
   for (int q = 0; q < QT; ++q) {
     float l = lq[q];
-#if !A3_MFMA_SUMS   // (an MFMA row-sum tile already holds the full sum of the lane's query in every lane group)
-    l += __shfl_xor(l, 16, 64);
-    l += __shfl_xor(l, 32, 64);
-#endif
     const float inv = 1.0f / l;
 #pragma unroll
     for (int dv = 0; dv < DVT; ++dv) {
