@@ -17,10 +17,17 @@
 //          the same relative rounding in the 16-bit P operand); the test is one wave vote per tile step and the rare fix-up (rescale O
 //          and l, recompute or shift the pending score tile) is its own block OUTSIDE the fast loop.  Softmax is invariant to the
 //          reference value: the result differs from the exact-max form by rounding only.
-//      Fast path per score: exp2, add, half a max3, half a convert = 3 instructions (4 issue slots) instead of ~6.8.
-//   2. The stream.  For the five query tiles q of a wave, "group q" is 16 MFMAs -- O^T[q] += V^T(t) P[q]^T (8), then
+//        * the ROW SUMS are matrix work (v5): l[q] += ones x P[q]^T, one extra MFMA per query tile and 32-key chunk whose A operand is a constant
+//          fragment of 16-bit ones, instead of 16 v_add_f32 per query tile and key tile -- the step is vector-issue bound (without its MFMAs it
+//          takes MORE cycles than with them, profiles/r06_attn3_step_ablation_v4.txt) and the matrix pipe is half idle;
+//        * keys past the end of a partial LAST tile are masked in that ones fragment, not in the scores (v6): their K rows are copies of the
+//          tile's key 0, their V^T columns zero, so the last tile is an ordinary step and nothing is recomputed for it.
+//      Fast path per score: exp2, half a max3, half a convert = 2 instructions (3 issue slots) instead of ~6.8.
+//   2. The stream.  For the five query tiles q of a wave, "group q" is 18 MFMAs -- O^T[q] += V^T(t) P[q]^T (8) and l[q] += ones x P[q]^T (2), then
 //      S[q] = K(t+1) Q[q]^T - m_ref[q] (8, overwriting the consumed scores in place) -- with the softmax of query tile q+1 and the maxima
-//      of the S[q-1] written one group earlier issued between them, packet by packet.
+//      of the S[q-1] written one group earlier issued between them, packet by packet.  Per step: 90 MFMAs (18 cycles each, 2 hidden issue
+//      slots each) against 80 exp2 + 40 max3 + 40 cvt_pk + 16 fragment reads = 256 slots: 90 x 18 + 76 x 4 = 1924 cycles by the model, 2498
+//      measured with the ring (tile DMA issue, barrier) and loop control (docs/lab_notebook_r6.md sections 3, 4, 7).
 //
 // Geometry: workgroup = 4 waves x 5 query tiles of 16 = 320 queries; T = 600 -> 2 workgroups per (sequence, head) pair; the headline
 // launch (16 sequences x 8 heads) is 256 workgroups = exactly one per CU, every SIMD carries 5 query tiles (attn_kernel: 6 on the
@@ -28,8 +35,8 @@
 // swizzles, the key <-> fragment map, slot-indexed K/V, time-token tail, XCD-aware grid, non-temporal policy, logit maximum and the
 // LDS-transposed store are attn_kernel's.
 //
-// REGISTER OWNERSHIP.  The score tile (80 registers), the five row-sum accumulators and the five running maxima live in
-// v[A3_OWN : 255] and are addressed LITERALLY by the asm statements; hipcc is held below A3_OWN (amdgpu_num_vgpr) and never sees
+// REGISTER OWNERSHIP.  The score tile (80 registers), the P fragments, the five row-sum accumulator tiles and the five running maxima live in
+// v[A3_OWN : 255], O, Q, the K / V^T fragment sets and the ones fragments in the accumulator file; all are addressed LITERALLY by the asm statements; hipcc is held below A3_OWN (amdgpu_num_vgpr) and never sees
 // them.  History of why (each seen in the ISA of a build of this file): builtins + sched_barrier(0) after every packet came out
 // with all 80 exponentials of a step in front of its first MFMA (instruction selection linearises pure values before the scheduler
 // ever sees the barriers); asm volatile statements keep their order, but with the tile as a C++ value hipcc parked the loop-carried
