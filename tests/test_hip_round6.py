@@ -208,11 +208,19 @@ def test_attn3_kernel_vs_fp64_and_vs_attn_kernel(dev, fmt, precision, monkeypatc
         return out.cpu(), _debug_i64(model, b"attn3_launches") - before
     worst = 0.0
     for (N, Tq, S, kind) in [(2, 100, 77, "plain"), (3, 33, 20, "plain"), (2, 321, 128, "plain"), (1, 600, 800, "spike"), (2, 150, 150, "neg"),
-                             (1, 600, 2000, "spike"), (2, 640, 254, "plain"), (1, 80, 1000, "spike")]:
+                             (1, 600, 2000, "spike"), (2, 640, 254, "plain"), (1, 80, 1000, "spike"),
+                             # round 6, v6 (the last tile is an ordinary step whose padding keys are masked in the ones fragment of the row-sum MFMAs): the reference has
+                             # to move ON the last tile (its own vote behind the loop), on a partial and on a full last tile; and a spike on KEY 0 of a partial last tile --
+                             # the key whose row is copied into the padding rows, so the padding scores are as large as the spike and only the mask keeps them out of l
+                             (1, 600, 2000, "spike_last"), (2, 320, 256, "spike_last"), (1, 600, 600, "spike_last_key0"), (2, 100, 77, "spike_last_key0")]:
         q, k, v = (torch.randn(N, L, d, generator=g) for L in (Tq, S, S))
         if kind == "spike":
             k[0, S // 3] *= 6.0
             k[0, (2 * S) // 3] *= -5.0
+        if kind == "spike_last":
+            k[:, S - 1] *= 6.0
+        if kind == "spike_last_key0":
+            k[:, ((S - 1) // 64) * 64] *= 6.0
         if kind == "neg":
             q[:] = q.abs() * 1.5
             k[:] = -k.abs() * 1.5
