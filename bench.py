@@ -616,6 +616,10 @@ def cpu_and_parity(case, dev, want_parity=True, chain_steps=1000, chain_batch=2,
         with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r06_chain_vs_oracle_body.json")) as f:
             cb = json.load(f)
         parity["chain_vs_oracle"]["body_ddim100"] = {"what": cb["what"], **{prec: m["steps"]["step100"] for prec, m in cb["modes"].items()}}
+        if "vs_reference" in co and "vs_reference" in cb:   # the same chains run by the reference itself (tests/golden/make_golden_chain.py): rel-L2 of the final state
+            parity["chain_vs_reference"] = {"what": co["vs_reference"]["what"], "source": parity["chain_vs_oracle"]["source"],
+                                            "face_1000_steps": {k: v["step1000"] for k, v in co["vs_reference"].items() if isinstance(v, dict)},
+                                            "body_ddim100": {k: v["step100"] for k, v in cb["vs_reference"].items() if isinstance(v, dict)}}
     except (OSError, KeyError, ValueError):
         pass
     bar = 1e-3

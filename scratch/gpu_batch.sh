@@ -1,11 +1,11 @@
 #!/bin/bash
-# round 6, call 53: attn3 v6 edge cases in the GPU test (reference move on the last tile, spike on the last tile's key 0)
+# round 6, call 54: the full chains gated against the REFERENCE's own chain states (tests/golden/golden_chain_*_ref_v1.npz)
 R=${GRAFT_REPO_ROOT:-/root/repo}
 cd $R
-timeout -k 5 600 python -m pytest tests/test_hip_round6.py -m gpu -q -k "attn3_kernel_vs_fp64" 2>&1 | tail -15
+timeout -k 5 600 python -m pytest tests/test_hip_round6.py -m gpu -q -k "full_sampling_chain" 2>&1 | tail -3
 python - <<'PY'
 import json
-d=json.load(open("gpurun_out/parity_tests.json")) if __import__("os").path.exists("gpurun_out/parity_tests.json") else {}
+d=json.load(open("gpurun_out/parity_tests.json"))
 for k,v in d.items():
-    if "spike_last" in k: print(k, v)
+    if k.startswith("chain_vs_reference"): print(k, {a:b for a,b in v.items() if a.endswith(("step1000","step100"))})
 PY

@@ -143,3 +143,21 @@ def test_chain_fixture_is_what_the_committed_generator_produces():
     face = np.load(CVO.golden_path("face"))
     assert sorted(k for k in face.files if k.startswith("step")) == ["step100", "step1000", "step500", "step900"]
     assert face["step1000"].shape == (1, 256, 1, 600) and np.isfinite(face["step1000"]).all()
+
+
+@pytest.mark.parametrize("workload", ["body", "face"])
+def test_oracle_chain_states_equal_the_references_own_chain(workload):
+    """The oracle's FULL chains (body ddim100, face 1000-step DDPM with per-step noise) against the same chains run by the reference itself
+    (tests/golden/make_golden_chain.py -> golden_chain_<workload>_ref_v1.npz): every stored state to 1e-5 (measured: body 7.4e-7 after 100 steps)."""
+    import os
+    import sys
+    import numpy as np
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "tools"))
+    import chain_vs_oracle as CVO
+    orc = np.load(CVO.golden_path(workload))
+    ref = np.load(CVO.golden_path(workload).replace("_v1.npz", "_ref_v1.npz"))
+    steps = sorted(k for k in orc.files if k.startswith("step"))
+    assert steps == sorted(k for k in ref.files if k.startswith("step"))
+    for k in steps:
+        a, b = ref[k].astype(np.float64), orc[k].astype(np.float64)
+        assert np.linalg.norm(a - b) / np.linalg.norm(a) < 1e-5, (workload, k)
