@@ -468,7 +468,11 @@ static int launch_attn(a2p_ctx* c, const AttnP& p0, int nseq, int kind, hipStrea
     // v5 (row sums on the matrix pipe; profiles/r06_attn3_bench_v5.txt): also x1.19 on the body model's cross attention (head_dim 32, 2000 keys, 512 workgroups:
     // 81 vs 97 us); its self attention (600 keys) and the B=32 face self attention stay x0.9
     const int S3 = p.S_main + p.S_tail;
-    const bool wins = p.Tq >= 160 && ((c->DH == 64 && (S3 >= 1024 || wgs <= 256)) || (c->DH == 32 && S3 >= 1024));
+    // ... and NOT below one attn_kernel workgroup per CU (profiles/r06_attn3_small_batch.txt: up to 6 sequences of 600 frames attn_kernel's 128-query workgroups
+    // are one round of <= 240 and finish in 32-36 us (cross) / 13-14 us (self) where attn3's 320-query workgroups take their fixed 41-44 / 19 us: x0.7-0.8;
+    // from 8 sequences on attn_kernel needs a second round and attn3 leads x1.18 / x1.02)
+    const int64_t wgs1 = (int64_t)p.nq * c->H * nseq;   // attn_kernel's grid
+    const bool wins = p.Tq >= 160 && wgs1 > 256 && ((c->DH == 64 && (S3 >= 1024 || wgs <= 256)) || (c->DH == 32 && S3 >= 1024));
     if (c->opt.attn3 >= 2 || wins) {
       p.nq = nq3;
       dim3 grid3((unsigned)wgs);

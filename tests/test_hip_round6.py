@@ -242,17 +242,18 @@ def test_attn3_kernel_vs_fp64_and_vs_attn_kernel(dev, fmt, precision, monkeypatc
 
 @pytest.mark.parametrize("precision", ["fp16", "bf16"])
 def test_guided_forward_with_attn3_matches_attn_kernel_path(dev, precision, monkeypatch):
-    """A whole guided forward of the face model (B = 2, T = 600: cached K/V slots, the shared unconditional slot, the two time tokens
-    patched into the LAST, PARTIAL key tile) with attn3_kernel on (the default rule picks it for self and cross attention: 16 launches
-    asserted) and off: the two paths must agree to the 16-bit operand rounding (they are not bit-identical, see above)."""
+    """A whole guided forward of the face model (B = 4, T = 600: cached K/V slots, the shared unconditional slot, the two time tokens
+    patched into the LAST, PARTIAL key tile) with attn3_kernel on (the default rule picks it for self and cross attention from 8 sequences
+    on -- below, attn_kernel's 128-query workgroups are one round and faster, profiles/r06_attn3_small_batch.txt: 15 launches asserted at
+    B = 4 -- layer 0's self attention runs on the 4 shared sequences --, none at B = 2) and off: the two paths must agree to the 16-bit operand rounding (they are not bit-identical, see above)."""
     spec = face_spec()
-    B, T = 2, 600
+    B, T = 4, 600
     inp = synthetic_inputs(spec, B, T, SEED)
     model, _ = create_model_and_diffusion(default_args("face"), "test", precision=precision, max_batch=B)
     load_model(model, synthetic_state_dict(spec, SEED))
     cfg = ClassifierFreeSampleModel(model.to(dev).eval())
     y = {"cond_embed": inp["cond_embed"].to(dev), "scale": torch.full((B,), 10.0, device=dev)}
-    t = torch.tensor([901, 33], device=dev)
+    t = torch.tensor([901, 33, 500, 7], device=dev)
     outs, launches = {}, {}
     for mode in ("0", "1"):
         monkeypatch.setenv("A2P_ATTN3", mode)
@@ -265,8 +266,16 @@ def test_guided_forward_with_attn3_matches_attn_kernel_path(dev, precision, monk
     model.release()
     e = rel_l2(outs["1"], outs["0"])
     record(f"attn3/guided_forward/{precision}", vs_attn_kernel_path=e, launches=launches["1"])
-    assert launches == {"0": 0, "1": 16}, launches      # 8 layers x (self + cross); layer 0's shared-half trick keeps one launch per attention
+    assert launches == {"0": 0, "1": 15}, launches      # 8 layers x (self + cross) minus layer 0's self attention: the shared-half trick runs it on 4 sequences (attn_kernel's round)
     assert e < (6e-4 if precision == "fp16" else 5e-3), e
+    # the rule at B = 2 (4 sequences: attn_kernel's grid of 160 workgroups is one round): no attn3 launch by default
+    model2, _ = create_model_and_diffusion(default_args("face"), "test", precision=precision, max_batch=2)
+    load_model(model2, synthetic_state_dict(spec, SEED))
+    cfg2 = ClassifierFreeSampleModel(model2.to(dev).eval())
+    y2 = {"cond_embed": inp["cond_embed"][:2].to(dev), "scale": torch.full((2,), 10.0, device=dev)}
+    cfg2(inp["x_T"][:2].to(dev), t[:2], y2)
+    assert _debug_i64(model2, b"attn3_launches") == 0
+    model2.release()
 
 
 # ----------------------------------------------------------------------------- the FULL chains of configs[1] and configs[2] against the REFERENCE's own chains
