@@ -625,10 +625,19 @@ __device__ __forceinline__ void chain4_body(const ChainP& p, h16_t* const smem, 
       return;
     }
     // next layer's PRE work: norm1 -> rotary -> [Q|K] ; norm1 -> V^T     (aux: bias_qk right behind bias_1, then bias_v)
+    // Parked kernels: the finished rows leave HERE, in front of the LayerNorm, not behind it (their registers are free during the [Q|K] GEMM either way).
+    // Every store sits in front of the weight ring's next loads in the in-order vmcnt queue, and this one is 2 KiB per row from every workgroup at once:
+    // behind the LayerNorm its acknowledgement was exposed at the start of the [Q|K] GEMM (80 rows, B=32: that phase took 28-30 us against 12 us of
+    // weight stream); here it drains during the two LayerNorm barriers and the panel rewrite, when the ring is full and nothing waits on it.
+    // (The rows are overwritten in the layout they were parked in, lane for lane; a row-major successor layout -- A2P_CHAIN_X_ROWMAJOR, A/B only --
+    // puts other lanes' parked bytes under the store: barrier first.)
+    if constexpr (PARK) {
+      if (!p.x_out_tiled) chain_bar();
+      store_x(R, p.x_out_tiled);
+    }
     ln_stats(R);
     ln_write(R, E4_LNB_G, Tt);
     stamp(8);
-    if constexpr (PARK) store_x(R, p.x_out_tiled);   // the finished rows; their registers are free during the [Q|K] GEMM
     __builtin_amdgcn_sched_barrier(0);
     stamp(9);
     gemm_store(std::integral_constant<int, 2>{}, aux + FT * 128, p.qk_out, p.ld_qk, F);
