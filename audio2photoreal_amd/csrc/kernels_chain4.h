@@ -529,6 +529,12 @@ __device__ __forceinline__ void chain4_body(const ChainP& p, h16_t* const smem, 
   stamp(2);
   film_res(R, E4_BIAS_O, E4_FILM_O, p.xsrc ? p.xsrc : p.x, p.x_in_tiled, true);
   stamp(3);
+  // POST kernels that park their rows around the feed-forward block: the store leaves here, in front of the LayerNorm (see the second park below for why)
+  constexpr bool PARK_FFN = MODE == CHAIN_POST && (MT >= 4 || CHAIN4_PARK3);
+  if constexpr (PARK_FFN) {
+    if (!p.x_in_tiled) chain_bar();   // (parked in the tiled layout: with a row-major predecessor layout -- A/B only -- other lanes' unread bytes lie under the store)
+    store_x(R, 1);
+  }
   ln_stats(R);   // (its barriers also order the panel rewrite behind every wave's out_proj reads)
   stamp(4);
   if constexpr (MODE == CHAIN_MID) {
@@ -547,9 +553,7 @@ __device__ __forceinline__ void chain4_body(const ChainP& p, h16_t* const smem, 
     [[maybe_unused]] f32x4 X[PARK ? 1 : NT][PARK ? 1 : MT];
     // (parked in the tiled layout whatever the final layout is: a 16-row block occupies the same bytes in both, and the workgroup owns
     // whole blocks -- the last layer writes its rows back row-major)
-    if constexpr (PARK) {
-      store_x(R, 1);
-    } else {
+    if constexpr (!PARK) {   // (PARK: stored in front of the LayerNorm, above)
 #pragma unroll
       for (int t = 0; t < NT; ++t)
 #pragma unroll
