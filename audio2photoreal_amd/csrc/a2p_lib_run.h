@@ -156,13 +156,17 @@ static void pk4_gemm(std::vector<ChainPackDesc>& v, const void* W, int ldw, int 
       for (int t = t0; t < t0 + group && t < nt; ++t)
         v.push_back({reinterpret_cast<const h16_t*>(W), ldw, (tile0 + t) * 128, k0 + kc * 32, nrows, omap});
 }
-static int chain4_pack(a2p_ctx* c, Buf& st, const std::vector<ChainPackDesc>& descs, hipStream_t s) {
+// descs_e: the order in which waves 0-3 consume the stream where it differs from descs (waves 4-7): the pipelined feed-forward block of the POST kernels
+static int chain4_pack(a2p_ctx* c, Buf& st, const std::vector<ChainPackDesc>& descs, hipStream_t s, const std::vector<ChainPackDesc>* descs_e = nullptr) {
   const size_t pad = 2 * CHAIN_STREAM_PAD;   // the register ring runs CHAIN4_PF half stages past the end
+  const size_t n = descs.size();
+  ARG(!descs_e || descs_e->size() == n, "chain4_pack: the two consumption orders differ in length");
   Buf dd;
-  CHK(buf_alloc_tmp(dd, descs.size() * sizeof(ChainPackDesc)));
-  HIPCHK(hipMemcpyAsync(dd.p, descs.data(), descs.size() * sizeof(ChainPackDesc), hipMemcpyHostToDevice, s));
-  CHK(buf_alloc(st, (descs.size() + pad) * CHAIN4_HS_ELEMS * 2));
-  chain4_pack_kernel<<<(int)descs.size(), 256, 0, s>>>(reinterpret_cast<const ChainPackDesc*>(dd.p), reinterpret_cast<h16_t*>(st.p));
+  CHK(buf_alloc_tmp(dd, 2 * n * sizeof(ChainPackDesc)));
+  HIPCHK(hipMemcpyAsync(dd.p, descs.data(), n * sizeof(ChainPackDesc), hipMemcpyHostToDevice, s));
+  HIPCHK(hipMemcpyAsync(static_cast<char*>(dd.p) + n * sizeof(ChainPackDesc), (descs_e ? descs_e : &descs)->data(), n * sizeof(ChainPackDesc), hipMemcpyHostToDevice, s));
+  CHK(buf_alloc(st, (n + pad) * CHAIN4_HS_ELEMS * 2));
+  chain4_pack_kernel<<<(int)n, 256, 0, s>>>(reinterpret_cast<const ChainPackDesc*>(dd.p), reinterpret_cast<h16_t*>(st.p), (int)n);
   HIPCHK(hipGetLastError());
   HIPCHK(hipStreamSynchronize(s));
   buf_free(dd);
@@ -226,19 +230,31 @@ static int chain_build_streams(a2p_ctx* c, hipStream_t s) {
       CHK(chain4_pack(c, c->ch_stream4[ch_index(l, CH_MID)], m4, s));
       if (l + 1 < L || c->tail32) {   // (the last layer too, unless final_layer is fused into its POST kernel: A2P_TAIL16)
         for (int hc = 128; hc <= 256; hc += 128) {   // hidden chunk of the feed-forward block: 128 (80-row panels) | 256 (<= 64 rows): Chain4Lds::HC
-          std::vector<ChainPackDesc> q4;
+          // two consumption orders of the feed-forward block (CHAIN4_FFN_PIPE, kernels_chain4.h): waves 4-7 (q4) linear1(h) linear2(h) per chunk; waves 0-3 (q4e)
+          // run their linear2 partial one chunk late: linear1(0) | linear1(1) linear2(0) | linear1(2) linear2(1) | ... | linear2(last)
+          std::vector<ChainPackDesc> q4, q4e;
           pk4_gemm(q4, c->wt.at(pf(l) + "multihead_attn.out_proj.weight").p, d, d, 0, d, 0, 4);
-          const int nh = hc / 128;
-          for (int h = 0; h < ff / hc; ++h) {
-            pk4_gemm(q4, w1.p, d, ff, 0, d, 0, nh, h * nh, nh);       // linear1, hidden columns [hc h, hc h + hc): nh tiles, k-chunk-major
-            pk4_gemm(q4, w2.p, ff, d, h * hc, hc, 0, 4);              // linear2 partial over that hidden chunk, 4 output tiles
+          q4e = q4;
+          const int nh = hc / 128, nc = ff / hc;
+          auto lin1_4 = [&](std::vector<ChainPackDesc>& v, int h) { pk4_gemm(v, w1.p, d, ff, 0, d, 0, nh, h * nh, nh); };   // linear1, hidden columns [hc h, hc h + hc): nh tiles, k-chunk-major
+          auto lin2_4 = [&](std::vector<ChainPackDesc>& v, int h) { pk4_gemm(v, w2.p, ff, d, h * hc, hc, 0, 4); };          // linear2 partial over that hidden chunk, 4 output tiles
+          for (int h = 0; h < nc; ++h) { lin1_4(q4, h); lin2_4(q4, h); }
+          if (CHAIN4_FFN_PIPE) {
+            for (int i = 0; i <= nc; ++i) {
+              if (i < nc) lin1_4(q4e, i);
+              if (i >= 1) lin2_4(q4e, i - 1);
+            }
+          } else {
+            for (int h = 0; h < nc; ++h) { lin1_4(q4e, h); lin2_4(q4e, h); }
           }
-          if (l + 1 < L) {
-            const Buf& inw = c->wt.at(pf(l + 1) + "self_attn.in_proj_weight");
-            pk4_gemm(q4, inw.p, d, 2 * d, 0, d, 1, 4);                  // [Q|K] of the next layer, in groups of four tiles
-            pk4_gemm(q4, c->offT(inw, (int64_t)2 * d * d), d, d, 0, d, 1, 4);   // V
+          for (std::vector<ChainPackDesc>* v : {&q4, &q4e}) {
+            if (l + 1 < L) {
+              const Buf& inw = c->wt.at(pf(l + 1) + "self_attn.in_proj_weight");
+              pk4_gemm(*v, inw.p, d, 2 * d, 0, d, 1, 4);                  // [Q|K] of the next layer, in groups of four tiles
+              pk4_gemm(*v, c->offT(inw, (int64_t)2 * d * d), d, d, 0, d, 1, 4);   // V
+            }
           }
-          CHK(chain4_pack(c, hc == 128 ? c->ch_stream4[ch_index(l, CH_POST)] : c->ch_stream4w[l], q4, s));
+          CHK(chain4_pack(c, hc == 128 ? c->ch_stream4[ch_index(l, CH_POST)] : c->ch_stream4w[l], q4, s, &q4e));
         }
       }
     }

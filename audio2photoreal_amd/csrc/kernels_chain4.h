@@ -49,20 +49,30 @@
 #endif
 #define CHAIN4_HS_ELEMS 4096   // 128 output columns x 32 k: 8 KiB
 
+#ifndef CHAIN4_FFN_PIPE
+#define CHAIN4_FFN_PIPE 1      // feed-forward block without workgroup barriers: per-chunk LDS counters, the two waves of a SIMD one phase apart (0: round-5 form, A/B)
+#endif
+
 template <int MT>
 struct Chain4Lds {
-  static constexpr int D = 512, BM = 16 * MT, AUX_F = 2560, EPI_F = 7168;
+  static constexpr int D = 512, BM = 16 * MT, AUX_F = 2560;
   // hidden chunk of the feed-forward block: 256 columns where the LDS has room (<= 64 rows), 128 at 80 rows.  256: linear1 computes
   // two hidden tiles per panel-fragment read (8 waves each read every panel row: with one tile the LDS port is linear1's roof) and the
-  // block has 8 workgroup barriers instead of 16.  The host packs the stream accordingly (a2p_lib_run.h: two POST streams).
+  // block has half the chunk hand-offs.  The host packs the stream accordingly (a2p_lib_run.h: two POST streams).
   static constexpr int HC = MT <= 4 ? 256 : 128;
-  // 16-bit elements: panelA [BM][512], panelH [BM][HC], LayerNorm partials [2][8][BM] fp32, aux [AUX_F] fp32, epilogue block [EPI_F] fp32
-  static constexpr int ELEMS = BM * D + BM * HC + 32 * BM + 2 * AUX_F + 2 * EPI_F;
+  // Epilogue block (fp32 offsets).  Operands that are dead once the feed-forward block starts come first: the SECOND hidden-chunk buffer
+  // (CHAIN4_FFN_PIPE) lies over the LayerNorm partials + those operands (+ PAD_F floats where that is not enough), so 80 rows still fit.
+  //   dead by the FFN: out_proj bias, norm-A gamma / beta, FiLM rows of the out_proj epilogue;  live: linear2 bias, norm-B gamma / beta, FiLM rows of the FFN epilogue
+  // (FiLM blocks: [sequence A: scale 512 | shift 512][sequence B: scale 512 | shift 512])
+  static constexpr int E_BIAS_O = 0, E_LNA_G = 512, E_LNA_B = 1024, E_FILM_O = 1536, E_DEAD_F = 3584;
+  static constexpr int RED_F = 16 * BM;                                               // LayerNorm partials [2][8][BM] fp32
+  static constexpr int PAD_F = (BM * HC) / 2 > RED_F + E_DEAD_F ? (BM * HC) / 2 - RED_F - E_DEAD_F : 0;
+  static constexpr int E_BIAS_2 = E_DEAD_F + PAD_F, E_LNB_G = E_BIAS_2 + 512, E_LNB_B = E_BIAS_2 + 1024, E_FILM_F = E_BIAS_2 + 1536, EPI_F = E_BIAS_2 + 3584;
+  static constexpr int FLAG_F = 32;                                                   // ready[16] | done[16] chunk counters
+  // 16-bit elements: panelA [BM][512], panelH [BM][HC], LayerNorm partials, epilogue block [EPI_F] fp32, aux [AUX_F] fp32, counters
+  static constexpr int ELEMS = BM * D + BM * HC + 2 * RED_F + 2 * EPI_F + 2 * AUX_F + 2 * FLAG_F;
   static_assert(ELEMS * 2 <= 160 * 1024, "panel too tall for the LDS");
 };
-// epilogue block (fp32 offsets)
-enum { E4_BIAS_O = 0, E4_BIAS_2 = 512, E4_LNA_G = 1024, E4_LNA_B = 1536, E4_LNB_G = 2048, E4_LNB_B = 2560, E4_FILM_O = 3072, E4_FILM_F = 5120 };
-// (FiLM blocks: [sequence A: scale 512 | shift 512][sequence B: scale 512 | shift 512])
 
 // compile-time loop (the LDS reads below carry their offsets as instruction immediates)
 template <class F, int... I>
@@ -90,11 +100,13 @@ __device__ __forceinline__ void chain4_lds_wait(h16x8 (&a)[MT]) {
 // one half stage of a packed stream: [wave 0..7][lane 0..63][8 k-values] -- lane (l15, g) of wave w gets
 // W[col(w, l15)][k0 + g*8 .. +8], the weight operand of v_mfma_f32_16x16x32 for this k-chunk.  Column ownership as chain_pack_kernel
 // with 8 waves (32-column group w >> 1, sub-tile w & 1, paired map for stored tiles).
-__global__ __launch_bounds__(256) void chain4_pack_kernel(const ChainPackDesc* __restrict__ descs, h16_t* __restrict__ dst) {
-  const ChainPackDesc d = descs[blockIdx.x];
+// descs: [2][n] -- half stage i of waves 4-7 is descs[i], of waves 0-3 descs[n + i] (the two wave groups of a pipelined feed-forward block consume their
+// linear1 / linear2 chunks in different orders; everywhere else the two entries are equal)
+__global__ __launch_bounds__(256) void chain4_pack_kernel(const ChainPackDesc* __restrict__ descs, h16_t* __restrict__ dst, int n) {
   uint4* out = reinterpret_cast<uint4*>(dst + (int64_t)blockIdx.x * CHAIN4_HS_ELEMS);
   for (int q = threadIdx.x; q < 512; q += 256) {
     const int w = q >> 6, lane = q & 63, i = lane & 15, g = lane >> 4;
+    const ChainPackDesc d = descs[(w < 4 ? n : 0) + blockIdx.x];
     const int w4 = w >> 1, J = w & 1, tile = d.row0 >> 7;
     const int row = d.omap ? (tile >> 1) * 256 + w4 * 64 + J * 32 + (tile & 1) * 16 + i : d.row0 + w4 * 32 + (i >> 2) * 8 + J * 4 + (i & 3);
     uint4 v = make_uint4(0, 0, 0, 0);
@@ -106,18 +118,22 @@ __global__ __launch_bounds__(256) void chain4_pack_kernel(const ChainPackDesc* _
 template <int MT, int MODE, bool LAST>
 __device__ __forceinline__ void chain4_body(const ChainP& p, h16_t* const smem, const int m0) {
   constexpr int D = 512, NW = 8, CW = 16, BM = 16 * MT, NT = 4, KC = D / 32, FT = 8, HLD = Chain4Lds<MT>::HC, NH = HLD / 128, PF = (MODE == CHAIN_MID && MT == 3) ? CHAIN4_PF_MID : (MODE == CHAIN_POST && MT == 3) ? CHAIN4_PF_POST3 : CHAIN4_PF;
-  constexpr int AUX_F = Chain4Lds<MT>::AUX_F;
+  using LY = Chain4Lds<MT>;
+  constexpr int AUX_F = LY::AUX_F;
+  constexpr int E4_BIAS_O = LY::E_BIAS_O, E4_BIAS_2 = LY::E_BIAS_2, E4_LNA_G = LY::E_LNA_G, E4_LNB_G = LY::E_LNB_G, E4_FILM_O = LY::E_FILM_O, E4_FILM_F = LY::E_FILM_F;
   h16_t* const panelA = smem;
   h16_t* const panelH = panelA + BM * D;
   float* const red = reinterpret_cast<float*>(panelH + BM * HLD);   // [2][8][BM] LayerNorm partial sums, one per wave
-  float* const aux = red + 16 * BM;                                   // [AUX_F] per-tile biases of the stored / FFN GEMMs
-  float* const epi = aux + AUX_F;                                     // [EPI_F] epilogue operands (E4_*)
+  float* const epi = red + LY::RED_F;                                 // [EPI_F] epilogue operands (Chain4Lds::E_*)
+  float* const aux = epi + LY::EPI_F;                                 // [AUX_F] per-tile biases of the stored / FFN GEMMs
+  uint32_t* const flags = reinterpret_cast<uint32_t*>(aux + AUX_F);   // [2][16] chunk counters of the feed-forward block (CHAIN4_FFN_PIPE)
+  h16_t* const panelH1 = reinterpret_cast<h16_t*>(red);               // second hidden-chunk buffer: over red + the epilogue operands that are dead by then
   const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6), l15 = lane & 15, g = lane >> 4;
   const int W4 = wid >> 1, J0 = wid & 1;
-#ifdef A2P_STAMPS   // diagnostic build (scratch/phase_probe4.py): 100 MHz phase stamps of workgroups 0 and 101 into p.fin_out
+#ifdef A2P_STAMPS   // diagnostic build (scratch/phase_probe4.py): 100 MHz phase stamps into p.fin_out: workgroups 0 and 101, or (A2P_STAMPS == 2) waves 0 and 4 of workgroup 0 (one SIMD)
   auto stamp = [&](int i) __attribute__((always_inline)) {
-    if (tid == 0 && (blockIdx.x == 0 || blockIdx.x == 101)) {
-      unsigned long long* o = reinterpret_cast<unsigned long long*>(p.fin_out) + (blockIdx.x ? 32 : 0);
+    if (A2P_STAMPS == 2 ? ((tid == 0 || tid == 256) && blockIdx.x == 0) : (tid == 0 && (blockIdx.x == 0 || blockIdx.x == 101))) {
+      unsigned long long* o = reinterpret_cast<unsigned long long*>(p.fin_out) + ((A2P_STAMPS == 2 ? tid : blockIdx.x) ? 32 : 0);
       o[i] = wall_clock64();
       if (i == 0) o[30] = __builtin_readcyclecounter();   // shader cycles at the first / the latest stamp: the EFFECTIVE clock of the launch
       o[31] = __builtin_readcyclecounter();
@@ -272,6 +288,7 @@ __device__ __forceinline__ void chain4_body(const ChainP& p, h16_t* const smem, 
                                        (__attribute__((address_space(3))) void*)(panelA + r0 * D), 16, 0, 0);
     }
     for (int kb = wid; kb < p.aux_kb; kb += NW) chain_glds16(p.aux + kb * 256 + lane * 4, aux + kb * 256);
+    if (tid < LY::FLAG_F) flags[tid] = 0u;
     // epilogue block: 28 pieces of 1 KiB (256 floats); piece q -> source pointer + destination offset
     const int nseq = p.M / p.rows_per_seq;
     const int seqB = seqA + 1 < nseq ? seqA + 1 : seqA;
@@ -283,7 +300,7 @@ __device__ __forceinline__ void chain4_body(const ChainP& p, h16_t* const smem, 
         const float* base = v == 0 ? p.bias_o : v == 1 ? p.bias_2 : v == 2 ? p.lnA_g : v == 3 ? p.lnA_b : v == 4 ? p.lnB_g : p.lnB_b;
         if (base == nullptr) base = p.bias_o;   // (MID: no bias_2 / lnB: never read)
         src = base + h * 256;
-        dst = v * 512 + h * 256;
+        dst = (v == 0 ? E4_BIAS_O : v == 1 ? E4_BIAS_2 : v == 2 ? E4_LNA_G : v == 3 ? E4_LNA_G + 512 : v == 4 ? E4_LNB_G : E4_LNB_G + 512) + h * 256;
       } else {        // FiLM rows: (film_o | film_f) x (sequence A | B) x (scale | shift) x 2 pieces
         const int r = q - 12, set = r >> 3, sq = (r >> 2) & 1, part = (r >> 1) & 1, h = r & 1;
         const float* film = set == 0 ? p.film_o : (p.film_f ? p.film_f : p.film_o);
@@ -567,6 +584,77 @@ __device__ __forceinline__ void chain4_body(const ChainP& p, h16_t* const smem, 
     for (int t = 0; t < NT; ++t)
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt) R[t][mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#if CHAIN4_FFN_PIPE
+    // No workgroup barrier inside the block.  Per hidden chunk two LDS counters: ready[c] = waves whose GELU'd columns of chunk c are in the buffer,
+    // done[c] = waves that have read chunk c for their linear2 partial.  Two chunk buffers (c & 1).  The waves w and w + 4 share a SIMD; waves 0-3 run
+    // their linear2 partial ONE CHUNK LATE (linear1(c+1) -> GELU(c+1) -> linear2(c)), waves 4-7 in the natural order (linear1(c) -> GELU(c) -> linear2(c)):
+    // after the first chunk one wave of every SIMD is in its GELU (vector unit) while the other issues MFMAs, instead of all eight computing the GELU
+    // between two barriers with the matrix pipe idle (round 5: 1.6-2.9 us per chunk of 256 at 48 rows, 19 of 48 us of the block at 80 rows).  Same products,
+    // same accumulation order (chunks 0, 1, 2 .. into R): bit-identical.  The weight stream is packed per wave group in ITS consumption order (a2p_lib_run.h).
+    {
+      constexpr int NC = FT / NH;
+      const int skew = wid < 4 ? 1 : 0;
+      const uint32_t fl = lds_off(flags);
+      auto arrive = [&](uint32_t byte_off) __attribute__((always_inline)) {   // this wave's LDS traffic so far is complete; count it
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (lane == 0) asm volatile("ds_add_u32 %0, %1" ::"v"(fl + byte_off), "v"(1u) : "memory");
+      };
+      auto wait_all = [&](uint32_t byte_off) __attribute__((always_inline)) {   // until all eight waves have counted
+        uint32_t seen;
+        asm volatile(
+            ".Lc4w_%=:\n\t"
+            "ds_read_b32 %0, %1\n\t"
+            "s_waitcnt lgkmcnt(0)\n\t"
+            "v_cmp_gt_u32 vcc, 8, %0\n\t"
+            "s_cbranch_vccz .Lc4d_%=\n\t"
+            "s_sleep 1\n\t"
+            "s_branch .Lc4w_%=\n\t"
+            ".Lc4d_%=:"
+            : "=&v"(seen)
+            : "v"(fl + byte_off)
+            : "vcc", "memory");
+      };
+#pragma unroll
+      for (int i = 0; i <= NC; ++i) {
+        if (i < NC) {
+          f32x4 acc[NH][MT];
+#pragma unroll
+          for (int tt = 0; tt < NH; ++tt) {
+            const f32x4 b = *reinterpret_cast<const f32x4*>(aux + (i * NH + tt) * 128 + W4 * 32 + g * 8 + J0 * 4);
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) acc[tt][mt] = b;
+          }
+          __builtin_amdgcn_sched_barrier(0);
+          gemm(std::integral_constant<int, NH>{}, std::integral_constant<int, KC>{}, std::integral_constant<int, D>{}, acc, panelA, false);
+          __builtin_amdgcn_sched_barrier(0);
+          if (13 + 3 * i < 28) stamp(13 + 3 * i);       // (stamped builds: linear1 of this hidden chunk done)
+          if (i >= 2) wait_all(64u + 4u * (i - 2));   // every wave has read chunk i - 2: its buffer is free
+          h16_t* const Hw = (i & 1) ? panelH1 : panelH;
+#pragma unroll
+          for (int tt = 0; tt < NH; ++tt)
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+              const f32x4 v = acc[tt][mt];
+              *reinterpret_cast<h16x4*>(Hw + (mt * 16 + l15) * HLD + tt * 128 + pswz) =
+                  h16x4{(h16_t)act_gelu_fast(v[0]), (h16_t)act_gelu_fast(v[1]), (h16_t)act_gelu_fast(v[2]), (h16_t)act_gelu_fast(v[3])};
+            }
+          arrive(4u * i);
+          if (14 + 3 * i < 29) stamp(14 + 3 * i);       // (GELU written and counted)
+        }
+        const bool do2 = i == 0 ? skew == 0 : i == NC ? skew == 1 : true;
+        if (do2) {
+          const int c = i - skew;
+          wait_all(4u * c);                             // the hidden chunk is complete
+          __builtin_amdgcn_sched_barrier(0);
+          gemm(std::integral_constant<int, NT>{}, std::integral_constant<int, HLD / 32>{}, std::integral_constant<int, HLD>{}, R, (c & 1) ? panelH1 : panelH, false);
+          __builtin_amdgcn_sched_barrier(0);
+          arrive(64u + 4u * c);
+        }
+        if (i < NC && 15 + 3 * i < 30) stamp(15 + 3 * i);     // (linear2 partial of chunk i - skew, where this wave has one in this round)
+      }
+      wait_all(64u + 4u * (NC - 1));   // the second chunk buffer lies over the LayerNorm partials: nobody reads it any more
+    }
+#else
 #pragma unroll
     for (int h = 0; h < FT / NH; ++h) {
       f32x4 acc[NH][MT];
@@ -596,6 +684,7 @@ __device__ __forceinline__ void chain4_body(const ChainP& p, h16_t* const smem, 
       __builtin_amdgcn_sched_barrier(0);
       if (15 + 3 * h < 30) stamp(15 + 3 * h);       // (linear2 partial)
     }
+#endif
     stamp(6);
     if constexpr (PARK) {
       // the parked rows come back from where store_x left them (same workgroup, same lanes: program order makes them visible)
