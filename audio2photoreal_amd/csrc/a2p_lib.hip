@@ -170,6 +170,7 @@ struct A2POpts {
   int attn2 = 0;            // A2P_ATTN2=1: the query-split 16-bit attention launches take attn2_kernel (kernels_attn2.h: one 8-wave workgroup per CU,
                             // 48 + 32 queries per SIMD, unit-level software pipeline); 0: attn_kernel
   int no_fused_kf = 0;      // A2P_NO_FUSED_KF=1: body model: MID2 | keyframe attention | POST as three launches instead of one (A/B, tests)
+  int no_fused_final = 0;   // A2P_NO_FUSED_FINAL=1: face model: final_layer behind the last tall POST kernel as split3_kernel + gemm_kernel instead of inside it (A/B, tests)
   int graph = 0;            // A2P_GRAPH=1: non-chain forwards replay a captured graph instead of stream launches (measured: same GPU
                             // time per step -- the launches are not host-bound -- at a tenth of the host time; off by default)
   int no_small = 0;         // A2P_NO_SMALL=1: per-op kernels for forwards below 960 rows instead of kernels_small.h
@@ -187,7 +188,7 @@ static void load_opts(A2POpts& o) {
   o.side_early_join = flag("A2P_SIDE_EARLY_JOIN"); o.no_shared_half = flag("A2P_NO_SHARED_HALF");
   o.graph = flag("A2P_GRAPH");
   o.no_ksplit = flag("A2P_NO_KSPLIT"); o.force_ksplit = flag("A2P_ATTN_KSPLIT"); o.ksplit_nw = num("A2P_KSPLIT_NW", 0); o.ksplit_qt = num("A2P_KSPLIT_QT", 0);
-  o.no_fused_kf = flag("A2P_NO_FUSED_KF"); o.attn2 = num("A2P_ATTN2", 0); o.attn3 = num("A2P_ATTN3", 1); o.chain_v = num("A2P_CHAIN_V", 0);
+  o.no_fused_kf = flag("A2P_NO_FUSED_KF"); o.no_fused_final = flag("A2P_NO_FUSED_FINAL"); o.attn2 = num("A2P_ATTN2", 0); o.attn3 = num("A2P_ATTN3", 1); o.chain_v = num("A2P_CHAIN_V", 0);
   o.no_small = flag("A2P_NO_SMALL"); o.chain_rows = num("A2P_CHAIN_ROWS", 1100);
 }
 
@@ -222,6 +223,7 @@ struct a2p_ctx {
   bool tail_fused = false;
   int64_t attn3_launches = 0;          // launches of attn3_kernel (a2p_debug_read "attn3_launches")
   int64_t ch4_launches = 0;            // launches of the tall chain kernels (a2p_debug_read "chain4_launches")
+  int64_t fin_fused_launches = 0;      // ... of those, last-layer POST kernels that computed final_layer too (a2p_debug_read "final_fused_launches")
   std::vector<Buf> ch_stream4w;        // POST streams with 256-column hidden chunks [layer]
   std::vector<Buf> ch_stream4;         // kernels_chain4.h: half-stage streams [layer*5 + kind] (CH_MID, CH_POST of the face model; empty Buf otherwise)
   std::vector<Buf> ch_stream, ch_aux;  // packed weight streams [layout * L*5 + layer*5 + kind] (layout 0: 4-wave LDS slices, 1: 8-wave; kinds: a2p_lib_run.h CH_*) / bias blocks [layer*5 + kind]

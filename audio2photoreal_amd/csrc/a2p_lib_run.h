@@ -221,6 +221,8 @@ static int chain_build_streams(a2p_ctx* c, hipStream_t s) {
     } else if (!c->pose && !c->tail32) {  // A2P_TAIL16: final_layer of the face model rides on the last stream (16-bit operands)
       pk_gemm(q, c->wt.at("final_layer.weight").p, d, c->C, d);
       aux.push_back({W32(c, "final_layer.bias"), c->C});
+    } else if (!c->pose && c->tail_x3) {  // the tall last-layer POST kernel computes final_layer as a split-operand island (ChainP::fin_x3): its bias behind bias_1
+      aux.push_back({W32(c, "final_layer.bias"), c->C});
     }
     CHK(chain_pack(c, ch_index(l, CH_POST), q, aux, s));
     if (v4) {   // the same chains for kernels_chain4.h (MID; POST of every layer that has a successor)
@@ -252,6 +254,13 @@ static int chain_build_streams(a2p_ctx* c, hipStream_t s) {
               const Buf& inw = c->wt.at(pf(l + 1) + "self_attn.in_proj_weight");
               pk4_gemm(*v, inw.p, d, 2 * d, 0, d, 1, 4);                  // [Q|K] of the next layer, in groups of four tiles
               pk4_gemm(*v, c->offT(inw, (int64_t)2 * d * d), d, d, 0, d, 1, 4);   // V
+            } else if (hc == 256 && c->tail_x3 && !c->pose && c->C == 256) {
+              // final_layer as a split-operand island inside the last POST kernel (chain4_kernel<.., 2>): the split weight rows are [W_hi | W_hi | W_lo] (make_wt3),
+              // consumed as hi x W_hi, lo x W_hi, hi x W_lo: three 256 x 512 GEMMs in pairs of tiles
+              const void* wf = c->wt.at("final_layer.weight").p;
+              pk4_gemm(*v, wf, 3 * d, c->C, 0, d, 0, 2);
+              pk4_gemm(*v, wf, 3 * d, c->C, 0, d, 0, 2);
+              pk4_gemm(*v, wf, 3 * d, c->C, 2 * d, d, 0, 2);
             }
           }
           CHK(chain4_pack(c, hc == 128 ? c->ch_stream4[ch_index(l, CH_POST)] : c->ch_stream4w[l], q4, s, &q4e));
@@ -418,28 +427,47 @@ static bool chain4_wanted(const a2p_ctx* c, int mode, const ChainP& p) {
   if ((p.rows_per_seq & 7) || p.rows_per_seq < 80) return false;
   return (mode == CHAIN_MID ? c->ch_fam_mid : c->ch_fam_post) == 4;   // the family of this forward's chain (chain_pick_family: forced, or measured on this box)
 }
-static int launch_chain4(a2p_ctx* c, int mode, const ChainP& p0, hipStream_t s) {
-  ChainP p = p0;
+static int chain4_pick_mt(const a2p_ctx* c, int M) {
   int mt = c->opt.chain_mt;
   if (mt < 3 || mt > 5) {   // fewest rounds over the 256 CUs, then the shorter panel
     int best = 1 << 30;
     for (int m = 3; m <= 5; ++m) {
-      const int blocks = (p.M + 16 * m - 1) / (16 * m);
+      const int blocks = (M + 16 * m - 1) / (16 * m);
       const int cost = ((blocks + 255) / 256) * (16 + 4 * m);
       if (cost < best) { best = cost; mt = m; }
     }
   }
+  return mt;
+}
+// final_layer inside the last layer's POST kernel (chain4_kernel<MT, CHAIN_POST, 2>): tall family, <= 64-row panels (the lo panel takes both 256-wide chunk buffers),
+// split-operand islands (the default), 256 output features.  The diagnostic build keeps its stamps in ChainP::fin_out.
+static bool chain4_final_fused(const a2p_ctx* c, int mode, const ChainP& p) {
+#ifdef A2P_STAMPS
+  return false;
+#else
+  return mode == CHAIN_POST && p.has_next == 0 && p.fin_x3 && c->tail_x3 && !c->pose && c->C == 256 && !c->opt.no_fused_final && chain4_wanted(c, mode, p) &&
+         chain4_pick_mt(c, p.M) <= 4;
+#endif
+}
+static int launch_chain4(a2p_ctx* c, int mode, const ChainP& p0, hipStream_t s) {
+  ChainP p = p0;
+  const int mt = chain4_pick_mt(c, p.M);
+  const bool fin = chain4_final_fused(c, mode, p);
   p.stream = (mode == CHAIN_POST && mt <= 4) ? p.stream4w : p.stream4;   // POST: the stream of the panel height's hidden-chunk width (Chain4Lds::HC)
   const int grid = (p.M + 16 * mt - 1) / (16 * mt);
   ++c->ch4_launches;
+  if (fin) ++c->fin_fused_launches;
   KernelTimer kt(c, A2P_KERNEL_CHAIN, mode == CHAIN_MID ? A2P_KERNEL_CHAIN_MID : A2P_KERNEL_CHAIN_POST);
 #define A2P_CHAIN4(MT)                                                                          \
   do {                                                                                          \
     if (mode == CHAIN_MID) A2P_LAUNCH(kt, (chain4_kernel<MT, CHAIN_MID>), grid, 512, s, p);     \
     else if (p.has_next) A2P_LAUNCH(kt, (chain4_kernel<MT, CHAIN_POST>), grid, 512, s, p);      \
-    else A2P_LAUNCH(kt, (chain4_kernel<MT, CHAIN_POST, true>), grid, 512, s, p);                \
+    else A2P_LAUNCH(kt, (chain4_kernel<MT, CHAIN_POST, 1>), grid, 512, s, p);                   \
   } while (0)
-  if (mt == 3) A2P_CHAIN4(3);
+  if (fin) {
+    if (mt == 3) A2P_LAUNCH(kt, (chain4_kernel<3, CHAIN_POST, 2>), grid, 512, s, p);
+    else A2P_LAUNCH(kt, (chain4_kernel<4, CHAIN_POST, 2>), grid, 512, s, p);
+  } else if (mt == 3) A2P_CHAIN4(3);
   else if (mt == 4) A2P_CHAIN4(4);
   else A2P_CHAIN4(5);
 #undef A2P_CHAIN4
@@ -590,7 +618,7 @@ static int launch_cross_attention(a2p_ctx* c, int N, int T, const CrossKV& kv, h
 // kernel of the second half reads the first half's rows (ChainP::src_rows)
 static int decoder_layer_chain(a2p_ctx* c, int l, int N, int T, const CrossKV& kv, const CrossKV* kv2, const FilmRef& fr, bool first,
                                bool has_next, hipStream_t s, hipEvent_t film_ready = nullptr, bool fuse_final = false,
-                               bool shared_half = false) {
+                               bool shared_half = false, bool* fused_x3 = nullptr) {
   const int d = c->d;
   const std::string pf = "seqTransDecoder.stack." + std::to_string(l) + ".";
   ChainP p;
@@ -665,6 +693,12 @@ static int decoder_layer_chain(a2p_ctx* c, int l, int N, int T, const CrossKV& k
   if (!has_next && fuse_final) {  // model output rows straight from the last POST kernel (c->x is NOT updated)
     p.has_next = 2; p.fin_out = c->mo.f(); p.ld_fin = c->C; p.fin_n = c->C;
     p.aux_kb = (c->ff + c->C + 255) / 256;
+  }
+  if (!has_next && fused_x3 && !fuse_kf && !fuse_final) {   // the caller wants the MODEL OUTPUT: the tall last-layer kernel computes final_layer too where it can (c->x is NOT updated then)
+    p.fin_x3 = 1; p.fin_out = c->mo.f(); p.ld_fin = c->C; p.fin_n = c->C;
+    p.aux_kb = (c->ff + c->C + 255) / 256;
+    *fused_x3 = chain4_final_fused(c, CHAIN_POST, p);
+    if (!*fused_x3) { p.fin_x3 = 0; p.fin_out = nullptr; p.aux_kb = (c->ff + 255) / 256; }
   }
   return launch_chain(c, fuse_kf ? CHAIN_MIDPOST : CHAIN_POST, p, s);
 }
@@ -964,6 +998,7 @@ static int forward_body(a2p_ctx* c, const float* x_in, const int64_t* t_orig, in
     if (tune0) HIPCHK(hipEventRecord(tune0, s));
   }
   CrossKV kv, kv2;
+  bool fused_x3 = false;
   for (int l = 0; l < L; ++l) {
     kv.K = c->offT(c->kc, (int64_t)l * d); kv.k_slot_stride = (int64_t)c->Sld * L * d; kv.ldk = (int64_t)L * d;
     kv.VT = c->offT(c->vtc, (int64_t)l * d * c->Sld); kv.vt_slot_stride = (int64_t)L * d * c->Sld; kv.ldvt = c->Sld;
@@ -982,13 +1017,14 @@ static int forward_body(a2p_ctx* c, const float* x_in, const int64_t* t_orig, in
     fr.seq_stride = (int64_t)L * F * 2 * d;
     if (use_chain)
       CHK(decoder_layer_chain(c, l, N, T, kv, c->pose ? &kv2 : nullptr, fr, l == 0, l + 1 < L, s, (overlap_tpath && l == 0) ? c->ev_join : nullptr,
-                              /*fuse_final=*/!c->pose && !c->tail32, /*shared_half=*/l == 0 && N == 2 * B && !c->opt.no_shared_half));
+                              /*fuse_final=*/!c->pose && !c->tail32, /*shared_half=*/l == 0 && N == 2 * B && !c->opt.no_shared_half, &fused_x3));
     else if (use_small) CHK(decoder_layer_small(c, l, N, T, kv, fr, s, (overlap_tpath && l == 0) ? c->ev_join : nullptr));
     else CHK(decoder_layer(c, l, N, T, kv, c->pose ? &kv2 : nullptr, fr, s));
   }
-  if (tune1) HIPCHK(hipEventRecord(tune1, s));
-  // final_layer (model/diffusion.py:397)   (A2P_TAIL16 + face + chain mode: already done by the last POST kernel)
-  if (use_chain && !c->pose && !c->tail32) {
+  // (the family calibration times the decoder stack INCLUDING final_layer: the tall last-layer kernel may contain it)
+  struct TuneEnd { hipEvent_t e; hipStream_t s; ~TuneEnd() { if (e) (void)hipEventRecord(e, s); } } tune_end{tune1, s};
+  // final_layer (model/diffusion.py:397)   (A2P_TAIL16 + face + chain mode, or the tall last-layer kernel's split-operand island: already done by the last POST kernel)
+  if (use_chain && !c->pose && (!c->tail32 || fused_x3)) {
     *mo_seq_rows = T;
     return 0;
   }
@@ -1433,6 +1469,11 @@ extern "C" int a2p_debug_read(a2p_ctx* c, const char* name, void* host, int64_t 
   if (n == "attn3_launches") {   // int64: launches of attn3_kernel (kernels_attn3.h) on this context so far (tests, bench)
     ARG(bytes >= 8, "attn3_launches is one int64");
     *reinterpret_cast<int64_t*>(host) = c->attn3_launches;
+    return 0;
+  }
+  if (n == "final_fused_launches") {   // int64: last-layer tall POST kernels that computed final_layer as a split-operand island (tests)
+    ARG(bytes >= 8, "final_fused_launches is one int64");
+    *reinterpret_cast<int64_t*>(host) = c->fin_fused_launches;
     return 0;
   }
   if (n == "chain4_launches") {   // int64: launches of the tall chain kernels (kernels_chain4.h) on this context so far (tests, bench)

@@ -126,6 +126,7 @@ struct ChainP {
   float* fin_out;
   int64_t ld_fin;
   int fin_n;
+  int fin_x3;             // kernels_chain4.h, last layer, <= 64 rows: final_layer as a split-operand exact island (stream: [W_hi | W_hi | W_lo]) into fin_out [m][ld_fin]; bias in aux after bias_1
   // diagnostic (A2P_CHAIN_CLK=1): blocks 0..7 write {s_memtime, s_memrealtime} at kernel begin / end to clk[block][2][2]: the
   // shader clock the kernel actually ran at inside the step (DVFS) = d(memtime) / d(memrealtime @ 100 MHz)
   unsigned long long* clk;

@@ -48,6 +48,10 @@
 #define CHAIN4_ABL 0           // scratch timing experiments (results wrong): 1 no weight loads after the ring is primed, 2 panel fragments read once per GEMM call, 4 the weight stream wraps inside its first 256 KiB (always L2-resident)
 #endif
 #define CHAIN4_HS_ELEMS 4096   // 128 output columns x 32 k: 8 KiB
+#ifndef CHAIN4_SPREAD
+#define CHAIN4_SPREAD 0        // stream layout: blocks of four half stages, a wave's four 1 KiB slices contiguous (4 KiB), the eight waves 4 KiB apart -- the eight requests of a
+                               // half stage go to eight different 4 KiB blocks instead of one 8 KiB run (0: [half stage][wave][lane], A/B)
+#endif
 
 #ifndef CHAIN4_FFN_PIPE
 #define CHAIN4_FFN_PIPE 1      // feed-forward block without workgroup barriers: per-chunk LDS counters, the two waves of a SIMD one phase apart (0: round-5 form, A/B)
@@ -103,19 +107,20 @@ __device__ __forceinline__ void chain4_lds_wait(h16x8 (&a)[MT]) {
 // descs: [2][n] -- half stage i of waves 4-7 is descs[i], of waves 0-3 descs[n + i] (the two wave groups of a pipelined feed-forward block consume their
 // linear1 / linear2 chunks in different orders; everywhere else the two entries are equal)
 __global__ __launch_bounds__(256) void chain4_pack_kernel(const ChainPackDesc* __restrict__ descs, h16_t* __restrict__ dst, int n) {
-  uint4* out = reinterpret_cast<uint4*>(dst + (int64_t)blockIdx.x * CHAIN4_HS_ELEMS);
   for (int q = threadIdx.x; q < 512; q += 256) {
     const int w = q >> 6, lane = q & 63, i = lane & 15, g = lane >> 4;
+    const int64_t h = blockIdx.x;
+    uint4* out = reinterpret_cast<uint4*>(dst) + (CHAIN4_SPREAD ? (h >> 2) * 2048 + w * 256 + (h & 3) * 64 + lane : h * 512 + q);
     const ChainPackDesc d = descs[(w < 4 ? n : 0) + blockIdx.x];
     const int w4 = w >> 1, J = w & 1, tile = d.row0 >> 7;
     const int row = d.omap ? (tile >> 1) * 256 + w4 * 64 + J * 32 + (tile & 1) * 16 + i : d.row0 + w4 * 32 + (i >> 2) * 8 + J * 4 + (i & 3);
     uint4 v = make_uint4(0, 0, 0, 0);
     if (row < d.nrows) v = *reinterpret_cast<const uint4*>(d.W + (int64_t)row * d.ldw + d.k0 + g * 8);
-    out[q] = v;
+    *out = v;
   }
 }
 
-template <int MT, int MODE, bool LAST>
+template <int MT, int MODE, int LAST>
 __device__ __forceinline__ void chain4_body(const ChainP& p, h16_t* const smem, const int m0) {
   constexpr int D = 512, NW = 8, CW = 16, BM = 16 * MT, NT = 4, KC = D / 32, FT = 8, HLD = Chain4Lds<MT>::HC, NH = HLD / 128, PF = (MODE == CHAIN_MID && MT == 3) ? CHAIN4_PF_MID : (MODE == CHAIN_POST && MT == 3) ? CHAIN4_PF_POST3 : CHAIN4_PF;
   using LY = Chain4Lds<MT>;
@@ -145,14 +150,15 @@ __device__ __forceinline__ void chain4_body(const ChainP& p, h16_t* const smem, 
   stamp(0);
 
   // ---- weight stream: register ring of PF half stages --------------------------------------------------------------------
-  uint32_t woff = (uint32_t)(wid * 64 + lane) * 16;   // byte offset of this lane's 16 bytes of the next half stage to load
+  uint32_t woff = CHAIN4_SPREAD ? (uint32_t)(wid * 4096 + lane * 16) : (uint32_t)(wid * 64 + lane) * 16;   // byte offset of this lane's 16 bytes of the next half stage to load
   h16x8 wr[PF];
   bool w_primed = false;
   auto w_issue = [&](int slot) __attribute__((always_inline)) {
     if ((CHAIN4_ABL & 1) && w_primed) { asm volatile("" : "+v"(wr[slot])); return; }
     if (CHAIN4_ABL & 4) wr[slot] = *reinterpret_cast<const h16x8*>(reinterpret_cast<const char*>(p.stream) + (woff & 0x3ffffu));   // (every half stage from the first 256 KiB: L2 hits by construction)
     else wr[slot] = *reinterpret_cast<const h16x8*>(reinterpret_cast<const char*>(p.stream) + woff);   // uniform base + 32-bit offset
-    woff += CHAIN4_HS_ELEMS * 2;    // the host pads the stream behind the last half stage
+    // the host pads the stream behind the last half stage.  (SPREAD: every GEMM starts on a multiple of the ring depth, so slot & 3 is the half stage's place in its block of four)
+    woff += CHAIN4_SPREAD ? ((slot & 3) == 3 ? 32768u - 3072u : 1024u) : CHAIN4_HS_ELEMS * 2;
   };
 
   // ---- helpers -----------------------------------------------------------------------------------------------------------
@@ -706,7 +712,50 @@ __device__ __forceinline__ void chain4_body(const ChainP& p, h16_t* const smem, 
       }
     }
     stamp(7);
-    if constexpr (LAST) {   // last decoder layer (final_layer runs on its own exact-island path): the rows go back in the caller's layout.
+    if constexpr (LAST == 2) {
+      // Last decoder layer, <= 64 rows: final_layer (model/diffusion.py:397) as a split-operand exact island on the rows in registers -- out = hi W_hi^T + lo W_hi^T + hi W_lo^T
+      // with x = hi + lo (16-bit pieces), fp32 accumulation: what split3_kernel + gemm_kernel compute behind the non-fused kernel (19.7 MB of fp32 rows out, 29.5 MB of
+      // split rows out and in again at B=8: 12.5 + ~30 us per step), without the round trip.  hi panel over the A panel, lo panel over the two hidden-chunk buffers (contiguous,
+      // [BM][512] where the chunk is 256 wide); the stream carries [W_hi | W_hi | W_lo] as three 256 x 512 GEMMs in pairs of tiles.  The residual stream is NOT written back.
+      static_assert(2 * HLD == D, "the lo panel takes both hidden-chunk buffers");
+      h16_t* const panelLo = panelH;
+      // (every wave has passed wait_all(done[last]): nobody reads the chunk buffers; every wave counted ready[last] before that: nobody reads the A panel)
+#pragma unroll
+      for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+          const f32x4 v = R[t][mt];
+          const h16x4 hi = {(h16_t)v[0], (h16_t)v[1], (h16_t)v[2], (h16_t)v[3]};
+          const h16x4 lo = {(h16_t)(v[0] - (float)hi[0]), (h16_t)(v[1] - (float)hi[1]), (h16_t)(v[2] - (float)hi[2]), (h16_t)(v[3] - (float)hi[3])};
+          *reinterpret_cast<h16x4*>(panelA + (mt * 16 + l15) * D + t * 128 + pswz) = hi;
+          *reinterpret_cast<h16x4*>(panelLo + (mt * 16 + l15) * D + t * 128 + pswz) = lo;
+        }
+      chain_bar();
+      // (accumulators from zero, k in gemm_kernel's order, the bias added last: the same bits as the launches this replaces -- the kernel family of a forward,
+      // which decides whether this kernel or kernels_chain.h + split3_kernel + gemm_kernel runs, stays invisible in the results: tests/test_hip_parity.py)
+      f32x4 acc[2][MT];
+#pragma unroll
+      for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) acc[tt][mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+      __builtin_amdgcn_sched_barrier(0);
+      gemm(std::integral_constant<int, 2>{}, std::integral_constant<int, KC>{}, std::integral_constant<int, D>{}, acc, panelA, false);    // hi x W_hi
+      __builtin_amdgcn_sched_barrier(0);
+      gemm(std::integral_constant<int, 2>{}, std::integral_constant<int, KC>{}, std::integral_constant<int, D>{}, acc, panelLo, false);   // lo x W_hi
+      __builtin_amdgcn_sched_barrier(0);
+      gemm(std::integral_constant<int, 2>{}, std::integral_constant<int, KC>{}, std::integral_constant<int, D>{}, acc, panelA, false);    // hi x W_lo
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) {
+        const int m = m0 + mt * 16 + l15;
+        if (m >= p.M) continue;
+#pragma unroll
+        for (int tt = 0; tt < 2; ++tt) st4(p.fin_out, (uint32_t)m * (uint32_t)p.ld_fin + (uint32_t)col_of(tt), acc[tt][mt] + *reinterpret_cast<const f32x4*>(aux + FT * 128 + col_of(tt)));
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      return;
+    }
+    if constexpr (LAST == 1) {   // last decoder layer (final_layer runs on its own exact-island path): the rows go back in the caller's layout.
       // Its own instantiation, not a run-time branch on p.has_next: with both continuations in one function hipcc spilled 70 registers of
       // the 80-row kernel (17 without the branch) and its POST launches at B=32 went from 232 to 263 us.
       // Parked rows were re-read in the TILED layout just now and the final layout is row-major: inside a 16-row block the two
@@ -746,9 +795,10 @@ __device__ __forceinline__ void chain4_body(const ChainP& p, h16_t* const smem, 
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the ring's run-ahead loads target this wave's registers
 }
 
-template <int MT, int MODE, bool LAST = false>   // LAST: the POST kernel behind the last decoder layer (ChainP::has_next == 0)
+template <int MT, int MODE, int LAST = 0>   // LAST: the POST kernel behind the last decoder layer (ChainP::has_next == 0); 2 = with final_layer as a split-operand island (ChainP::fin_x3)
 __global__ __launch_bounds__(512, 2) void chain4_kernel(const ChainP p) {
   static_assert(!LAST || MODE == CHAIN_POST, "only POST has a last-layer form");
+  static_assert(LAST != 2 || MT <= 4, "the fused final_layer needs the 256-wide chunk buffers");
   __shared__ __attribute__((aligned(16))) h16_t smem[Chain4Lds<MT>::ELEMS];
   chain4_body<MT, MODE, LAST>(p, smem, blockIdx.x * (16 * MT));
 }

@@ -274,9 +274,11 @@ def test_properties_full_size(dev):
     full = cfg(x, t, y)
     again = cfg(x, t, y)
     assert torch.equal(full, again)
-    y2 = {"cond_embed": y["cond_embed"][2:4].contiguous(), "scale": y["scale"][2:4].contiguous()}
-    part = cfg(x[2:4].contiguous(), t[2:4], y2)
-    assert rel_l2(part.cpu(), full[2:4].cpu()) < 1e-6
+    # four neighbours, not two: below 8 sequences the attention launches take attn_kernel instead of attn3_kernel (launch_attn's rule, round 6) -- two 16-bit
+    # roundings of the same softmax that agree to 4e-4 (fp16) / 2e-3 (bf16), not to the bit; the property is about batch POSITION, so both runs must take the same kernels
+    y2 = {"cond_embed": y["cond_embed"][2:6].contiguous(), "scale": y["scale"][2:6].contiguous()}
+    part = cfg(x[2:6].contiguous(), t[2:6], y2)
+    assert rel_l2(part.cpu(), full[2:6].cpu()) < 1e-6
     assert torch.isfinite(full).all()
 
 

@@ -63,16 +63,56 @@ def test_face_guided_forward_at_the_benchmarked_batch_vs_oracle_tall_kernels(dev
         y = {"cond_embed": inp["cond_embed"].to(dev), "scale": torch.full((B,), 10.0, device=dev)}
         x, t = inp["x_T"].to(dev), times.to(dev)
         cfg(x, t, y)                                          # context + hoisted conditioning
-        before = _debug_i64(model, b"chain4_launches")
+        before, before_fin = _debug_i64(model, b"chain4_launches"), _debug_i64(model, b"final_fused_launches")
         got = cfg(x, t, y).cpu()
         launched = _debug_i64(model, b"chain4_launches") - before
+        fused_final = _debug_i64(model, b"final_fused_launches") - before_fin
         model.check_finite()
         model.release()
         e = {"rel_l2": rel_l2(got, want), "max_norm": rel_max(got, want), "worst_sample_rel_l2": _worst_sample(got, want)}
         record(f"oracle_at_bench_batch/face_B{B}_{rows}row/{precision}", tall_launches=launched, **e)
         if precision != "fp32":                               # fp32 parity mode runs the per-op exact-fp32 kernels, not the chain kernels
             assert launched == 16, launched
+            # 48-row panels: the last POST kernel computes final_layer too (split-operand island inside the kernel); 80-row panels: split3 + GEMM launches behind it
+            assert fused_final == (1 if rows == 48 else 0), fused_final
         assert e["rel_l2"] < tol and e["worst_sample_rel_l2"] < tol * (1.0 if precision == "fp32" else 1.5), e
+
+
+@pytest.mark.parametrize("precision", ["fp16", "bf16"])
+@pytest.mark.parametrize("B,T,mt", [(8, 600, 0), (3, 208, 4), (2, 88, 3)])
+def test_final_layer_inside_the_last_post_kernel_is_bit_identical(dev, B, T, mt, precision, monkeypatch):
+    """model/diffusion.py:397 (final_layer) as a split-operand exact island INSIDE the last decoder layer's tall POST kernel (chain4_kernel<MT, POST, 2>: the rows never
+    leave the registers, hi / lo panels in LDS, [W_hi | W_hi | W_lo] on the weight stream) against the launches it replaces (the rows stored, split3_kernel, gemm_kernel;
+    A2P_NO_FUSED_FINAL=1): accumulators from zero, the same k order, the bias last -- the SAME BITS, for 48- and 64-row panels, ragged last panels and panels that
+    straddle two sequences.  (The kernel family of a forward is chosen per box; it must stay invisible in the results.)"""
+    spec = face_spec()
+    inp = synthetic_inputs(spec, B, T, SEED)
+    model, _ = create_model_and_diffusion(default_args("face"), "test", precision=precision, max_batch=B)
+    load_model(model, synthetic_state_dict(spec, SEED))
+    cfg = ClassifierFreeSampleModel(model.to(dev).eval())
+    y = {"cond_embed": inp["cond_embed"].to(dev), "scale": torch.full((B,), 10.0, device=dev)}
+    t = torch.tensor(([901, 417, 33, 650] * 4)[:B], device=dev)
+    monkeypatch.setenv("A2P_CHAIN_V", "4")
+    if mt:
+        monkeypatch.setenv("A2P_CHAIN_MT", str(mt))
+    if 2 * B * T < 1100:
+        monkeypatch.setenv("A2P_CHAIN_ROWS", "1")
+    outs, fused = {}, {}
+    for name, flag in (("fused", None), ("launches", "1")):
+        if flag:
+            monkeypatch.setenv("A2P_NO_FUSED_FINAL", flag)
+        before = _debug_i64(model, b"final_fused_launches") if model._ctx is not None else 0
+        outs[name] = cfg(inp["x_T"].to(dev), t, y).cpu()
+        fused[name] = _debug_i64(model, b"final_fused_launches") - before
+    for k in ("A2P_CHAIN_V", "A2P_CHAIN_MT", "A2P_CHAIN_ROWS", "A2P_NO_FUSED_FINAL"):
+        monkeypatch.delenv(k, raising=False)
+    model.check_finite()
+    model.release()
+    assert fused == {"fused": 1, "launches": 0}, fused
+    assert torch.isfinite(outs["fused"]).all()
+    diff = float((outs["fused"] - outs["launches"]).abs().max())
+    record(f"fused_final_vs_launches/B{B}_T{T}_mt{mt}/{precision}", max_abs_diff=diff)
+    assert diff == 0.0, diff
 
 
 # ----------------------------------------------------------------------------- body, B = 16 (BASELINE configs[2])
