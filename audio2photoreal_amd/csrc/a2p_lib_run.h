@@ -254,7 +254,7 @@ static int chain_build_streams(a2p_ctx* c, hipStream_t s) {
               const Buf& inw = c->wt.at(pf(l + 1) + "self_attn.in_proj_weight");
               pk4_gemm(*v, inw.p, d, 2 * d, 0, d, 1, 4);                  // [Q|K] of the next layer, in groups of four tiles
               pk4_gemm(*v, c->offT(inw, (int64_t)2 * d * d), d, d, 0, d, 1, 4);   // V
-            } else if (hc == 256 && c->tail_x3 && !c->pose && c->C == 256) {
+            } else if (c->tail_x3 && !c->pose && c->C == 256) {
               // final_layer as a split-operand island inside the last POST kernel (chain4_kernel<.., 2>): the split weight rows are [W_hi | W_hi | W_lo] (make_wt3),
               // consumed as hi x W_hi, lo x W_hi, hi x W_lo: three 256 x 512 GEMMs in pairs of tiles
               const void* wf = c->wt.at("final_layer.weight").p;
@@ -439,14 +439,13 @@ static int chain4_pick_mt(const a2p_ctx* c, int M) {
   }
   return mt;
 }
-// final_layer inside the last layer's POST kernel (chain4_kernel<MT, CHAIN_POST, 2>): tall family, <= 64-row panels (the lo panel takes both 256-wide chunk buffers),
-// split-operand islands (the default), 256 output features.  The diagnostic build keeps its stamps in ChainP::fin_out.
+// final_layer inside the last layer's POST kernel (chain4_kernel<MT, CHAIN_POST, 2>): tall family, split-operand islands (the default), 256 output features.
+// The diagnostic build keeps its stamps in ChainP::fin_out.
 static bool chain4_final_fused(const a2p_ctx* c, int mode, const ChainP& p) {
 #ifdef A2P_STAMPS
   return false;
 #else
-  return mode == CHAIN_POST && p.has_next == 0 && p.fin_x3 && c->tail_x3 && !c->pose && c->C == 256 && !c->opt.no_fused_final && chain4_wanted(c, mode, p) &&
-         chain4_pick_mt(c, p.M) <= 4;
+  return mode == CHAIN_POST && p.has_next == 0 && p.fin_x3 && c->tail_x3 && !c->pose && c->C == 256 && !c->opt.no_fused_final && chain4_wanted(c, mode, p);
 #endif
 }
 static int launch_chain4(a2p_ctx* c, int mode, const ChainP& p0, hipStream_t s) {
@@ -466,7 +465,8 @@ static int launch_chain4(a2p_ctx* c, int mode, const ChainP& p0, hipStream_t s) 
   } while (0)
   if (fin) {
     if (mt == 3) A2P_LAUNCH(kt, (chain4_kernel<3, CHAIN_POST, 2>), grid, 512, s, p);
-    else A2P_LAUNCH(kt, (chain4_kernel<4, CHAIN_POST, 2>), grid, 512, s, p);
+    else if (mt == 4) A2P_LAUNCH(kt, (chain4_kernel<4, CHAIN_POST, 2>), grid, 512, s, p);
+    else A2P_LAUNCH(kt, (chain4_kernel<5, CHAIN_POST, 2>), grid, 512, s, p);
   } else if (mt == 3) A2P_CHAIN4(3);
   else if (mt == 4) A2P_CHAIN4(4);
   else A2P_CHAIN4(5);

@@ -717,19 +717,26 @@ __device__ __forceinline__ void chain4_body(const ChainP& p, h16_t* const smem, 
       // with x = hi + lo (16-bit pieces), fp32 accumulation: what split3_kernel + gemm_kernel compute behind the non-fused kernel (19.7 MB of fp32 rows out, 29.5 MB of
       // split rows out and in again at B=8: 12.5 + ~30 us per step), without the round trip.  hi panel over the A panel, lo panel over the two hidden-chunk buffers (contiguous,
       // [BM][512] where the chunk is 256 wide); the stream carries [W_hi | W_hi | W_lo] as three 256 x 512 GEMMs in pairs of tiles.  The residual stream is NOT written back.
-      static_assert(2 * HLD == D, "the lo panel takes both hidden-chunk buffers");
-      h16_t* const panelLo = panelH;
+      h16_t* const panelLo = panelH;   // the two chunk buffers, contiguous: [BM][512] at <= 64 rows, [BM][256] (half of K at a time) at 80 rows
+      constexpr bool LO_HALVES = 2 * HLD != D;
+      static_assert(2 * HLD == D || 4 * HLD == D, "chunk buffers");
+      constexpr int LLD = LO_HALVES ? D / 2 : D;
       // (every wave has passed wait_all(done[last]): nobody reads the chunk buffers; every wave counted ready[last] before that: nobody reads the A panel)
+      auto split_rows = [&](auto hi_c, int t_lo0, int t_lo1) __attribute__((always_inline)) {   // hi pieces of every tile (once), lo pieces of tiles [t_lo0, t_lo1)
 #pragma unroll
-      for (int t = 0; t < NT; ++t)
+        for (int t = 0; t < NT; ++t)
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt) {
-          const f32x4 v = R[t][mt];
-          const h16x4 hi = {(h16_t)v[0], (h16_t)v[1], (h16_t)v[2], (h16_t)v[3]};
-          const h16x4 lo = {(h16_t)(v[0] - (float)hi[0]), (h16_t)(v[1] - (float)hi[1]), (h16_t)(v[2] - (float)hi[2]), (h16_t)(v[3] - (float)hi[3])};
-          *reinterpret_cast<h16x4*>(panelA + (mt * 16 + l15) * D + t * 128 + pswz) = hi;
-          *reinterpret_cast<h16x4*>(panelLo + (mt * 16 + l15) * D + t * 128 + pswz) = lo;
-        }
+          for (int mt = 0; mt < MT; ++mt) {
+            const f32x4 v = R[t][mt];
+            const h16x4 hi = {(h16_t)v[0], (h16_t)v[1], (h16_t)v[2], (h16_t)v[3]};
+            if constexpr (decltype(hi_c)::value) *reinterpret_cast<h16x4*>(panelA + (mt * 16 + l15) * D + t * 128 + pswz) = hi;
+            if (t >= t_lo0 && t < t_lo1) {
+              const h16x4 lo = {(h16_t)(v[0] - (float)hi[0]), (h16_t)(v[1] - (float)hi[1]), (h16_t)(v[2] - (float)hi[2]), (h16_t)(v[3] - (float)hi[3])};
+              *reinterpret_cast<h16x4*>(panelLo + (mt * 16 + l15) * LLD + (LO_HALVES ? (t & 1) : t) * 128 + pswz) = lo;
+            }
+          }
+      };
+      split_rows(Tt, 0, LO_HALVES ? 2 : NT);
       chain_bar();
       // (accumulators from zero, k in gemm_kernel's order, the bias added last: the same bits as the launches this replaces -- the kernel family of a forward,
       // which decides whether this kernel or kernels_chain.h + split3_kernel + gemm_kernel runs, stays invisible in the results: tests/test_hip_parity.py)
@@ -741,7 +748,17 @@ __device__ __forceinline__ void chain4_body(const ChainP& p, h16_t* const smem, 
       __builtin_amdgcn_sched_barrier(0);
       gemm(std::integral_constant<int, 2>{}, std::integral_constant<int, KC>{}, std::integral_constant<int, D>{}, acc, panelA, false);    // hi x W_hi
       __builtin_amdgcn_sched_barrier(0);
-      gemm(std::integral_constant<int, 2>{}, std::integral_constant<int, KC>{}, std::integral_constant<int, D>{}, acc, panelLo, false);   // lo x W_hi
+      if constexpr (!LO_HALVES) {
+        gemm(std::integral_constant<int, 2>{}, std::integral_constant<int, KC>{}, std::integral_constant<int, D>{}, acc, panelLo, false);   // lo x W_hi
+      } else {   // 80 rows: the lo pieces of k < 256, then of k >= 256, through the same 40 KiB (the stream's k order is the same either way: one group of two tiles)
+        gemm(std::integral_constant<int, 2>{}, std::integral_constant<int, KC / 2>{}, std::integral_constant<int, LLD>{}, acc, panelLo, false);
+        __builtin_amdgcn_sched_barrier(0);
+        chain_bar();
+        split_rows(F, 2, 4);
+        chain_bar();
+        __builtin_amdgcn_sched_barrier(0);
+        gemm(std::integral_constant<int, 2>{}, std::integral_constant<int, KC / 2>{}, std::integral_constant<int, LLD>{}, acc, panelLo, false);
+      }
       __builtin_amdgcn_sched_barrier(0);
       gemm(std::integral_constant<int, 2>{}, std::integral_constant<int, KC>{}, std::integral_constant<int, D>{}, acc, panelA, false);    // hi x W_lo
       __builtin_amdgcn_sched_barrier(0);
@@ -798,7 +815,6 @@ __device__ __forceinline__ void chain4_body(const ChainP& p, h16_t* const smem, 
 template <int MT, int MODE, int LAST = 0>   // LAST: the POST kernel behind the last decoder layer (ChainP::has_next == 0); 2 = with final_layer as a split-operand island (ChainP::fin_x3)
 __global__ __launch_bounds__(512, 2) void chain4_kernel(const ChainP p) {
   static_assert(!LAST || MODE == CHAIN_POST, "only POST has a last-layer form");
-  static_assert(LAST != 2 || MT <= 4, "the fused final_layer needs the 256-wide chunk buffers");
   __shared__ __attribute__((aligned(16))) h16_t smem[Chain4Lds<MT>::ELEMS];
   chain4_body<MT, MODE, LAST>(p, smem, blockIdx.x * (16 * MT));
 }
