@@ -351,8 +351,9 @@ static int launch_gemm(a2p_ctx* c, const GemmP& p, hipStream_t s) {
   // narrow tap-accumulating launches (the body model's dilated conv tail: N <= 128, i.e. one column tile; 312 workgroups of 64 rows
   // at B=16 = 1.2 per CU, each a chain of 18 k-tile round trips): 32-row tiles double the workgroups per CU (A2P_GEMM_MT1=0|1)
   static const int mt1 = getenv("A2P_GEMM_MT1") ? atoi(getenv("A2P_GEMM_MT1")) : 1;
+  static const int ring4_blocks = getenv("A2P_GEMM_RING4_BLOCKS") ? atoi(getenv("A2P_GEMM_RING4_BLOCKS")) : 256;   // (A/B: the 4-deep ring up to this many 64-row workgroups)
   if (c->bf16 && mt1 && p.ntaps > 1 && p.N <= 128 && blocks64 <= 3 * 256) rc = gemm_dispatch<h16_t, 1>(kt, p, s);
-  else if (c->bf16 && small && blocks64 <= 256 && p.ntaps == 1 && !ring2) rc = gemm_dispatch<h16_t, 2, 4>(kt, p, s);
+  else if (c->bf16 && small && blocks64 <= ring4_blocks && p.ntaps == 1 && !ring2) rc = gemm_dispatch<h16_t, 2, 4>(kt, p, s);
   else if (c->bf16) rc = small ? gemm_dispatch<h16_t, 2>(kt, p, s) : gemm_dispatch<h16_t, 4>(kt, p, s);
   else rc = small ? gemm_dispatch<float, 2>(kt, p, s) : gemm_dispatch<float, 4>(kt, p, s);
   CHK(rc);

@@ -1,16 +1,16 @@
 #!/bin/bash
-# round 6, call 71: fused final_layer also at 80 rows (lo pieces half of K at a time): GPU tests, same-box A/B at B=32 / B=16 against the build that fuses only <= 64 rows
+# round 6, call 72: 4-deep GEMM ring for the input projection (A2P_GEMM_RING4_BLOCKS=512 vs the default 256), same box; the two re-written parity tests
 R=${GRAFT_REPO_ROOT:-/root/repo}
 O=$R/gpurun_out; mkdir -p $O
 cd $R
-timeout -k 5 1200 python -X faulthandler -m pytest tests/test_hip_round5.py tests/test_hip_round6.py tests/test_hip_parity.py -m gpu -q -x 2>&1 | tail -4
-for b in 32 16; do for lib in new prev new prev; do
-  if [ $lib = prev ]; then export A2P_NO_FUSED_FINAL=1; else unset A2P_NO_FUSED_FINAL; fi
-  timeout -k 5 300 python bench.py --batch $b --no-cpu-baseline --no-parity --no-legs --steps 60 --warmup 8 > $O/r06_c71.json 2>/dev/null
+timeout -k 5 600 python -m pytest tests/test_hip_parity.py -m gpu -q -x -k "properties_full_size" 2>&1 | tail -2
+for b in 8 32; do for v in 512 256 512 256; do
+  export A2P_GEMM_RING4_BLOCKS=$v
+  timeout -k 5 300 python bench.py --batch $b --no-cpu-baseline --no-parity --no-legs --steps 100 --warmup 8 > $O/r06_c72.json 2>/dev/null
   python - <<PY
 import json
-j=json.loads([l for l in open("$O/r06_c71.json") if l.startswith("{")][-1])
-k=j["kernels"]; sub=k["_sub_classes"]
-print("B=$b final_layer=$lib", j["value"], "steps/s", {a:v["avg_launch_us"] for a,v in sub.items()}, {x:(k[x]["avg_launch_us"],k[x]["launches_per_step"]) for x in ("gemm","attn_self","attn_cross")}, "decoder", j.get("decoder_mfma_frac"), "family", j["roofline"].get("chain_family"))
+j=json.loads([l for l in open("$O/r06_c72.json") if l.startswith("{")][-1])
+k=j["kernels"]
+print("B=$b ring4_blocks=$v", j["value"], "steps/s", {x:(k[x]["avg_launch_us"],k[x]["launches_per_step"]) for x in ("gemm",)})
 PY
-done; done | sed 's/=new/=fused/; s/=prev/=launches/' | tee $O/r06_fused_final_80row_ab.txt
+done; done | tee $O/r06_gemm_ring4_ab.txt
