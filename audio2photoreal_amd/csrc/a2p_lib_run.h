@@ -377,7 +377,7 @@ static int chain_pick_nw(a2p_ctx* c, int64_t rows, hipEvent_t* e0, hipEvent_t* e
 // gen-1 MID kernels on a fast box (family 14: 664 instead of 676 steps/s).  Now: forwards 0 and 1 of a size warm both candidates up
 // (untimed), forwards 2..9 alternate them with an event pair around the decoder stack (four samples each), forward 10 compares the
 // MINIMA (interference from other streams only ever adds time) and keeps gen 1 only if it leads by more than 1.5 %.
-// A2P_CHAIN_V=1 | 4 forces one family for both chains.
+// A2P_CHAIN_V=1 | 4 forces one family for both chains, 41 the mixed choice (tall MID, gen-1 POST).
 static const int kFamConfigs[2][2] = {{4, 4}, {4, 1}};
 static const int kTuneForwards4 = 10;
 static void chain_pick_family(a2p_ctx* c, int64_t rows, hipEvent_t* e0, hipEvent_t* e1) {
@@ -385,6 +385,7 @@ static void chain_pick_family(a2p_ctx* c, int64_t rows, hipEvent_t* e0, hipEvent
   auto set = [&](int cfg) { c->ch_fam_mid = kFamConfigs[cfg][0]; c->ch_fam_post = kFamConfigs[cfg][1]; };
   if (c->opt.chain_v == 1 || c->ch_stream4.empty() || c->d != 512 || c->ch_nw != 8) { c->ch_fam_mid = c->ch_fam_post = 1; return; }
   if (c->opt.chain_v == 4) return set(0);
+  if (c->opt.chain_v == 41) return set(1);   // (tests, A/B: what the calibration picks on the slow GPU type -- tall MID, gen-1 POST)
   if (c->ch_tune4.size() > 64 && !c->ch_tune4.count(rows)) {   // (variable-length clips: the table stays bounded; pending event pairs are released)
     for (auto& kv : c->ch_tune4)
       for (auto& sm : kv.second.samples) { (void)hipEventDestroy(std::get<1>(sm)); (void)hipEventDestroy(std::get<2>(sm)); }
@@ -420,11 +421,23 @@ static void chain_pick_family(a2p_ctx* c, int64_t rows, hipEvent_t* e0, hipEvent
 // Contract: face model (d = 512), MID or POST-with-successor, FiLM present, frame count a multiple of 8 and >= the panel height.
 // Rule: forwards of >= 16 sequences (B >= 8 under guidance is 16 sequences of 600 frames = 37.5 rows per CU: the 48-row panels of
 // kernels_chain.h are one round there; from 75 rows per CU on -- B = 16 -- an 80-row panel is one round where 48-row panels are two).
+// final_layer inside the last layer's POST kernel (chain4_kernel<MT, CHAIN_POST, 2>) asked for and possible: split-operand islands (the default), 256 output features.
+// The diagnostic build keeps its stamps in ChainP::fin_out.
+static bool chain4_final_ok(const a2p_ctx* c, int mode, const ChainP& p) {
+#ifdef A2P_STAMPS
+  return false;
+#else
+  return mode == CHAIN_POST && p.has_next == 0 && p.fin_x3 && c->tail_x3 && !c->pose && c->C == 256 && !c->opt.no_fused_final;
+#endif
+}
 static bool chain4_wanted(const a2p_ctx* c, int mode, const ChainP& p) {
   if (c->opt.chain_v == 1 || p.stream4 == nullptr || c->d != 512 || c->ch_nw != 8) return false;
   if (!(mode == CHAIN_MID || (mode == CHAIN_POST && p.has_next <= 1))) return false;   // (has_next == 2: final_layer fused, kernels_chain.h only)
   if (p.film_o == nullptr || (mode == CHAIN_POST && p.film_f == nullptr)) return false;
   if ((p.rows_per_seq & 7) || p.rows_per_seq < 80) return false;
+  // The LAST layer's POST kernel is tall whatever the calibration says about the other seven: with final_layer inside it replaces three launches and 49 MB of traffic
+  // (B=8: 53 us against 48 + 12.5 + 29), which no box type's gen-1 lead (at most ~20 % of one POST launch on the slow type) outweighs.  Same bits either way.
+  if (chain4_final_ok(c, mode, p)) return true;
   return (mode == CHAIN_MID ? c->ch_fam_mid : c->ch_fam_post) == 4;   // the family of this forward's chain (chain_pick_family: forced, or measured on this box)
 }
 static int chain4_pick_mt(const a2p_ctx* c, int M) {
@@ -439,15 +452,7 @@ static int chain4_pick_mt(const a2p_ctx* c, int M) {
   }
   return mt;
 }
-// final_layer inside the last layer's POST kernel (chain4_kernel<MT, CHAIN_POST, 2>): tall family, split-operand islands (the default), 256 output features.
-// The diagnostic build keeps its stamps in ChainP::fin_out.
-static bool chain4_final_fused(const a2p_ctx* c, int mode, const ChainP& p) {
-#ifdef A2P_STAMPS
-  return false;
-#else
-  return mode == CHAIN_POST && p.has_next == 0 && p.fin_x3 && c->tail_x3 && !c->pose && c->C == 256 && !c->opt.no_fused_final && chain4_wanted(c, mode, p);
-#endif
-}
+static bool chain4_final_fused(const a2p_ctx* c, int mode, const ChainP& p) { return chain4_final_ok(c, mode, p) && chain4_wanted(c, mode, p); }
 static int launch_chain4(a2p_ctx* c, int mode, const ChainP& p0, hipStream_t s) {
   ChainP p = p0;
   const int mt = chain4_pick_mt(c, p.M);

@@ -114,6 +114,31 @@ def test_final_layer_inside_the_last_post_kernel_is_bit_identical(dev, B, T, mt,
     assert diff == 0.0, diff
 
 
+def test_last_layer_takes_the_tall_fused_kernel_under_the_mixed_family(dev, monkeypatch):
+    """On the slow GPU type the in-situ calibration keeps the gen-1 POST kernels (family 41: tall MID, gen-1 POST).  The LAST layer's POST kernel is tall regardless -- with
+    final_layer inside it replaces three launches -- and the result is the same bits as the all-tall forward: 8 tall MID + 1 tall POST launches, one fused final_layer."""
+    B, T = 8, 600
+    spec = face_spec()
+    inp = synthetic_inputs(spec, B, T, SEED)
+    model, _ = create_model_and_diffusion(default_args("face"), "test", precision="fp16", max_batch=B)
+    load_model(model, synthetic_state_dict(spec, SEED))
+    cfg = ClassifierFreeSampleModel(model.to(dev).eval())
+    y = {"cond_embed": inp["cond_embed"].to(dev), "scale": torch.full((B,), 10.0, device=dev)}
+    t = torch.tensor(([901, 417, 33, 650] * 4)[:B], device=dev)
+    outs, tall, fused = {}, {}, {}
+    for v in ("4", "41"):
+        monkeypatch.setenv("A2P_CHAIN_V", v)
+        b0 = (_debug_i64(model, b"chain4_launches"), _debug_i64(model, b"final_fused_launches")) if model._ctx is not None else (0, 0)
+        outs[v] = cfg(inp["x_T"].to(dev), t, y).cpu()
+        tall[v] = _debug_i64(model, b"chain4_launches") - b0[0]
+        fused[v] = _debug_i64(model, b"final_fused_launches") - b0[1]
+    monkeypatch.delenv("A2P_CHAIN_V", raising=False)
+    model.check_finite()
+    model.release()
+    assert tall == {"4": 16, "41": 9} and fused == {"4": 1, "41": 1}, (tall, fused)
+    assert torch.equal(outs["4"], outs["41"])
+
+
 # ----------------------------------------------------------------------------- body, B = 16 (BASELINE configs[2])
 def test_body_B16_T600_two_ddim_steps_vs_oracle(dev):
     """BASELINE configs[2] at its own batch: body model, keyframe conditioning, CFG scale 2, B = 16, T = 600 -- the first two steps of
