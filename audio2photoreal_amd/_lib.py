@@ -170,7 +170,7 @@ def check(rc: int, what: str) -> int:
 # the environment switches a context caches (csrc/a2p_lib.hip A2POpts); changing one after context creation takes a2p_reload_env
 ENV_SWITCHES = ("A2P_KV_CACHED", "A2P_NO_CHAIN", "A2P_CHAIN_NW", "A2P_CHAIN_MT", "A2P_CHAIN_TUNE", "A2P_CHAIN_NO_MIX", "A2P_TUNE_VERBOSE",
                 "A2P_SIDE_JOIN", "A2P_CHAIN_X_ROWMAJOR", "A2P_NO_SIDE_STREAM", "A2P_SIDE_EARLY_JOIN", "A2P_NO_SHARED_HALF", "A2P_NO_SMALL", "A2P_CHAIN_ROWS",
-                "A2P_NO_KSPLIT", "A2P_ATTN_KSPLIT", "A2P_NO_FUSED_KF", "A2P_NO_FUSED_FINAL", "A2P_KSPLIT_NW", "A2P_KSPLIT_QT", "A2P_GRAPH", "A2P_CHAIN_V", "A2P_ATTN2", "A2P_ATTN3")
+                "A2P_NO_KSPLIT", "A2P_ATTN_KSPLIT", "A2P_NO_FUSED_KF", "A2P_NO_FUSED_FINAL", "A2P_NO_FUSED_IN", "A2P_TIME_TABLE", "A2P_KSPLIT_NW", "A2P_KSPLIT_QT", "A2P_GRAPH", "A2P_CHAIN_V", "A2P_ATTN2", "A2P_ATTN3")
 
 
 def env_signature():

@@ -170,6 +170,8 @@ struct A2POpts {
   int attn2 = 0;            // A2P_ATTN2=1: the query-split 16-bit attention launches take attn2_kernel (kernels_attn2.h: one 8-wave workgroup per CU,
                             // 48 + 32 queries per SIMD, unit-level software pipeline); 0: attn_kernel
   int no_fused_kf = 0;      // A2P_NO_FUSED_KF=1: body model: MID2 | keyframe attention | POST as three launches instead of one (A/B, tests)
+  int time_table = 1000;    // A2P_TIME_TABLE: rows of the time-MLP table (a2p_ctx::tct_table) built at a2p_finalize_weights; 0 = compute the time MLP in every forward
+  int no_fused_in = 0;      // A2P_NO_FUSED_IN=1: face model: pack_input_split3 + gemm_kernel + the gen-1 PRE kernel instead of chain4_kernel<MT, CHAIN_IN> (A/B, tests)
   int no_fused_final = 0;   // A2P_NO_FUSED_FINAL=1: face model: final_layer behind the last tall POST kernel as split3_kernel + gemm_kernel instead of inside it (A/B, tests)
   int graph = 0;            // A2P_GRAPH=1: non-chain forwards replay a captured graph instead of stream launches (measured: same GPU
                             // time per step -- the launches are not host-bound -- at a tenth of the host time; off by default)
@@ -188,7 +190,7 @@ static void load_opts(A2POpts& o) {
   o.side_early_join = flag("A2P_SIDE_EARLY_JOIN"); o.no_shared_half = flag("A2P_NO_SHARED_HALF");
   o.graph = flag("A2P_GRAPH");
   o.no_ksplit = flag("A2P_NO_KSPLIT"); o.force_ksplit = flag("A2P_ATTN_KSPLIT"); o.ksplit_nw = num("A2P_KSPLIT_NW", 0); o.ksplit_qt = num("A2P_KSPLIT_QT", 0);
-  o.no_fused_kf = flag("A2P_NO_FUSED_KF"); o.no_fused_final = flag("A2P_NO_FUSED_FINAL"); o.attn2 = num("A2P_ATTN2", 0); o.attn3 = num("A2P_ATTN3", 1); o.chain_v = num("A2P_CHAIN_V", 0);
+  o.no_fused_kf = flag("A2P_NO_FUSED_KF"); o.no_fused_final = flag("A2P_NO_FUSED_FINAL"); o.no_fused_in = flag("A2P_NO_FUSED_IN"); o.time_table = num("A2P_TIME_TABLE", 1000); o.attn2 = num("A2P_ATTN2", 0); o.attn3 = num("A2P_ATTN3", 1); o.chain_v = num("A2P_CHAIN_V", 0);
   o.no_small = flag("A2P_NO_SMALL"); o.chain_rows = num("A2P_CHAIN_ROWS", 1100);
 }
 
@@ -215,6 +217,8 @@ struct a2p_ctx {
   bool finalized = false, prepared = false;
   int rope_npos = 0;
   Buf rope_cs, rope_cst, time_freq, film_w, film_b, tct_w, tct_b;
+  Buf tct_table;         // [tct_rows][3d]: the time MLP's outputs (time cond | token 0 | token 1) for every timestep value 0 .. tct_rows-1, built at a2p_finalize_weights by the
+  int tct_rows = 0;      // same kernels that compute them per forward otherwise (same bits); A2P_TIME_TABLE=rows (default 1000 = the reference's diffusion_steps; 0: off)
   Buf cak_w32, cak_b, cav_w32, cav_b, cak_wt, cav_wt;
   Buf ca2k_wt, ca2v_wt, ca2k_b, ca2v_b;
   Buf conv_wt[7];
@@ -225,6 +229,8 @@ struct a2p_ctx {
   int64_t ch4_launches = 0;            // launches of the tall chain kernels (a2p_debug_read "chain4_launches")
   int64_t fin_fused_launches = 0;      // ... of those, last-layer POST kernels that computed final_layer too (a2p_debug_read "final_fused_launches")
   std::vector<Buf> ch_stream4w;        // POST streams with 256-column hidden chunks [layer]
+  Buf ch_stream4_in, ch_aux_in;        // CHAIN_IN (input_projection + layer 0's PRE work in one tall kernel): stream [W_hi | W_hi | W_lo | Q|K | V], aux [bias_in 512 | 0 | bias_qkv]
+  int64_t in4_launches = 0;            // launches of chain4_kernel<MT, CHAIN_IN> (a2p_debug_read "chain_in_launches")
   std::vector<Buf> ch_stream4;         // kernels_chain4.h: half-stage streams [layer*5 + kind] (CH_MID, CH_POST of the face model; empty Buf otherwise)
   std::vector<Buf> ch_stream, ch_aux;  // packed weight streams [layout * L*5 + layer*5 + kind] (layout 0: 4-wave LDS slices, 1: 8-wave; kinds: a2p_lib_run.h CH_*) / bias blocks [layer*5 + kind]
   int ch_nw = 4;                       // waves per chain workgroup of the forward being enqueued (4 or 8; chain_pick_nw)
@@ -710,7 +716,7 @@ extern "C" int a2p_ctx_destroy(a2p_ctx* c) {
   if (c->gstream) (void)hipStreamDestroy(c->gstream);
   for (auto& kv : c->w) buf_free(kv.second);
   for (auto& kv : c->wt) buf_free(kv.second);
-  Buf* all[] = {&c->rope_cs, &c->rope_cst, &c->time_freq, &c->film_w, &c->film_b, &c->tct_w, &c->tct_b, &c->cak_w32, &c->cak_b, &c->cav_w32,
+  Buf* all[] = {&c->rope_cs, &c->rope_cst, &c->time_freq, &c->film_w, &c->film_b, &c->tct_w, &c->tct_b, &c->tct_table, &c->cak_w32, &c->cak_b, &c->cav_w32,
                 &c->cav_b, &c->cak_wt, &c->cav_wt, &c->ca2k_wt, &c->ca2v_wt, &c->ca2k_b, &c->ca2v_b, &c->hidden, &c->kc, &c->vtc,
                 &c->k2c, &c->vt2c, &c->slot_cond, &c->slot_unc, &c->slot_cfg, &c->x, &c->xn, &c->xr, &c->qk, &c->vt, &c->ao,
                 &c->hff, &c->inpack, &c->mo, &c->cb[0], &c->cb[1], &c->cb[2], &c->cb[3], &c->emb, &c->th, &c->tct, &c->tvec,
@@ -721,6 +727,7 @@ extern "C" int a2p_ctx_destroy(a2p_ctx* c) {
   for (auto& b : c->ch_stream) buf_free(b);
   for (auto& b : c->ch_stream4) buf_free(b);
   for (auto& b : c->ch_stream4w) buf_free(b);
+  buf_free(c->ch_stream4_in); buf_free(c->ch_aux_in);
   for (auto* m : {&c->ch_tune, &c->ch_tune4})
     for (auto& kv : *m)
       for (auto& sm : kv.second.samples) { (void)hipEventDestroy(std::get<1>(sm)); (void)hipEventDestroy(std::get<2>(sm)); }
@@ -893,6 +900,23 @@ extern "C" int a2p_finalize_weights(a2p_ctx* c, void* stream) {
   HIPCHK(d2d(c->tct_w.f() + (size_t)d * 4 * d, W32(c, "to_time_tokens.0.weight"), (size_t)2 * d * 4 * d * 4));
   HIPCHK(d2d(c->tct_b.f(), W32(c, "to_time_cond.0.bias"), (size_t)d * 4));
   HIPCHK(d2d(c->tct_b.f() + d, W32(c, "to_time_tokens.0.bias"), (size_t)2 * d * 4));
+  // ... and its outputs for every timestep value: three latency-bound launches of every forward become a row lookup in tpath_post_kernel
+  c->tct_rows = 0;
+  if (c->opt.time_table > 0) {
+    const int n = c->opt.time_table;
+    std::vector<int64_t> tv(n);
+    for (int i = 0; i < n; ++i) tv[i] = i;
+    Buf tt, te, th;
+    CHK(buf_alloc_tmp(tt, (size_t)n * 8)); CHK(buf_alloc_tmp(te, (size_t)n * d * 4)); CHK(buf_alloc_tmp(th, (size_t)n * 4 * d * 4));
+    HIPCHK(hipMemcpyAsync(tt.p, tv.data(), (size_t)n * 8, hipMemcpyHostToDevice, s));
+    time_embed_kernel<<<(n * (d / 2) + 255) / 256, 256, 0, s>>>(reinterpret_cast<const int64_t*>(tt.p), c->time_freq.f(), te.f(), n, d / 2);
+    CHK(launch_skinny(te.f(), d, W32(c, "time_mlp.1.weight"), d, W32(c, "time_mlp.1.bias"), th.f(), 4 * d, n, 4 * d, d, ACT_MISH, s));
+    CHK(buf_alloc(c->tct_table, (size_t)n * 3 * d * 4));
+    CHK(launch_skinny(th.f(), 4 * d, c->tct_w.f(), 4 * d, c->tct_b.f(), c->tct_table.f(), 3 * d, n, 3 * d, 4 * d, ACT_NONE, s));
+    HIPCHK(hipStreamSynchronize(s));   // (tv is host memory; the temporaries go back)
+    buf_free(tt); buf_free(te); buf_free(th);
+    c->tct_rows = n;
+  }
   // slot 0 of the caches: the unconditional branch is batch- and input-invariant
   HIPCHK(d2d(c->hidden.p, W32(c, "null_cond_hidden"), (size_t)d * 4));
   {

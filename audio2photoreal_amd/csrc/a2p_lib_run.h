@@ -225,6 +225,24 @@ static int chain_build_streams(a2p_ctx* c, hipStream_t s) {
       aux.push_back({W32(c, "final_layer.bias"), c->C});
     }
     CHK(chain_pack(c, ch_index(l, CH_POST), q, aux, s));
+    if (v4 && l == 0 && c->tail_x3 && c->C == 256 && c->Cpad == 256) {
+      // CHAIN_IN: input_projection as a split-operand island (split weight rows [W_hi | W_hi | W_lo], 256 k each: hi x W_hi, lo x W_hi, hi x W_lo over the four output
+      // tiles, k-chunk-major) followed by layer 0's PRE work ([Q|K] and V in groups of four tiles, as behind a POST kernel)
+      std::vector<ChainPackDesc> in4;
+      const void* wi = c->wt.at("input_projection.weight").p;
+      pk4_gemm(in4, wi, 3 * c->Cpad, d, 0, c->Cpad, 0, 4);
+      pk4_gemm(in4, wi, 3 * c->Cpad, d, 0, c->Cpad, 0, 4);
+      pk4_gemm(in4, wi, 3 * c->Cpad, d, 2 * c->Cpad, c->Cpad, 0, 4);
+      const Buf& inw = c->wt.at(pf(0) + "self_attn.in_proj_weight");
+      pk4_gemm(in4, inw.p, d, 2 * d, 0, d, 1, 4);
+      pk4_gemm(in4, c->offT(inw, (int64_t)2 * d * d), d, d, 0, d, 1, 4);
+      CHK(chain4_pack(c, c->ch_stream4_in, in4, s));
+      CHK(buf_alloc(c->ch_aux_in, 2560 * 4 + 1024));   // [input_projection.bias 512 | 512 unused | in_proj_bias 1536]: the offsets of a POST kernel's aux block
+      HIPCHK(hipMemsetAsync(c->ch_aux_in.p, 0, 2560 * 4 + 1024, s));
+      HIPCHK(hipMemcpyAsync(c->ch_aux_in.f(), W32(c, "input_projection.bias"), (size_t)d * 4, hipMemcpyDeviceToDevice, s));
+      HIPCHK(hipMemcpyAsync(c->ch_aux_in.f() + 1024, W32(c, pf(0) + "self_attn.in_proj_bias"), (size_t)3 * d * 4, hipMemcpyDeviceToDevice, s));
+      HIPCHK(hipStreamSynchronize(s));
+    }
     if (v4) {   // the same chains for kernels_chain4.h (MID; POST of every layer that has a successor)
       std::vector<ChainPackDesc> m4;
       pk4_gemm(m4, c->wt.at(pf(l) + "self_attn.out_proj.weight").p, d, d, 0, d, 0, 4);
@@ -480,6 +498,32 @@ static int launch_chain4(a2p_ctx* c, int mode, const ChainP& p0, hipStream_t s) 
   return 0;
 }
 
+// input_projection + layer 0's PRE work as ONE tall kernel (chain4_kernel<MT, CHAIN_IN>) instead of pack_input_split3 + gemm_kernel + the gen-1 PRE kernel.
+// Face model with split-operand islands, 256 input features, the 8-wave shape, clips of >= 80 frames (a multiple of 8), and one set of rows for the whole pass
+// (no guidance, or guidance with the shared layer-0 half).  A2P_CHAIN_V=1 keeps the gen-1 launches.
+static bool chain_in_wanted(const a2p_ctx* c, int T, bool rows_shared) {
+#ifdef A2P_STAMPS
+  return false;
+#else
+  return c->ch_stream4_in.p && c->opt.chain_v != 1 && !c->opt.no_fused_in && c->d == 512 && !c->pose && c->tail_x3 && c->C == 256 && c->ch_nw == 8 &&
+         (T & 7) == 0 && T >= 80 && rows_shared;
+#endif
+}
+static int launch_chain_in(a2p_ctx* c, const ChainP& p0, hipStream_t s) {
+  ChainP p = p0;
+  const int mt = chain4_pick_mt(c, p.M);
+  p.stream = reinterpret_cast<const h16_t*>(c->ch_stream4_in.p);
+  const int grid = (p.M + 16 * mt - 1) / (16 * mt);
+  ++c->ch4_launches;
+  ++c->in4_launches;
+  KernelTimer kt(c, A2P_KERNEL_CHAIN, A2P_KERNEL_CHAIN_PRE);
+  if (mt == 3) A2P_LAUNCH(kt, (chain4_kernel<3, CHAIN_IN>), grid, 512, s, p);
+  else if (mt == 4) A2P_LAUNCH(kt, (chain4_kernel<4, CHAIN_IN>), grid, 512, s, p);
+  else A2P_LAUNCH(kt, (chain4_kernel<5, CHAIN_IN>), grid, 512, s, p);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
 static int launch_chain(a2p_ctx* c, int mode, const ChainP& p, hipStream_t s) {
   if (chain4_wanted(c, mode, p)) return launch_chain4(c, mode, p, s);
   const bool env_mt = c->opt.chain_mt != 0;  // tuning / test override of the panel height (rows = 16 * MT)
@@ -623,7 +667,7 @@ static int launch_cross_attention(a2p_ctx* c, int N, int T, const CrossKV& kv, h
 // kernel of the second half reads the first half's rows (ChainP::src_rows)
 static int decoder_layer_chain(a2p_ctx* c, int l, int N, int T, const CrossKV& kv, const CrossKV* kv2, const FilmRef& fr, bool first,
                                bool has_next, hipStream_t s, hipEvent_t film_ready = nullptr, bool fuse_final = false,
-                               bool shared_half = false, bool* fused_x3 = nullptr) {
+                               bool shared_half = false, bool* fused_x3 = nullptr, const float* x_in_fused = nullptr) {
   const int d = c->d;
   const std::string pf = "seqTransDecoder.stack." + std::to_string(l) + ".";
   ChainP p;
@@ -639,7 +683,14 @@ static int decoder_layer_chain(a2p_ctx* c, int l, int N, int T, const CrossKV& k
     chain_base(c, p, Nsa, T, ch_index(l, CH_PRE), 3 * d);
     chain_set_pre(c, p, l, T);
     if (x0) p.x = x0;
-    CHK(launch_chain(c, CHAIN_PRE, p, s));
+    if (x_in_fused) {   // input_projection inside the kernel: the rows it computes are stored (row-major) where the GEMM left them
+      p.xin = x_in_fused; p.xin_C = c->C;
+      p.aux = c->ch_aux_in.f(); p.aux_kb = 10;
+      p.x_in_tiled = 0; p.x_out_tiled = 0;
+      CHK(launch_chain_in(c, p, s));
+    } else {
+      CHK(launch_chain(c, CHAIN_PRE, p, s));
+    }
   }
   if (film_ready && join_at == 2) HIPCHK(hipStreamWaitEvent(s, film_ready, 0));
   CHK(launch_self_attention(c, Nsa, T, s));
@@ -875,11 +926,18 @@ extern "C" int a2p_prepare_cond(a2p_ctx* c, const float* cond_embed, int32_t B, 
 // ------------------------------------------------------------------------------------------------
 static int time_path(a2p_ctx* c, const int64_t* t_orig, int N, const int* slots, hipStream_t s, bool embed = true) {
   const int d = c->d, B = c->pB, L = c->L, F = c->F;
-  if (embed) time_embed_kernel<<<(B * (d / 2) + 255) / 256, 256, 0, s>>>(t_orig, c->time_freq.f(), c->emb.f(), B, d / 2);
-  CHK(launch_skinny(c->emb.f(), d, W32(c, "time_mlp.1.weight"), d, W32(c, "time_mlp.1.bias"), c->th.f(), 4 * d, B, 4 * d, d, ACT_MISH, s));
-  CHK(launch_skinny(c->th.f(), 4 * d, c->tct_w.f(), 4 * d, c->tct_b.f(), c->tct.f(), 3 * d, B, 3 * d, 4 * d, ACT_NONE, s));
+  // time_embed -> time_mlp -> [to_time_cond ; to_time_tokens] depend on the timestep VALUE alone: a row of the table built at a2p_finalize_weights (same kernels, same bits)
+  // where there is one and this call may read the caller's timestep tensor (not under graph replay); three launches otherwise
+  const bool table = embed && c->tct_rows > 0 && c->opt.time_table > 0;
+  if (!table) {
+    if (embed) time_embed_kernel<<<(B * (d / 2) + 255) / 256, 256, 0, s>>>(t_orig, c->time_freq.f(), c->emb.f(), B, d / 2);
+    CHK(launch_skinny(c->emb.f(), d, W32(c, "time_mlp.1.weight"), d, W32(c, "time_mlp.1.bias"), c->th.f(), 4 * d, B, 4 * d, d, ACT_MISH, s));
+    CHK(launch_skinny(c->th.f(), 4 * d, c->tct_w.f(), 4 * d, c->tct_b.f(), c->tct.f(), 3 * d, B, 3 * d, 4 * d, ACT_NONE, s));
+  }
   TPathP tp;
-  tp.tct = c->tct.f(); tp.hidden = c->hidden.f(); tp.slot = slots; tp.tvec = c->tvec.f(); tp.mt = c->mt.f();
+  memset(&tp, 0, sizeof(tp));
+  tp.tct = table ? c->tct_table.f() : c->tct.f();
+  tp.trow = table ? t_orig : nullptr; tp.trows = c->tct_rows; tp.err = reinterpret_cast<int*>(c->nonfinite.p); tp.hidden = c->hidden.f(); tp.slot = slots; tp.tvec = c->tvec.f(); tp.mt = c->mt.f();
   tp.gamma = W32(c, "norm_cond.weight"); tp.beta = W32(c, "norm_cond.bias"); tp.cs = (const float2*)c->rope_cs.p;
   tp.tok_n = c->tokn.f(); tp.tok_r = c->tokr.f(); tp.B = B; tp.nseq = N; tp.d = d; tp.pos0 = c->pS0;
   if (d == 512) tpath_post_kernel<8><<<N + B, 256, 0, s>>>(tp);
@@ -970,8 +1028,17 @@ static int forward_body(a2p_ctx* c, const float* x_in, const int64_t* t_orig, in
   } else {
     CHK(time_path(c, t_orig, N, slots, s, ext));
   }
-  // input permute + projection (model/diffusion.py:345-346,364); exact fp32 in every mode (a2p_ctx::tail32)
-  {
+  hipEvent_t tune0 = nullptr, tune1 = nullptr;
+  if (use_chain) {   // (in front of the input projection: chain_in_wanted needs the workgroup shape; the calibration's timed region now includes the projection)
+    c->ch_nw = chain_pick_nw(c, (int64_t)N * T, &tune0, &tune1);
+    if (!tune0) chain_pick_family(c, (int64_t)N * T, &tune0, &tune1);   // (one calibration at a time)
+    else c->ch_fam_mid = c->ch_fam_post = 1;
+    if (tune0) HIPCHK(hipEventRecord(tune0, s));
+  }
+  // input permute + projection (model/diffusion.py:345-346,364); exact fp32 in every mode (a2p_ctx::tail32).
+  // Chain forwards of the face model: inside the first chain kernel (chain4_kernel<MT, CHAIN_IN>: decoder_layer_chain), nothing to launch here.
+  const bool fuse_in = use_chain && ext && chain_in_wanted(c, T, N == B || (N == 2 * B && !c->opt.no_shared_half));
+  if (!fuse_in) {
     Fp32Scope f32(c, c->tail32 && !c->tail_x3);
     dim3 grid((T + 31) / 32, (c->Cpad + 31) / 32, B);
     const int X = c->tail_x3 ? 3 : 1;
@@ -995,13 +1062,6 @@ static int forward_body(a2p_ctx* c, const float* x_in, const int64_t* t_orig, in
                                                              reinterpret_cast<float4*>(c->x.f() + (size_t)B * T * d), n4);
     }
   }
-  hipEvent_t tune0 = nullptr, tune1 = nullptr;
-  if (use_chain) {
-    c->ch_nw = chain_pick_nw(c, (int64_t)N * T, &tune0, &tune1);
-    if (!tune0) chain_pick_family(c, (int64_t)N * T, &tune0, &tune1);   // (one calibration at a time)
-    else c->ch_fam_mid = c->ch_fam_post = 1;
-    if (tune0) HIPCHK(hipEventRecord(tune0, s));
-  }
   CrossKV kv, kv2;
   bool fused_x3 = false;
   for (int l = 0; l < L; ++l) {
@@ -1022,7 +1082,7 @@ static int forward_body(a2p_ctx* c, const float* x_in, const int64_t* t_orig, in
     fr.seq_stride = (int64_t)L * F * 2 * d;
     if (use_chain)
       CHK(decoder_layer_chain(c, l, N, T, kv, c->pose ? &kv2 : nullptr, fr, l == 0, l + 1 < L, s, (overlap_tpath && l == 0) ? c->ev_join : nullptr,
-                              /*fuse_final=*/!c->pose && !c->tail32, /*shared_half=*/l == 0 && N == 2 * B && !c->opt.no_shared_half, &fused_x3));
+                              /*fuse_final=*/!c->pose && !c->tail32, /*shared_half=*/l == 0 && N == 2 * B && !c->opt.no_shared_half, &fused_x3, (l == 0 && fuse_in) ? x_in : nullptr));
     else if (use_small) CHK(decoder_layer_small(c, l, N, T, kv, fr, s, (overlap_tpath && l == 0) ? c->ev_join : nullptr));
     else CHK(decoder_layer(c, l, N, T, kv, c->pose ? &kv2 : nullptr, fr, s));
   }
@@ -1228,6 +1288,11 @@ extern "C" int a2p_check_finite(a2p_ctx* c, void* stream) {
   HIPCHK(hipStreamSynchronize(s));
   if (!flag) return 0;
   HIPCHK(hipMemsetAsync(c->nonfinite.p, 0, sizeof(int), s));
+  if (flag & 4) {
+    set_err("a denoiser evaluation since the last check had a timestep outside [0, %d): the time-MLP table (a2p_finalize_weights) covers the reference's diffusion_steps; "
+            "set A2P_TIME_TABLE=<rows> before loading the weights, or A2P_TIME_TABLE=0 to compute the time MLP in every forward", c->tct_rows);
+    return A2P_ERR_ARG;
+  }
   set_err("a denoiser evaluation since the last check produced inf / nan outputs (%s operands): the activations of this checkpoint "
           "leave the operand format's range, or the inputs / weights were not finite.  precision=\"bf16\" has fp32's range, "
           "precision=\"fp32\" is the parity mode",
@@ -1474,6 +1539,11 @@ extern "C" int a2p_debug_read(a2p_ctx* c, const char* name, void* host, int64_t 
   if (n == "attn3_launches") {   // int64: launches of attn3_kernel (kernels_attn3.h) on this context so far (tests, bench)
     ARG(bytes >= 8, "attn3_launches is one int64");
     *reinterpret_cast<int64_t*>(host) = c->attn3_launches;
+    return 0;
+  }
+  if (n == "chain_in_launches") {   // int64: launches of chain4_kernel<MT, CHAIN_IN> (input_projection + layer 0's PRE work) so far (tests)
+    ARG(bytes >= 8, "chain_in_launches is one int64");
+    *reinterpret_cast<int64_t*>(host) = c->in4_launches;
     return 0;
   }
   if (n == "final_fused_launches") {   // int64: last-layer tall POST kernels that computed final_layer as a split-operand island (tests)

@@ -52,7 +52,7 @@
 // OFF in this header and every fused multiply-add is written as an explicit fmaf.
 #pragma clang fp contract(off)
 
-enum { CHAIN_PRE = 0, CHAIN_MID = 1, CHAIN_POST = 2, CHAIN_MIDPOST = 3 };
+enum { CHAIN_PRE = 0, CHAIN_MID = 1, CHAIN_POST = 2, CHAIN_MIDPOST = 3, CHAIN_IN = 4 };   // CHAIN_IN (kernels_chain4.h only): input_projection + layer 0's PRE work
 // CHAIN_MIDPOST (round 4, body model): MID work of the audio cross attention's output -> the KEYFRAME cross attention
 // (multihead_attn2: <= 32 keys per sequence, transformer_modules.py:206-215) inside the kernel, on the query panel in LDS -> POST
 // work.  One launch where MID2 | attention | POST were three: the residual rows stay in registers, the query never leaves the CU,
@@ -126,6 +126,8 @@ struct ChainP {
   float* fin_out;
   int64_t ld_fin;
   int fin_n;
+  const float* xin;       // kernels_chain4.h CHAIN_IN: the noisy input [B][xin_C][rows_per_seq] fp32 (model/diffusion.py:345-346: permuted and projected inside the kernel)
+  int xin_C;
   int fin_x3;             // kernels_chain4.h, last layer, <= 64 rows: final_layer as a split-operand exact island (stream: [W_hi | W_hi | W_lo]) into fin_out [m][ld_fin]; bias in aux after bias_1
   // diagnostic (A2P_CHAIN_CLK=1): blocks 0..7 write {s_memtime, s_memrealtime} at kernel begin / end to clk[block][2][2]: the
   // shader clock the kernel actually ran at inside the step (DVFS) = d(memtime) / d(memrealtime @ 100 MHz)

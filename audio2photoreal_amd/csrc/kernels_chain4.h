@@ -286,12 +286,14 @@ __device__ __forceinline__ void chain4_body(const ChainP& p, h16_t* const smem, 
 
   // ---- kernel start: attention-output panel + aux + epilogue operands by LDS-DMA, weight ring primed ---------------------
   {
-    for (int r0 = wid; r0 < BM; r0 += NW) {   // one 1 KiB row per wave instruction
-      int m = m0 + r0;
-      m = m < p.M ? m : p.M - 1;
-      m = (p.src_rows > 0 && m >= p.src_rows) ? m - p.src_rows : m;
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(p.ain + (int64_t)m * p.ld_ain + ((lane ^ (r0 & 15)) << 3)),
-                                       (__attribute__((address_space(3))) void*)(panelA + r0 * D), 16, 0, 0);
+    if constexpr (MODE != CHAIN_IN) {
+      for (int r0 = wid; r0 < BM; r0 += NW) {   // one 1 KiB row per wave instruction
+        int m = m0 + r0;
+        m = m < p.M ? m : p.M - 1;
+        m = (p.src_rows > 0 && m >= p.src_rows) ? m - p.src_rows : m;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(p.ain + (int64_t)m * p.ld_ain + ((lane ^ (r0 & 15)) << 3)),
+                                         (__attribute__((address_space(3))) void*)(panelA + r0 * D), 16, 0, 0);
+      }
     }
     for (int kb = wid; kb < p.aux_kb; kb += NW) chain_glds16(p.aux + kb * 256 + lane * 4, aux + kb * 256);
     if (tid < LY::FLAG_F) flags[tid] = 0u;
@@ -299,6 +301,7 @@ __device__ __forceinline__ void chain4_body(const ChainP& p, h16_t* const smem, 
     const int nseq = p.M / p.rows_per_seq;
     const int seqB = seqA + 1 < nseq ? seqA + 1 : seqA;
     for (int q = wid; q < 28; q += NW) {
+      if (MODE == CHAIN_IN && (q < 8 || q >= 12)) continue;   // (norm-B gamma / beta only: no attention output, no FiLM in front of layer 0)
       const float* src;
       int dst;
       if (q < 12) {   // six 512-float vectors, two pieces each
@@ -319,6 +322,36 @@ __device__ __forceinline__ void chain4_body(const ChainP& p, h16_t* const smem, 
 #pragma unroll
   for (int i = 0; i < PF; ++i) w_issue(i);
   w_primed = true;
+  if constexpr (MODE == CHAIN_IN) {
+    // The noisy input x [B][256][T] (model/diffusion.py:345-346: permute to [T][256]) as the split operand panel [BM][hi 256 | lo 256] over the A panel: wave w takes
+    // channels 32 w .. 32 w + 31, lane = panel row (consecutive frames: each load instruction reads BM contiguous floats of one channel).  What pack_input_split3_kernel
+    // wrote to HBM for gemm_kernel to read back.
+    for (int r0 = 0; r0 < BM; r0 += 64) {
+      const int r = r0 + lane;
+      if (r < BM) {
+        int m = m0 + r;
+        m = m < p.M ? m : p.M - 1;
+        const int b = m / p.rows_per_seq, tpos = m - b * p.rows_per_seq;
+        const float* src = p.xin + ((int64_t)b * p.xin_C + wid * 32) * p.rows_per_seq + tpos;
+        float v[32];
+#pragma unroll
+        for (int j = 0; j < 32; ++j) v[j] = src[(int64_t)j * p.rows_per_seq];
+#pragma unroll
+        for (int jp = 0; jp < 4; ++jp) {
+          h16x8 hi, lo;
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            const float xv = v[jp * 8 + e];
+            hi[e] = (h16_t)xv;
+            lo[e] = (h16_t)(xv - (float)hi[e]);
+          }
+          const int q = wid * 4 + jp;   // 16-byte piece of the row's hi half; the lo half starts 32 pieces further; pieces are XOR-swizzled inside groups of 16 (the fragment reads' layout)
+          *reinterpret_cast<h16x8*>(panelA + r * D + (((q & ~15) | ((q & 15) ^ (r & 15))) << 3)) = hi;
+          *reinterpret_cast<h16x8*>(panelA + r * D + ((((q + 32) & ~15) | ((q & 15) ^ (r & 15))) << 3)) = lo;
+        }
+      }
+    }
+  }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the DMA pieces have landed for this wave (once per kernel: the ring's first loads too)
   chain_bar();                                        // ... and for every other wave
   stamp(1);
@@ -547,19 +580,40 @@ __device__ __forceinline__ void chain4_body(const ChainP& p, h16_t* const smem, 
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) R[t][mt] = f32x4{0.f, 0.f, 0.f, 0.f};
   __builtin_amdgcn_sched_barrier(0);
-  gemm(std::integral_constant<int, NT>{}, std::integral_constant<int, KC>{}, std::integral_constant<int, D>{}, R, panelA, false);   // out_proj of the attention that produced `ain`
-  __builtin_amdgcn_sched_barrier(0);
-  stamp(2);
-  film_res(R, E4_BIAS_O, E4_FILM_O, p.xsrc ? p.xsrc : p.x, p.x_in_tiled, true);
-  stamp(3);
+  if constexpr (MODE == CHAIN_IN) {
+    // input_projection (model/diffusion.py:364) as a split-operand exact island: x = hi + lo, rows = hi W_hi^T + lo W_hi^T + hi W_lo^T + bias, in gemm_kernel's k order
+    // (the stream carries [W_hi | W_hi | W_lo], 256 k each, four tiles k-chunk-major), accumulators from zero, the bias last: the bits of pack_input_split3 + gemm_kernel.
+    gemm(std::integral_constant<int, NT>{}, std::integral_constant<int, KC / 2>{}, std::integral_constant<int, D>{}, R, panelA, false);
+    __builtin_amdgcn_sched_barrier(0);
+    gemm(std::integral_constant<int, NT>{}, std::integral_constant<int, KC / 2>{}, std::integral_constant<int, D>{}, R, panelA + D / 2, false);
+    __builtin_amdgcn_sched_barrier(0);
+    gemm(std::integral_constant<int, NT>{}, std::integral_constant<int, KC / 2>{}, std::integral_constant<int, D>{}, R, panelA, false);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      const f32x4 b = *reinterpret_cast<const f32x4*>(aux + col_of(t));
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) R[t][mt] += b;
+    }
+    chain_bar();   // every wave is done reading the input panel (the LayerNorm below rewrites it)
+    stamp(2);
+  } else {
+    gemm(std::integral_constant<int, NT>{}, std::integral_constant<int, KC>{}, std::integral_constant<int, D>{}, R, panelA, false);   // out_proj of the attention that produced `ain`
+    __builtin_amdgcn_sched_barrier(0);
+    stamp(2);
+    film_res(R, E4_BIAS_O, E4_FILM_O, p.xsrc ? p.xsrc : p.x, p.x_in_tiled, true);
+    stamp(3);
+  }
   // POST kernels that park their rows around the feed-forward block: the store leaves here, in front of the LayerNorm (see the second park below for why)
   constexpr bool PARK_FFN = MODE == CHAIN_POST && (MT >= 4 || CHAIN4_PARK3);
   if constexpr (PARK_FFN) {
     if (!p.x_in_tiled) chain_bar();   // (parked in the tiled layout: with a row-major predecessor layout -- A/B only -- other lanes' unread bytes lie under the store)
     store_x(R, 1);
   }
-  ln_stats(R);   // (its barriers also order the panel rewrite behind every wave's out_proj reads)
-  stamp(4);
+  if constexpr (MODE != CHAIN_IN) {
+    ln_stats(R);   // (its barriers also order the panel rewrite behind every wave's out_proj reads)
+    stamp(4);
+  }
   if constexpr (MODE == CHAIN_MID) {
     ln_write(R, E4_LNA_G, Tt);
     stamp(5);
@@ -572,6 +626,7 @@ __device__ __forceinline__ void chain4_body(const ChainP& p, h16_t* const smem, 
     // per lane that the linear2 partials / the four-tile groups need.  At 48 rows they stay in registers from load to the final
     // store (X), as in kernels_chain.h: no extra traffic, and no store in front of a GEMM's weight loads.
     constexpr bool PARK = MT >= 4 || CHAIN4_PARK3;   // (64 rows without parking: 91 registers spilled)
+    if constexpr (MODE != CHAIN_IN) {   // (CHAIN_IN: the rows just computed go straight to layer 0's PRE work below)
     ln_write(R, E4_LNA_G, F);
     [[maybe_unused]] f32x4 X[PARK ? 1 : NT][PARK ? 1 : MT];
     // (parked in the tiled layout whatever the final layout is: a 16-row block occupies the same bytes in both, and the workgroup owns
@@ -783,6 +838,7 @@ __device__ __forceinline__ void chain4_body(const ChainP& p, h16_t* const smem, 
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       return;
     }
+    }   // MODE != CHAIN_IN
     // next layer's PRE work: norm1 -> rotary -> [Q|K] ; norm1 -> V^T     (aux: bias_qk right behind bias_1, then bias_v)
     // Parked kernels: the finished rows leave HERE, in front of the LayerNorm, not behind it (their registers are free during the [Q|K] GEMM either way).
     // Every store sits in front of the weight ring's next loads in the in-order vmcnt queue, and this one is 2 KiB per row from every workgroup at once:

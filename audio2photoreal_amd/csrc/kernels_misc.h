@@ -223,7 +223,21 @@ struct TPathP {
   float* tok_n;         // [B*2, d]
   float* tok_r;         // [B*2, d]
   int B, nseq, d, pos0; // pos0 = number of audio tokens (time tokens sit at pos0, pos0+1)
+  // Time-MLP table (a2p_ctx::tct_table): tct holds one row per TIMESTEP VALUE 0 .. trows-1 (time_embed -> time_mlp -> to_time_cond | to_time_tokens depend on t alone),
+  // trow[b] = sample b's timestep selects the row.  A timestep outside the table sets bit 2 of *err (a2p_check_finite reports it) and reads row 0 / trows-1.
+  const int64_t* trow;
+  int trows;
+  int* err;
 };
+__device__ __forceinline__ int64_t tpath_row(const TPathP& p, int b) {
+  if (!p.trow) return b;
+  int64_t t = p.trow[b];
+  if (t < 0 || t >= p.trows) {
+    if (threadIdx.x == 0 && p.err) atomicOr(p.err, 4);
+    t = t < 0 ? 0 : p.trows - 1;
+  }
+  return t;
+}
 
 template <int NPL>  // d / 64: 8 (face) or 4 (pose) contiguous features per lane in the token part
 __global__ __launch_bounds__(256) void tpath_post_kernel(TPathP p) {
@@ -232,8 +246,9 @@ __global__ __launch_bounds__(256) void tpath_post_kernel(TPathP p) {
   const int blk = blockIdx.x;
   if (blk < p.nseq) {  // t vector of one sequence
     const int n = blk, b = n % p.B, sl = p.slot[n];
+    const int64_t tr = tpath_row(p, b);
     for (int c = threadIdx.x; c < d; c += 256) {
-      const float v = p.tct[(int64_t)b * 3 * d + c] + p.hidden[(int64_t)sl * d + c];
+      const float v = p.tct[tr * 3 * d + c] + p.hidden[(int64_t)sl * d + c];
       p.tvec[(int64_t)n * d + c] = v;
       p.mt[(int64_t)n * d + c] = act_mish(v);
     }
@@ -242,7 +257,7 @@ __global__ __launch_bounds__(256) void tpath_post_kernel(TPathP p) {
   // time tokens of one sample: waves 0,1 -> token 0,1
   const int b = blk - p.nseq;
   if (wid >= 2) return;
-  const float* src = p.tct + (int64_t)b * 3 * d + d + wid * d;
+  const float* src = p.tct + tpath_row(p, b) * 3 * d + d + wid * d;
   const int row = b * 2 + wid, pos = p.pos0 + wid;
   // The rotary (cos, sin) pairs are fetched first and pinned in registers: they are not consumed until after both
   // LayerNorm reductions, so the loads have long landed by then.  (With the fetch next to its first use, the first VALU

@@ -72,7 +72,7 @@ def test_face_guided_forward_at_the_benchmarked_batch_vs_oracle_tall_kernels(dev
         e = {"rel_l2": rel_l2(got, want), "max_norm": rel_max(got, want), "worst_sample_rel_l2": _worst_sample(got, want)}
         record(f"oracle_at_bench_batch/face_B{B}_{rows}row/{precision}", tall_launches=launched, **e)
         if precision != "fp32":                               # fp32 parity mode runs the per-op exact-fp32 kernels, not the chain kernels
-            assert launched == 16, launched
+            assert launched == 17, launched                   # 8 MID + 8 POST + the input projection / PRE kernel of layer 0
             assert fused_final == 1, fused_final             # the last POST kernel computes final_layer too (split-operand island inside the kernel)
         assert e["rel_l2"] < tol and e["worst_sample_rel_l2"] < tol * (1.0 if precision == "fp32" else 1.5), e
 
@@ -114,6 +114,73 @@ def test_final_layer_inside_the_last_post_kernel_is_bit_identical(dev, B, T, mt,
     assert diff == 0.0, diff
 
 
+@pytest.mark.parametrize("precision", ["fp16", "bf16"])
+@pytest.mark.parametrize("B,T,mt,guided", [(8, 600, 0, True), (3, 208, 4, True), (2, 88, 3, True), (16, 600, 0, True), (2, 328, 5, True), (3, 600, 0, False)])
+def test_input_projection_inside_the_first_chain_kernel_is_bit_identical(dev, B, T, mt, guided, precision, monkeypatch):
+    """model/diffusion.py:345-346,364 (permute + input_projection) and layer 0's PRE work (norm1 -> rotary -> [Q|K], V^T) as ONE tall kernel (chain4_kernel<MT, CHAIN_IN>: the
+    noisy input is read in its [B, C, T] layout, split into hi / lo 16-bit panels in LDS, projected as a split-operand island in gemm_kernel's k order, the rows stored once and
+    normalised from registers) against the three launches it replaces (pack_input_split3_kernel, gemm_kernel, the gen-1 PRE kernel; A2P_NO_FUSED_IN=1): the SAME BITS for 48- /
+    64- / 80-row panels, ragged last panels, panels that straddle two samples, with guidance (shared layer-0 half) and without (one conditional pass)."""
+    spec = face_spec()
+    inp = synthetic_inputs(spec, B, T, SEED)
+    model, _ = create_model_and_diffusion(default_args("face"), "test", precision=precision, max_batch=B)
+    load_model(model, synthetic_state_dict(spec, SEED))
+    model = model.to(dev).eval()
+    fwd = ClassifierFreeSampleModel(model) if guided else model
+    y = {"cond_embed": inp["cond_embed"].to(dev), "scale": torch.full((B,), 10.0, device=dev)}
+    t = torch.tensor(([901, 417, 33, 650] * 4)[:B], device=dev)
+    monkeypatch.setenv("A2P_CHAIN_V", "4")
+    if mt:
+        monkeypatch.setenv("A2P_CHAIN_MT", str(mt))
+    if (2 if guided else 1) * B * T < 1100:
+        monkeypatch.setenv("A2P_CHAIN_ROWS", "1")
+    outs, fused = {}, {}
+    for name, flag in (("fused", None), ("launches", "1")):
+        if flag:
+            monkeypatch.setenv("A2P_NO_FUSED_IN", flag)
+        before = _debug_i64(model, b"chain_in_launches") if model._ctx is not None else 0
+        outs[name] = fwd(inp["x_T"].to(dev), t, y).cpu()
+        fused[name] = _debug_i64(model, b"chain_in_launches") - before
+    for k in ("A2P_CHAIN_V", "A2P_CHAIN_MT", "A2P_CHAIN_ROWS", "A2P_NO_FUSED_IN"):
+        monkeypatch.delenv(k, raising=False)
+    model.check_finite()
+    model.release()
+    assert fused == {"fused": 1, "launches": 0}, fused
+    assert torch.isfinite(outs["fused"]).all()
+    diff = float((outs["fused"] - outs["launches"]).abs().max())
+    record(f"fused_input_vs_launches/B{B}_T{T}_mt{mt}_{'cfg' if guided else 'cond'}/{precision}", max_abs_diff=diff)
+    assert diff == 0.0, diff
+
+
+@pytest.mark.parametrize("fmt", ["face", "pose"])
+def test_time_mlp_table_gives_the_bits_of_the_per_forward_time_mlp(dev, fmt, monkeypatch):
+    """model/diffusion.py:349-353 (time_mlp -> to_time_cond / to_time_tokens) depends on the timestep VALUE alone: a2p_finalize_weights tabulates it for t = 0 .. 999 with the kernels
+    that otherwise run in every forward, and tpath_post_kernel picks sample b's row by t[b].  Same bits as the three launches (A2P_TIME_TABLE=0), for mixed timesteps in one batch;
+    a timestep outside the table is REPORTED by check_finite (never silently clamped)."""
+    from audio2photoreal_amd._lib import A2PError
+    spec = face_spec() if fmt == "face" else pose_spec()
+    B, T = 3, 208
+    inp = synthetic_inputs(spec, B, T, SEED)
+    model, _ = create_model_and_diffusion(default_args(fmt), "test", precision="fp16", max_batch=B)
+    load_model(model, synthetic_state_dict(spec, SEED))
+    cfg = ClassifierFreeSampleModel(model.to(dev).eval())
+    y = {"cond_embed": inp["cond_embed"].to(dev), "scale": torch.full((B,), 10.0 if fmt == "face" else 2.0, device=dev)}
+    if spec.is_pose:
+        y["keyframes"], y["mask"] = inp["keyframes"].to(dev), inp["mask"].to(dev)
+    t = torch.tensor([999, 0, 417], device=dev)
+    x = inp["x_T"].to(dev)
+    table = cfg(x, t, y).cpu()
+    monkeypatch.setenv("A2P_TIME_TABLE", "0")
+    computed = cfg(x, t, y).cpu()
+    monkeypatch.delenv("A2P_TIME_TABLE", raising=False)
+    model.check_finite()
+    assert torch.isfinite(table).all() and torch.equal(table, computed), float((table - computed).abs().max())
+    cfg(x, torch.tensor([1000, 3, 4], device=dev), y)
+    with pytest.raises(A2PError, match="timestep outside"):
+        model.check_finite()
+    model.release()
+
+
 def test_last_layer_takes_the_tall_fused_kernel_under_the_mixed_family(dev, monkeypatch):
     """On the slow GPU type the in-situ calibration keeps the gen-1 POST kernels (family 41: tall MID, gen-1 POST).  The LAST layer's POST kernel is tall regardless -- with
     final_layer inside it replaces three launches -- and the result is the same bits as the all-tall forward: 8 tall MID + 1 tall POST launches, one fused final_layer."""
@@ -135,7 +202,7 @@ def test_last_layer_takes_the_tall_fused_kernel_under_the_mixed_family(dev, monk
     monkeypatch.delenv("A2P_CHAIN_V", raising=False)
     model.check_finite()
     model.release()
-    assert tall == {"4": 16, "41": 9} and fused == {"4": 1, "41": 1}, (tall, fused)
+    assert tall == {"4": 17, "41": 10} and fused == {"4": 1, "41": 1}, (tall, fused)   # (8 MID + 8 | 1 POST + the input / PRE kernel of layer 0)
     assert torch.equal(outs["4"], outs["41"])
 
 
