@@ -23,6 +23,12 @@
 //     tiles (8 waves each read every panel row: the LDS port is the second roof of these phases) and the pair is what the paired
 //     column map writes as 64-byte runs anyway.
 //
+// Round 6 (docs/lab_notebook_r6.md sections 12-14), each bit-identical to what it replaces:
+//   * THE FEED-FORWARD BLOCK HAS NO WORKGROUP BARRIER (CHAIN4_FFN_PIPE): per-chunk LDS counters, two chunk buffers (the second over LDS that is dead during the block), the
+//     two waves of a SIMD one chunk apart so that one computes the GELU while the other issues MFMAs; the stream is packed per wave group.
+//   * LAST = 2: final_layer (model/diffusion.py:397) inside the last decoder layer's POST kernel, as a split-operand exact island on the rows in registers.
+//   * MODE = CHAIN_IN: input permute + input_projection (model/diffusion.py:345-346,364) + layer 0's PRE work in one launch.
+//
 // One workgroup = 8 waves (two 256-register waves per SIMD) per CU.  Host contract: d = 512, ff = 1024, FiLM present, rows_per_seq
 // >= 16 * MT (a panel touches at most two sequences) and a multiple of 8 (staged V^T store); everything else takes kernels_chain.h.
 #pragma once
