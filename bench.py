@@ -287,6 +287,11 @@ def kernel_breakdown(case, ksteps):
                 "frac": round(kernels[dom]["tflops"] / peak, 4), "traffic": None,
                 "avg_launch_us": kernels[dom]["avg_launch_us"],
                 "algorithmic_gflop_per_launch": round(flops[dom] / 1e9 / kernels[dom]["launches_per_step"], 3)}
+    if dom == "chain" and case.fmt == "face":
+        # since round 6 the first and the last chain launch of a face forward also compute input_projection and final_layer (split-operand islands, three 16-bit products each):
+        # their MFMA work is NOT in the algorithmic figure above, their time IS in the class
+        roofline["note"] = ("the 17 chain launches of a step include input_projection and final_layer (chain4_kernel<MT, CHAIN_IN> / <MT, POST, 2>); "
+                            "only the decoder layers' GEMM flops are counted")
     return kernels, roofline
 
 
