@@ -751,10 +751,11 @@ static int decoder_layer_chain(a2p_ctx* c, int l, int N, int T, const CrossKV& k
     p.aux_kb = (c->ff + c->C + 255) / 256;
   }
   if (!has_next && fused_x3 && !fuse_kf && !fuse_final) {   // the caller wants the MODEL OUTPUT: the tall last-layer kernel computes final_layer too where it can (c->x is NOT updated then)
+    float* const fin_out0 = p.fin_out;   // (the diagnostic build keeps its stamp slots there)
     p.fin_x3 = 1; p.fin_out = c->mo.f(); p.ld_fin = c->C; p.fin_n = c->C;
     p.aux_kb = (c->ff + c->C + 255) / 256;
     *fused_x3 = chain4_final_fused(c, CHAIN_POST, p);
-    if (!*fused_x3) { p.fin_x3 = 0; p.fin_out = nullptr; p.aux_kb = (c->ff + 255) / 256; }
+    if (!*fused_x3) { p.fin_x3 = 0; p.fin_out = fin_out0; p.aux_kb = (c->ff + 255) / 256; }
   }
   return launch_chain(c, fuse_kf ? CHAIN_MIDPOST : CHAIN_POST, p, s);
 }
